@@ -1,0 +1,116 @@
+"""ctypes loaders for the two CPU checkers (test infrastructure only)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SO = os.path.join(HERE, "_ref", "libh4mref.so")
+ORACLE_SO = os.path.join(HERE, "libhvqoracle.so")
+
+# probe column order of ref_decode_clip (matches hvqm4_amd.synth stream indices)
+PROBE_STREAMS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+
+
+def build(target: str = "all") -> None:
+    subprocess.check_call(["make", "-C", HERE, target], stdout=subprocess.DEVNULL)
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+_ref = None
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(REF_SO)
+        lib.ref_decode_clip.restype = C.c_int
+        lib.ref_decode_clip.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        lib.ref_picsize.restype = C.c_uint32
+        lib.ref_picsize.argtypes = [C.c_char_p, C.c_size_t]
+        lib.ref_time_clip.restype = C.c_double
+        lib.ref_time_clip.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
+        lib.ref_buffsize.restype = C.c_uint32
+        lib.ref_buffsize.argtypes = [C.c_uint16, C.c_uint16, C.c_uint8, C.c_uint8]
+        _ref = lib
+    return _ref
+
+
+def ref_decode(data: bytes, n_pictures: int, probe: bool = False):
+    """-> (pictures uint8[n, picsize], probe int32[n, 20] | None) from the compiled reference"""
+    lib = ref()
+    ps = lib.ref_picsize(data, len(data))
+    out = np.zeros((n_pictures, ps), dtype=np.uint8)
+    pr = np.full((n_pictures, 20), -2, dtype=np.int32) if probe else None
+    n = lib.ref_decode_clip(data, len(data), out.ctypes.data, out.nbytes,
+                            pr.ctypes.data if probe else None, n_pictures)
+    if n != n_pictures:
+        raise RuntimeError(f"reference decoded {n} pictures, expected {n_pictures}")
+    return out, pr
+
+
+def ref_time(data: bytes, reps: int) -> Tuple[float, int]:
+    px = C.c_uint64(0)
+    t = ref().ref_time_clip(data, len(data), reps, C.byref(px))
+    return t, px.value
+
+
+_orc = None
+
+
+def oracle():
+    global _orc
+    if _orc is None:
+        if not os.path.exists(ORACLE_SO):
+            build("oracle")
+        lib = C.CDLL(ORACLE_SO)
+        lib.hvqo_create.restype = C.c_void_p
+        lib.hvqo_create.argtypes = [C.c_int] * 5
+        lib.hvqo_destroy.argtypes = [C.c_void_p]
+        lib.hvqo_picsize.restype = C.c_uint32
+        lib.hvqo_picsize.argtypes = [C.c_void_p]
+        lib.hvqo_decode_ipic.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        lib.hvqo_decode_ppic.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]
+        lib.hvqo_decode_bpic.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.hvqo_decode_clip.restype = C.c_int
+        lib.hvqo_decode_clip.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        lib.hvqo_time_clip.restype = C.c_double
+        lib.hvqo_time_clip.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
+        lib.hvqo_weight_block.argtypes = [C.c_void_p] + [C.c_uint8] * 5
+        lib.hvqo_motion_comp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+        lib.hvqo_tables.argtypes = [C.c_void_p, C.c_void_p]
+        lib.hvqo_nest.restype = C.c_void_p
+        lib.hvqo_nest.argtypes = [C.c_void_p]
+        _orc = lib
+    return _orc
+
+
+def clip_picsize(data: bytes) -> int:
+    w = int.from_bytes(data[0x34:0x36], "big")
+    h = int.from_bytes(data[0x36:0x38], "big")
+    ss = data[0x38] * data[0x39]
+    return w * h * (ss + 2) // ss
+
+
+def oracle_decode(data: bytes, n_pictures: int) -> np.ndarray:
+    """-> pictures uint8[n, picsize] (decode order) from this repo's CPU restatement"""
+    lib = oracle()
+    ps = clip_picsize(data)
+    out = np.zeros((n_pictures, ps), dtype=np.uint8)
+    n = lib.hvqo_decode_clip(data, len(data), out.ctypes.data, out.nbytes, n_pictures)
+    if n != n_pictures:
+        raise RuntimeError(f"oracle decoded {n} pictures, expected {n_pictures}")
+    return out
+
+
+def oracle_time(data: bytes, reps: int) -> Tuple[float, int]:
+    px = C.c_uint64(0)
+    t = oracle().hvqo_time_clip(data, len(data), reps, C.byref(px))
+    return t, px.value
