@@ -1,0 +1,75 @@
+"""Batched, device-resident decode path (include/hvqm4_amd.h) -- thin ctypes layer."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+
+from ._lib import HvqStats, check, lib
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        check(lib().hvq_context_create(device, C.byref(self._h)))
+
+    def open_stream(self, width: int, height: int, h_samp: int = 2, v_samp: int = 2, is15: bool = True,
+                    nslots: int = 4) -> int:
+        return check(lib().hvq_stream_open(self._h, width, height, h_samp, v_samp, int(is15), nslots))
+
+    def close_stream(self, sid: int) -> None:
+        check(lib().hvq_stream_close(self._h, sid))
+
+    def submit(self, sid: int, frame_type: int, picture: bytes) -> int:
+        return check(lib().hvq_stream_submit(self._h, sid, frame_type, picture, len(picture)))
+
+    def flush(self) -> None:
+        check(lib().hvq_flush(self._h))
+
+    def sync(self) -> None:
+        check(lib().hvq_sync(self._h))
+
+    def replay(self, reps: int) -> float:
+        ms = C.c_float(0)
+        check(lib().hvq_replay(self._h, reps, C.byref(ms)))
+        return float(ms.value)
+
+    def pic_bytes(self, sid: int) -> int:
+        return int(lib().hvq_stream_pic_bytes(self._h, sid))
+
+    def read_picture(self, sid: int, ordinal: int) -> np.ndarray:
+        out = np.empty(self.pic_bytes(sid), dtype=np.uint8)
+        check(lib().hvq_read_picture(self._h, sid, ordinal, out.ctypes.data, out.nbytes))
+        return out
+
+    def stats(self) -> HvqStats:
+        st = HvqStats()
+        check(lib().hvq_get_stats(self._h, C.byref(st)))
+        return st
+
+    def close(self):
+        if self._h:
+            lib().hvq_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_clip(ctx: Context, data: bytes, nslots: Optional[int] = None) -> np.ndarray:
+    """Decode a whole .h4m through the batched path; returns uint8[n_pictures, pic_bytes] (decode order)."""
+    from .container import parse_header, video_pictures
+    hdr = parse_header(data)
+    pics = list(video_pictures(data))
+    sid = ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15,
+                          nslots if nslots is not None else len(pics) + 3)
+    for ft, _disp, pic in pics:
+        ctx.submit(sid, ft, pic)
+    ctx.flush()
+    out = np.stack([ctx.read_picture(sid, i) for i in range(len(pics))])
+    ctx.close_stream(sid)
+    return out

@@ -1,0 +1,127 @@
+/*
+ * hvq_desc.h -- per-picture descriptor blob: the interface between the host entropy
+ * parse (hvq_parse.c) and the gfx950 reconstruction kernels (hvq_kernels.hip).
+ *
+ * The reference interleaves bit-buffer reads with pixel work (h4m_audio_decode.c:691, 726,
+ * 1405-1406, 1950-1951).  Here the serial parse runs first and leaves everything the pixel
+ * stage needs in one self-contained, position-independent blob (all offsets are byte offsets
+ * from the blob start, every section 16-byte aligned):
+ *
+ *   HvqPicHeader
+ *   map[3]      per plane (hb+2)*(vb+2) entries of {u8 value, u8 type} INCLUDING the border
+ *               {0x7F,0xFF} -- byte-identical to the reference's BlockData maps (h4m:432-436,
+ *               1001-1040).  I pictures: type = basis-count byte (luma) / nibble (chroma);
+ *               P/B pictures: type = [6:5] macroblock type, [4] proc, [3:0] kind (h4m:1296-1304).
+ *   mv          P/B only: per 8x8 macroblock {i16 ref_x, i16 ref_y}, the ABSOLUTE half-sample
+ *               position of the macroblock in the reference picture (h4m:1954-1955); the
+ *               predictor chain of getMVector (h4m:1846-1860) is resolved on the host.
+ *   tile_base   one u32 per tile: dword index into `pool` of the tile's first payload.
+ *   pool        u32[]: block payloads in (plane, raster) order.  A block's payload length is a
+ *               pure function of its map type (hvq_payload_dwords), so a tile finds each
+ *               block's payload with one prefix scan -- no per-block offsets are stored.
+ *                 literal block (kind 6)      : 4 dwords = the 16 samples, row-major
+ *                 AOT basis                   : 1 dword  = HVQ_BASIS(word, coef_sum)
+ *                 MC-residual ("predi") block : 2 dwords {i32 dc_part, i32 gain_part} + bases
+ *   nest        70*38 bytes (I pictures, and P/B pictures that contain intra AOT blocks; the
+ *               nest of the most recent I picture, h4m:1823 -> 1367).
+ *
+ * A tile is HVQ_TILE_BLOCKS consecutive 4x4 blocks of ONE plane in raster order; one
+ * workgroup reconstructs one tile.
+ */
+#ifndef HVQ_DESC_H
+#define HVQ_DESC_H
+
+#include <stdint.h>
+
+#define HVQ_MAGIC        0x34515648u   /* "HVQ4" */
+#define HVQ_TILE_BLOCKS  256
+#define HVQ_NEST_BYTES   (70 * 38)
+
+#define HVQ_PIC_I 0
+#define HVQ_PIC_P 1
+#define HVQ_PIC_B 2
+
+/* header flags */
+#define HVQ_F_IS15        0x0001u   /* HVQM4 1.5 stream: per-plane half-sample rule (h4m:1337-1343) */
+#define HVQ_F_LANDSCAPE   0x0002u   /* width >= height (h4m:965-975) */
+#define HVQ_F_HAS_NEST    0x0004u   /* blob carries a nest: some block needs intra AOT */
+#define HVQ_F_SELF_REF    0x0008u   /* P picture with a future-referencing macroblock: the reference
+                                       reads the picture being written (h4m:2060); not reproducible
+                                       data-parallel -- flagged, decoded against `ref1` as given */
+#define HVQ_F_BIG_AOT     0x0010u   /* some block has more than 15 bases (I-luma type byte > 15) */
+#define HVQ_F_CLAMPED     0x0020u   /* malformed input: a value was clamped to keep the device in bounds */
+
+typedef struct HvqPicHeader {
+    uint32_t magic;
+    uint32_t total_bytes;
+    uint16_t width, height;        /* luma samples */
+    uint8_t  pic_kind;             /* HVQ_PIC_* */
+    uint8_t  unk_shift;            /* h4m:1974 / 2022: accumulator scale of the AOT */
+    uint8_t  dc_shift;             /* informational; already folded into pool values */
+    uint8_t  wshift, hshift;       /* chroma subsampling shifts (1,1 for 4:2:0) */
+    uint8_t  pad0[3];
+    uint32_t flags;
+    uint16_t hb[3], vb[3];         /* 4x4 blocks per plane */
+    uint32_t plane_off[3];         /* byte offset of each plane inside a picture buffer */
+    uint32_t pic_bytes;            /* Y|U|V size */
+    uint32_t map_off[3];
+    uint32_t mv_off;               /* 0 for I pictures */
+    uint32_t tile_base_off;
+    uint32_t pool_off;
+    uint32_t pool_dwords;
+    uint32_t nest_off;             /* 0 when absent */
+    uint32_t tile_first[4];        /* first tile index of plane 0,1,2 and the total */
+    uint32_t mcb_w, mcb_h;
+    uint32_t reserved[5];
+} HvqPicHeader;
+
+#if defined(__cplusplus)
+static_assert(sizeof(HvqPicHeader) == 128, "HvqPicHeader must be 128 bytes");
+#else
+_Static_assert(sizeof(HvqPicHeader) == 128, "HvqPicHeader must be 128 bytes");
+#endif
+
+/* AOT basis dword.  bits 12:0 = reference word bits 12:0 (offsets + strides, h4m:683-690),
+ * bit 13 = negate (word bit 15), bits 31:14 = running coefficient sum + word offset bits 14:13
+ * (the `*sum + offset` of h4m:726-731; <= 255*1020+3 < 2^18). */
+#define HVQ_BASIS(word, sum_plus_off) \
+    ((uint32_t)((word) & 0x1FFFu) | ((uint32_t)(((word) >> 15) & 1u) << 13) | ((uint32_t)(sum_plus_off) << 14))
+
+/* Payload length in dwords of one block, from its map type byte.
+ *   intra context (I picture, or P/B macroblock type 0; h4m:1433-1455, 1789-1827):
+ *       kind 0 / 8 -> none; 6 -> literal; else -> `kind` bases
+ *   inter context (h4m:1862-1910): proc = 1 -> none; kind 0 -> none; 6 -> literal;
+ *       else -> 2 parameters + (kind-1) bases
+ * `is_I_luma` selects the full type byte as kind (h4m:1093) instead of the low nibble. */
+#if defined(__HIPCC__)
+#define HVQ_HD __host__ __device__
+#else
+#define HVQ_HD
+#endif
+HVQ_HD static inline uint32_t hvq_payload_dwords(uint32_t type, int is_pb, int is_I_luma)
+{
+    uint32_t kind = is_I_luma ? type : (type & 0xFu);
+    if (is_pb && (type & 0x60u)) {
+        if (type & 0x10u) return 0;
+        return kind == 0 ? 0u : kind == 6 ? 4u : kind + 1u;
+    }
+    return (kind == 0 || kind == 8) ? 0u : kind == 6 ? 4u : kind;
+}
+
+/* one reconstruction job = one picture of one stream (device-visible) */
+typedef struct HvqJob {
+    uint64_t blob;                 /* device address of the descriptor blob */
+    uint64_t dst;                  /* device address of the picture being written */
+    uint64_t ref0;                 /* "past"   (macroblock type 1) */
+    uint64_t ref1;                 /* "future" (macroblock type 2) */
+    uint32_t slot_bytes;           /* readable bytes at ref0/ref1 (>= pic_bytes + 8) */
+    uint32_t pad[7];
+} HvqJob;
+
+/* one workgroup = one tile */
+typedef struct HvqTileRef {
+    uint32_t job;
+    uint32_t tile;
+} HvqTileRef;
+
+#endif

@@ -1,0 +1,325 @@
+/*
+ * hvq_kernels.hip -- HVQM4 picture reconstruction for CDNA4 / gfx950 (MI355X).
+ *
+ * One launch reconstructs a BATCH of pictures (one job per picture, any mix of streams,
+ * sizes and picture kinds).  One 256-thread workgroup = one tile = 256 consecutive 4x4
+ * blocks of one plane; one lane = one 4x4 block, held as four packed dwords (4 samples per
+ * dword).  Because intra prediction reads neighbour DC values from the descriptor map, not
+ * neighbour pixels, every block of a picture is independent:
+ * no intra-picture wavefront dependency exists and the whole batch is data-parallel.
+ *
+ * Integer/byte work, HBM-bound by design: no MFMA.  What matters here:
+ *   - stores: lane i writes dword i of a 256-byte row segment -> every store instruction of a
+ *     wave covers whole contiguous segments of the destination plane;
+ *   - payload lookup: a block's payload length is a function of its type byte, so one
+ *     workgroup prefix scan replaces per-block offsets (no offset traffic);
+ *   - the 70x38 intra nest (2660 B) is staged once per workgroup in LDS and gathered from
+ *     there (16 byte-gathers per basis);
+ *   - sample arithmetic is SIMD-within-register: v_lerp_u8 for the 2-tap half-sample
+ *     filters, 16-bit packed math for the weighted-DC predictor, v_sad_u8 for block sums;
+ *   - reference pictures are addressed LINEARLY inside the Y|U|V buffer exactly like the
+ *     reference's pointer arithmetic; every address is clamped to the
+ *     picture slot so malformed vectors cannot fault the GPU.
+ *
+ * Reference behaviour restated per device function (h4m: = h4m_audio_decode.c).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hvq_desc.h"
+
+typedef uint32_t u32;
+typedef int32_t i32;
+typedef uint64_t __attribute__((aligned(1))) u64u;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+#define HVQ_WG 256
+
+/* divTable of h4m:265-273: 0x1000 / (i*16) * 16 */
+__device__ __constant__ uint16_t k_div16[16] = { 0, 4096, 2048, 1360, 1024, 816, 672, 576, 512, 448, 400, 368, 336, 304, 288, 272 };
+
+struct Blk { u32 r[4]; };
+
+__device__ __forceinline__ u32 sat_pack(s16x2 a, s16x2 b)
+{
+    /* h4m:288-296 on pre-biased sums: (s+4)/8 as unsigned then clamp -> negatives become 255 */
+    const u16x2 k255 = { 255, 255 };
+    u16x2 ua = __builtin_elementwise_min(__builtin_bit_cast(u16x2, (s16x2)(a >> 3)), k255);
+    u16x2 ub = __builtin_elementwise_min(__builtin_bit_cast(u16x2, (s16x2)(b >> 3)), k255);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(u32, ub), __builtin_bit_cast(u32, ua), 0x06040200u);
+}
+
+/* Weighted-DC intra block (h4m:299-383): out = sat_mean8(8V + r[y] + c[x]),
+ * r[y] = a[y](T-V) + a[3-y](B-V), c[x] = a[x](L-V) + a[3-x](R-V), a = {2,0,-1,-1}. */
+__device__ __forceinline__ Blk weight_block(int V, int T, int B, int L, int R)
+{
+    int dT = T - V, dB = B - V, dL = L - V, dR = R - V;
+    int base = 8 * V + 4;
+    s16x2 c01 = { (short)(base + 2 * dL - dR), (short)(base - dR) };
+    s16x2 c23 = { (short)(base - dL), (short)(base - dL + 2 * dR) };
+    int rr[4] = { 2 * dT - dB, -dB, -dT, 2 * dB - dT };
+    Blk o;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        s16x2 r2 = { (short)rr[y], (short)rr[y] };
+        o.r[y] = sat_pack(c01 + r2, c23 + r2);
+    }
+    return o;
+}
+
+__device__ __forceinline__ i32 clampi(i32 v, i32 lo, i32 hi) { return min(max(v, lo), hi); }
+
+/* 4x4 motion-compensated block (h4m:1242-1294).  `a` = linear byte offset of the top-left
+ * source sample inside the reference picture buffer. */
+__device__ __forceinline__ Blk mc_block(const uint8_t *ref, i32 a, i32 stride, int hx, int hy, i32 amax8)
+{
+    uint64_t q[5];
+#pragma unroll
+    for (int y = 0; y < 5; ++y) q[y] = *(const u64u *)(ref + clampi(a + y * stride, 0, amax8));
+    Blk o;
+    if (!hy) {
+        if (!hx) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) o.r[y] = (u32)q[y];
+        } else {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) o.r[y] = __builtin_amdgcn_lerp((u32)q[y], (u32)(q[y] >> 8), 0x01010101u);
+        }
+    } else if (!hx) {
+#pragma unroll
+        for (int y = 0; y < 4; ++y) o.r[y] = __builtin_amdgcn_lerp((u32)q[y], (u32)q[y + 1], 0x01010101u);
+    } else {
+        /* (a+b+c+d+2)>>2 exactly: two 16-bit lanes per dword, even and odd bytes */
+        const u32 M = 0x00FF00FFu;
+        u32 he[5], ho[5];
+#pragma unroll
+        for (int y = 0; y < 5; ++y) {
+            u32 p = (u32)q[y], n = (u32)(q[y] >> 8);
+            he[y] = (p & M) + (n & M);
+            ho[y] = ((p >> 8) & M) + ((n >> 8) & M);
+        }
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            u32 e = ((he[y] + he[y + 1] + 0x00020002u) >> 2) & M;
+            u32 d = ((ho[y] + ho[y + 1] + 0x00020002u) >> 2) & M;
+            o.r[y] = e | (d << 8);
+        }
+    }
+    return o;
+}
+
+/* Sum of n AOT bases (h4m:679-817).  GATHER(off) returns one 4-bit nest value. */
+template <class Gather>
+__device__ __forceinline__ i32 aot_accumulate(const u32 *__restrict__ bases, u32 n, bool landscape, i32 stride,
+                                              u32 acc[16], Gather gather)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    for (u32 k = 0; k < n; ++k) {
+        u32 d = bases[k];
+        i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
+        u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
+        i32 o, xs, ys;
+        if (landscape) { o = stride * os + ol; xs = 1 << sl; ys = stride << ss; }
+        else           { o = stride * ol + os; xs = 1 << ss; ys = stride << sl; }
+        u32 e[16];
+        u32 lo = 255, hi = 0;
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                u32 v = gather(o + y * ys + x * xs);
+                e[4 * y + x] = v;
+                lo = min(lo, v);
+                hi = max(hi, v);
+            }
+        i32 inv = k_div16[(hi - lo) & 15];
+        if (d & 0x2000u) inv = -inv;
+        u32 factor = (d >> 14) * (u32)inv;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += factor * e[i];
+    }
+    u32 total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) total += acc[i];
+    return (i32)total >> 4;
+}
+
+/* TOOLCHAIN HAZARD (ROCm 7.2 hipcc, gfx950): `clamp(x >> s, 0, 255)` pairs are pattern-matched into
+ * v_ashr_pk_u8_i32 and OR-ed with the other two samples as if the instruction cleared the upper 16 bits
+ * of its destination; on MI355X it leaves them as they were, which corrupted samples 2 and 3 of a row
+ * (found by the parity suite).  The empty asm hides the shift result from that combine. */
+__device__ __forceinline__ i32 sar(u32 v, i32 s)
+{
+    i32 r = (i32)v >> s;
+    __asm__ volatile("" : "+v"(r));
+    return r;
+}
+
+__device__ __forceinline__ u32 pack4(i32 a, i32 b, i32 c, i32 d)
+{
+    a = clampi(a, 0, 255); b = clampi(b, 0, 255); c = clampi(c, 0, 255); d = clampi(d, 0, 255);
+    return (u32)a | ((u32)b << 8) | ((u32)c << 16) | ((u32)d << 24);
+}
+
+__device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(HVQ_WG)
+void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_nest[2672];
+    __shared__ u32 s_wave_sum[HVQ_WG / 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const u32 job_id = __builtin_amdgcn_readfirstlane(tiles[blockIdx.x].job);
+    const u32 tile = __builtin_amdgcn_readfirstlane(tiles[blockIdx.x].tile);
+    if (job_id == 0xFFFFFFFFu) return;            /* padding entry of the XCD-dealt tile table (uniform exit) */
+    const HvqJob *job = jobs + job_id;
+    const uint8_t *__restrict__ blob = (const uint8_t *)job->blob;
+    const HvqPicHeader *__restrict__ h = (const HvqPicHeader *)blob;
+
+    const int p = (tile >= h->tile_first[1]) + (tile >= h->tile_first[2]);
+    const i32 hb = h->hb[p], vb = h->vb[p];
+    const u32 nblocks = (u32)hb * (u32)vb;
+    const u32 b = (tile - h->tile_first[p]) * HVQ_TILE_BLOCKS + (u32)tid;
+    const bool valid = b < nblocks;
+    const u32 bb = valid ? b : 0;
+    const i32 by = (i32)(bb / (u32)hb), bx = (i32)(bb - (u32)by * (u32)hb);
+    const i32 ws = p ? h->wshift : 0, hs = p ? h->hshift : 0;
+    const i32 pw = h->width >> ws;
+    const u32 flags = h->flags;
+    const bool is_pb = h->pic_kind != HVQ_PIC_I;
+    const bool I_luma = !is_pb && p == 0;
+    const i32 unk = h->unk_shift;
+    const i32 mstride = hb + 2;
+
+    const uint8_t *map = blob + h->map_off[p];
+    const uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
+    const u32 e16 = *(const uint16_t *)ent;
+    const i32 V = e16 & 0xFF;
+    const u32 T = valid ? (e16 >> 8) : 0u;
+    const bool inter = is_pb && (T & 0x60u);
+    const u32 kind = I_luma ? T : (T & 0xFu);
+
+    /* payload offset: workgroup exclusive scan of the per-block payload lengths */
+    const u32 npay = valid ? hvq_payload_dwords(T, is_pb, I_luma) : 0u;
+    const u32 incl = wave_incl_scan(npay, lane);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    const bool need_nest = valid && !inter && kind != 0 && kind != 8 && kind != 6;
+    const int any_nest = __syncthreads_or(need_nest);
+    u32 off = ((const u32 *)(blob + h->tile_base_off))[tile] + incl - npay;
+#pragma unroll
+    for (int w = 0; w < HVQ_WG / 64 - 1; ++w)
+        if (w < wave) off += s_wave_sum[w];
+    const u32 *__restrict__ pay = (const u32 *)(blob + h->pool_off) + off;
+
+    if (any_nest) {
+        const u32 *src = (const u32 *)(blob + h->nest_off);
+        for (int i = tid; i < HVQ_NEST_BYTES / 4; i += HVQ_WG) ((u32 *)s_nest)[i] = src[i];
+        __syncthreads();
+    }
+    if (!valid) return;
+
+    Blk o;
+    const bool landscape = flags & HVQ_F_LANDSCAPE;
+    if (!inter) {
+        if (kind == 0) {
+            /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
+             * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
+            u32 t = *(const uint16_t *)(ent - 2 * mstride), bt = *(const uint16_t *)(ent + 2 * mstride);
+            u32 l = *(const uint16_t *)(ent - 2), r = *(const uint16_t *)(ent + 2);
+            i32 Tt = (t & 0x7700u) ? V : (i32)(t & 0xFF);
+            i32 Bb = (bt & 0x7700u) ? V : (i32)(bt & 0xFF);
+            i32 Rr = (r & 0x7700u) ? V : (i32)(r & 0xFF);
+            bool lexp = is_pb ? !(l & 0x7700u) : ((l >> 8) == 0 || (l >> 8) == 8);
+            i32 Ll = lexp ? (i32)(l & 0xFF) : V;
+            o = weight_block(V, Tt, Bb, Ll, Rr);
+        } else if (kind == 8) {
+            u32 v = (u32)V * 0x01010101u;                                     /* h4m:281-286 */
+            o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
+        } else if (kind == 6) {
+            o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3];   /* h4m:543-549 */
+        } else {
+            /* intra AOT (h4m:1358-1377) */
+            u32 acc[16];
+            const i32 nw = landscape ? 70 : 38;
+            i32 mean = aot_accumulate(pay, kind, landscape, nw, acc, [&](i32 a) -> u32 { return s_nest[a]; });
+            u32 delta = ((u32)V << unk) - (u32)mean;
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                o.r[y] = pack4(sar(acc[4 * y] + delta, unk), sar(acc[4 * y + 1] + delta, unk),
+                               sar(acc[4 * y + 2] + delta, unk), sar(acc[4 * y + 3] + delta, unk));
+        }
+    } else {
+        const i32 mx = bx >> (1 - ws), my = by >> (1 - hs);
+        const u32 mvw = ((const u32 *)(blob + h->mv_off))[my * (i32)h->mcb_w + mx];
+        const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+        const uint8_t *ref = (const uint8_t *)((((T >> 5) & 3u) == 1u) ? job->ref0 : job->ref1);
+        const i32 slot = (i32)job->slot_bytes;
+        const i32 pdx = rx >> ws, pdy = ry >> hs;
+        const bool is15 = flags & HVQ_F_IS15;
+        const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
+        const i32 a = (i32)h->plane_off[p] + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+        if ((T & 0x10u) || kind == 0) {
+            o = mc_block(ref, a, pw, hx, hy, slot - 8);
+        } else if (kind == 6) {
+            o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3];
+        } else {
+            /* MC + AOT residual (h4m:1379-1420); nest = window of the reference LUMA plane (h4m:1865-1868) */
+            const i32 lw = h->width;
+            const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
+            u32 acc[16];
+            u32 mean_aot = (u32)aot_accumulate(pay + 2, kind - 1, landscape, lw, acc,
+                                               [&](i32 g) -> u32 { return (u32)(ref[clampi(origin + g, 0, slot - 1)] >> 4) & 0xFu; });
+            Blk m = mc_block(ref, a, pw, hx, hy, slot - 8);
+            u32 sum = 8;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) sum = __builtin_amdgcn_sad_u8(m.r[y], 0u, sum);
+            const i32 mean = (i32)(sum >> 4);
+            u32 lo = 255, hi = 0;
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    u32 v = (m.r[y] >> (8 * x)) & 0xFFu;
+                    lo = min(lo, v);
+                    hi = max(hi, v);
+                }
+            const u32 range = hi - lo;
+            const u32 addend = pay[0] - mean_aot;
+            const u32 factor = pay[1] * (range ? 0x1000u / range : 0u);                /* mcdivTable, h4m:272 */
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                i32 v[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    i32 px = (i32)((m.r[y] >> (8 * x)) & 0xFFu);
+                    u32 r = acc[4 * y + x] + addend + (u32)(px - mean) * factor;
+                    v[x] = sar(r, unk) + px;
+                }
+                o.r[y] = pack4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+
+    uint8_t *dst = (uint8_t *)job->dst + h->plane_off[p] + (size_t)(by * 4) * pw + bx * 4;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) *(u32 *)(dst + (size_t)y * pw) = o.r[y];
+}
+
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles, hipStream_t stream)
+{
+    if (ntiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), 0, stream, jobs_dev, tiles_dev);
+    return hipGetLastError();
+}

@@ -1,0 +1,52 @@
+/*
+ * hvq_parse.h -- host entropy parse: HVQM4 picture bitstream -> descriptor blob (hvq_desc.h).
+ *
+ * This is the serial half of the reference's HVQM4DecodeIpic / HVQM4DecodeBpic
+ * (h4m_audio_decode.c:1970-2056): bit reader, prefix trees, overflow symbols, run lengths,
+ * DC prediction, nest construction, P/B descriptor map and motion-vector chains
+ * (SURVEY.md rows a22-a29).  It never touches pixels, so it can run
+ * arbitrarily far ahead of the GPU and one parser per stream can run on its own thread.
+ */
+#ifndef HVQ_PARSE_H
+#define HVQ_PARSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "hvq_desc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVQ_OK            0
+#define HVQ_E_ARG        -1
+#define HVQ_E_OVERFLOW   -2   /* blob capacity exceeded (absurd basis counts) */
+#define HVQ_E_GEOMETRY   -3   /* unsupported size / sampling */
+#define HVQ_E_NOGPU      -4
+#define HVQ_E_HIP        -5
+#define HVQ_E_STATE      -6
+
+typedef struct HvqParser HvqParser;
+
+/* width/height multiples of 8 (h4m:1749-1752), <= 8192; h_samp/v_samp: 2,2 (4:2:0) or 1,1 */
+HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int is15);
+void hvq_parser_destroy(HvqParser *p);
+
+/* capacity that holds any picture whose blocks carry <= 15 bases each */
+size_t hvq_parser_blob_bound(const HvqParser *p);
+uint32_t hvq_parser_pic_bytes(const HvqParser *p);
+
+/*
+ * Parse one picture.  `frame_type` is the container id 0x10 I / 0x20 P / 0x30 B
+ * (h4m:2065-2070); `pic` points at the picture data (after the 4-byte disp_id); `len` is the
+ * number of readable bytes at `pic` (0 = unknown, trust the stream like the reference does).
+ * Writes the blob to `blob` (16-byte aligned) and its size to *blob_len.
+ */
+int hvq_parse_picture(HvqParser *p, int frame_type, const uint8_t *pic, size_t len,
+                      uint8_t *blob, size_t cap, size_t *blob_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,567 @@
+/*
+ * hvq_runtime.cpp -- host side of the MI355X HVQM4 back end: the C ABI of include/hvqm4.h
+ * (the reference's SDK entry points, h4m_audio_decode.c:275, 819, 828, 957, 1970, 2018, 2058)
+ * and include/hvqm4_amd.h (batched device-resident path).
+ *
+ * Picture-buffer rotation of the reference player (h4m:2087-2093, 2131-2137) is restated as
+ * slot assignment: every decoded picture gets a slot in an HBM-resident ring of its stream,
+ * anchors (I/P) stay pinned while they are the past/future reference.  Queued pictures are
+ * grouped into dependency LEVELS (RAW on reference slots, WAR/WAW on the destination slot);
+ * one kernel launch reconstructs one level across all streams.  Workgroups are dealt to the
+ * tile table so that all tiles of a picture land on one XCD (blockIdx % 8), keeping its map,
+ * nest and reference-picture reads in that XCD's L2.
+ *
+ * There is NO CPU reconstruction path: without a usable HIP device every entry point that
+ * would produce pixels fails with HVQ_E_NOGPU.
+ */
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/hvqm4.h"
+#include "../../include/hvqm4_amd.h"
+#include "hvq_desc.h"
+#include "hvq_parse.h"
+
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles, hipStream_t stream);
+
+#define HVQ_EXPORT extern "C" __attribute__((visibility("default")))
+
+static thread_local std::string g_err;
+static thread_local int g_sdk_err = 0;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(HVQ_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+HVQ_EXPORT const char *hvq_last_error_string(void) { return g_err.c_str(); }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/* ------------------------------------------------------------------ context */
+struct Slot {
+    int w_level = -1;   /* level (in the pending batch) of the launch that writes the current content */
+    int r_level = -1;   /* highest level that reads it */
+    int pic = -1;       /* ordinal of the occupant */
+};
+
+struct Stream {
+    bool open = false;
+    HvqParser *parser = nullptr;
+    int w = 0, h = 0;
+    uint32_t pic_bytes = 0, slot_bytes = 0;
+    uint8_t *dev = nullptr;                  /* (nslots + 1) slots; the last one stays zero */
+    std::vector<Slot> slots;
+    int anchor_old = -1, anchor_new = -1;    /* "past" / "future" of the reference player */
+    int ring = 0;
+    int npics = 0;
+    std::vector<int> pic_slot;
+    uint8_t *slot_ptr(int s) const { return dev + (size_t)(s < 0 ? (int)slots.size() : s) * slot_bytes; }
+};
+
+struct Pending {
+    int stream, ordinal, level;
+    size_t blob_off, blob_len;
+    int dst, ref0, ref1;
+    uint32_t ntiles, kind;
+    uint32_t w, h;
+};
+
+struct Launch {
+    uint32_t first_tile, ntiles;
+};
+
+struct HvqContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<Stream> streams;
+    /* staging: pinned host arena mirrored by a device arena */
+    uint8_t *host_arena = nullptr, *dev_arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0;
+    std::vector<Pending> pending;
+    /* last flushed batch (kept resident for hvq_replay) */
+    HvqJob *jobs_dev = nullptr;
+    HvqTileRef *tiles_dev = nullptr;
+    size_t jobs_cap = 0, tiles_cap = 0;
+    std::vector<Launch> launches;
+    HvqStats stats{};
+    double parse_seconds = 0;
+};
+
+static int arena_reserve(HvqContext *c, size_t need)
+{
+    if (c->arena_used + need <= c->arena_cap) return HVQ_OK;
+    size_t ncap = c->arena_cap ? c->arena_cap : (size_t)64 << 20;
+    while (ncap < c->arena_used + need) ncap *= 2;
+    uint8_t *nh = nullptr, *nd = nullptr;
+    HIPCHK(hipHostMalloc((void **)&nh, ncap, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&nd, ncap));
+    if (c->arena_used) memcpy(nh, c->host_arena, c->arena_used);
+    if (c->host_arena) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipHostFree(c->host_arena));
+        HIPCHK(hipFree(c->dev_arena));
+    }
+    c->host_arena = nh; c->dev_arena = nd; c->arena_cap = ncap;
+    return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
+{
+    if (!out) return fail(HVQ_E_ARG, "null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(HVQ_E_NOGPU, "no HIP device available (%s): the HVQM4 reconstruction path is GPU-only",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(HVQ_E_ARG, "device %d out of range (%d devices)", device, n);
+    HIPCHK(hipSetDevice(device));
+    HvqContext *c = new HvqContext();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    *out = c;
+    return HVQ_OK;
+}
+
+HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->streams) {
+        if (s.parser) hvq_parser_destroy(s.parser);
+        if (s.dev) (void)hipFree(s.dev);
+    }
+    if (c->host_arena) (void)hipHostFree(c->host_arena);
+    if (c->dev_arena) (void)hipFree(c->dev_arena);
+    if (c->jobs_dev) (void)hipFree(c->jobs_dev);
+    if (c->tiles_dev) (void)hipFree(c->tiles_dev);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+HVQ_EXPORT int hvq_stream_open(HvqContext *c, int width, int height, int h_samp, int v_samp, int is15, int nslots)
+{
+    if (!c) return fail(HVQ_E_ARG, "null context");
+    if (nslots < 3) return fail(HVQ_E_ARG, "nslots must be >= 3 (past, present, future)");
+    HIPCHK(hipSetDevice(c->device));
+    HvqParser *p = hvq_parser_create(width, height, h_samp, v_samp, is15);
+    if (!p) return fail(HVQ_E_GEOMETRY, "unsupported geometry %dx%d sampling %dx%d (need multiples of 8, <= 8192, 4:2:0 or 4:4:4)",
+                        width, height, h_samp, v_samp);
+    Stream s;
+    s.open = true; s.parser = p; s.w = width; s.h = height;
+    s.pic_bytes = hvq_parser_pic_bytes(p);
+    s.slot_bytes = (uint32_t)align_up((size_t)s.pic_bytes + 64, 256);
+    s.slots.resize((size_t)nslots);
+    size_t bytes = (size_t)(nslots + 1) * s.slot_bytes;
+    hipError_t e = hipMalloc((void **)&s.dev, bytes);
+    if (e != hipSuccess) { hvq_parser_destroy(p); return fail(HVQ_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    e = hipMemsetAsync(s.dev, 0, bytes, c->stream);
+    if (e != hipSuccess) { hvq_parser_destroy(p); (void)hipFree(s.dev); return fail(HVQ_E_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    c->streams.push_back(s);
+    return (int)c->streams.size() - 1;
+}
+
+HVQ_EXPORT int hvq_stream_close(HvqContext *c, int sid)
+{
+    if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
+    for (auto &p : c->pending)
+        if (p.stream == sid) return fail(HVQ_E_STATE, "stream %d has queued pictures; flush first", sid);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    Stream &s = c->streams[sid];
+    hvq_parser_destroy(s.parser); s.parser = nullptr;
+    HIPCHK(hipFree(s.dev)); s.dev = nullptr;
+    s.open = false;
+    return HVQ_OK;
+}
+
+HVQ_EXPORT uint32_t hvq_stream_pic_bytes(HvqContext *c, int sid)
+{
+    if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return 0;
+    return c->streams[sid].pic_bytes;
+}
+
+static int alloc_slot(Stream &s)
+{
+    int n = (int)s.slots.size();
+    for (int i = 0; i < n; ++i) {
+        int cand = (s.ring + i) % n;
+        if (cand != s.anchor_old && cand != s.anchor_new) { s.ring = (cand + 1) % n; return cand; }
+    }
+    return -1;
+}
+
+HVQ_EXPORT int hvq_stream_submit(HvqContext *c, int sid, int frame_type, const uint8_t *pic, size_t len)
+{
+    if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
+    if (!pic || len < 8 + 0x44 + 4) return fail(HVQ_E_ARG, "picture too short (%zu bytes)", len);
+    if (frame_type != HVQ_FRAME_I && frame_type != HVQ_FRAME_P && frame_type != HVQ_FRAME_B)
+        return fail(HVQ_E_ARG, "unknown frame type 0x%x", frame_type);
+    HIPCHK(hipSetDevice(c->device));
+    Stream &s = c->streams[sid];
+    size_t bound = align_up(hvq_parser_blob_bound(s.parser), 256);
+    int rc = arena_reserve(c, bound);
+    if (rc) return rc;
+    size_t off = c->arena_used, blen = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = hvq_parse_picture(s.parser, frame_type, pic, len, c->host_arena + off, bound, &blen);
+    c->parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc) return fail(rc, "parse failed (%d) for stream %d picture %d", rc, sid, s.npics);
+    c->arena_used = off + align_up(blen, 256);
+
+    /* slot assignment == picture rotation of h4m:2087-2093 / 2131-2137 */
+    Pending q{};
+    q.stream = sid; q.ordinal = s.npics; q.blob_off = off; q.blob_len = blen;
+    const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + off);
+    q.ntiles = hd->tile_first[3]; q.kind = hd->pic_kind; q.w = hd->width; q.h = hd->height;
+    if (frame_type != HVQ_FRAME_B) std::swap(s.anchor_old, s.anchor_new);   /* past <-> future */
+    q.dst = alloc_slot(s);
+    if (frame_type == HVQ_FRAME_I) { q.ref0 = -1; q.ref1 = -1; }
+    else if (frame_type == HVQ_FRAME_P) { q.ref0 = s.anchor_old; q.ref1 = q.dst; }  /* future aliases present, h4m:2060 */
+    else { q.ref0 = s.anchor_old; q.ref1 = s.anchor_new; }
+    int lvl = 0;
+    auto dep_w = [&](int slot) { if (slot >= 0 && slot != q.dst) lvl = std::max(lvl, s.slots[slot].w_level + 1); };
+    dep_w(q.ref0); dep_w(q.ref1);
+    lvl = std::max(lvl, std::max(s.slots[q.dst].w_level, s.slots[q.dst].r_level) + 1);
+    q.level = lvl;
+    if (q.ref0 >= 0) s.slots[q.ref0].r_level = std::max(s.slots[q.ref0].r_level, lvl);
+    if (q.ref1 >= 0 && q.ref1 != q.dst) s.slots[q.ref1].r_level = std::max(s.slots[q.ref1].r_level, lvl);
+    if (s.slots[q.dst].pic >= 0) s.pic_slot[(size_t)s.slots[q.dst].pic] = -1;
+    s.slots[q.dst].w_level = lvl; s.slots[q.dst].r_level = -1; s.slots[q.dst].pic = q.ordinal;
+    s.pic_slot.push_back(q.dst);
+    if (frame_type != HVQ_FRAME_B) s.anchor_new = q.dst;     /* present <-> future: newest anchor becomes "future" */
+    c->pending.push_back(q);
+    return s.npics++;
+}
+
+HVQ_EXPORT int hvq_flush(HvqContext *c)
+{
+    if (!c) return fail(HVQ_E_ARG, "null context");
+    if (c->pending.empty()) return HVQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    /* 1. descriptors -> HBM (one copy) */
+    HIPCHK(hipMemcpyAsync(c->dev_arena, c->host_arena, c->arena_used, hipMemcpyHostToDevice, c->stream));
+    /* 2. job + tile tables, level by level, tiles dealt so that a picture stays on one XCD */
+    int max_level = 0;
+    for (auto &p : c->pending) max_level = std::max(max_level, p.level);
+    std::vector<HvqJob> jobs(c->pending.size());
+    std::vector<HvqTileRef> tiles;
+    c->launches.clear();
+    HvqStats st{};
+    for (size_t i = 0; i < c->pending.size(); ++i) {
+        const Pending &p = c->pending[i];
+        const Stream &s = c->streams[(size_t)p.stream];
+        HvqJob &j = jobs[i];
+        memset(&j, 0, sizeof j);
+        j.blob = (uint64_t)(uintptr_t)(c->dev_arena + p.blob_off);
+        j.dst = (uint64_t)(uintptr_t)s.slot_ptr(p.dst);
+        j.ref0 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref0);
+        j.ref1 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref1);
+        j.slot_bytes = s.slot_bytes;
+        st.pictures++;
+        st.luma_pixels += (uint64_t)p.w * p.h;
+        st.algorithmic_bytes += (uint64_t)s.pic_bytes * (p.kind == HVQ_PIC_I ? 1u : 2u);
+        st.descriptor_bytes += p.blob_len;
+        st.flags_or |= ((const HvqPicHeader *)(c->host_arena + p.blob_off))->flags;
+    }
+    for (int lvl = 0; lvl <= max_level; ++lvl) {
+        std::vector<HvqTileRef> bins[8];
+        int nb = 0;
+        for (size_t i = 0; i < c->pending.size(); ++i) {
+            const Pending &p = c->pending[i];
+            if (p.level != lvl) continue;
+            auto &bin = bins[nb++ & 7];
+            for (uint32_t t = 0; t < p.ntiles; ++t) bin.push_back(HvqTileRef{ (uint32_t)i, t });
+        }
+        if (!nb) continue;
+        Launch L{ (uint32_t)tiles.size(), 0 };
+        if (nb < 8) {
+            /* too few pictures to give every XCD its own: plain order, no padding */
+            for (int x = 0; x < nb; ++x) tiles.insert(tiles.end(), bins[x].begin(), bins[x].end());
+        } else {
+            /* blockIdx % 8 selects the XCD: entry 8k+x comes from bin x; ragged tails are padded
+             * with {0xFFFFFFFF,0} entries that exit at once */
+            size_t longest = 0;
+            for (auto &b : bins) longest = std::max(longest, b.size());
+            for (size_t k = 0; k < longest; ++k)
+                for (int x = 0; x < 8; ++x)
+                    tiles.push_back(k < bins[x].size() ? bins[x][k] : HvqTileRef{ 0xFFFFFFFFu, 0u });
+        }
+        L.ntiles = (uint32_t)tiles.size() - L.first_tile;
+        c->launches.push_back(L);
+        st.workgroups += L.ntiles;
+    }
+    st.launches = (uint32_t)c->launches.size();
+    st.parse_seconds = c->parse_seconds;
+    if (jobs.size() > c->jobs_cap) {
+        if (c->jobs_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->jobs_dev)); }
+        c->jobs_cap = jobs.size() * 2;
+        HIPCHK(hipMalloc((void **)&c->jobs_dev, c->jobs_cap * sizeof(HvqJob)));
+    }
+    if (tiles.size() > c->tiles_cap) {
+        if (c->tiles_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tiles_dev)); }
+        c->tiles_cap = tiles.size() * 2;
+        HIPCHK(hipMalloc((void **)&c->tiles_dev, c->tiles_cap * sizeof(HvqTileRef)));
+    }
+    /* pageable sources: hipMemcpyAsync stages them before returning, so the vectors may die */
+    HIPCHK(hipMemcpyAsync(c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->tiles_dev, tiles.data(), tiles.size() * sizeof(HvqTileRef), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    /* 3. one launch per level */
+    for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, c->stream));
+    c->stats = st;
+    /* the batch is in flight: levels restart from zero for whatever is queued next */
+    for (auto &s : c->streams)
+        for (auto &sl : s.slots) { sl.w_level = -1; sl.r_level = -1; }
+    c->pending.clear();
+    c->arena_used = 0;      /* blobs stay valid in dev_arena until the next flush overwrites them */
+    return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_sync(HvqContext *c)
+{
+    if (!c) return fail(HVQ_E_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
+{
+    if (!c || reps < 0) return fail(HVQ_E_ARG, "bad arguments");
+    if (c->launches.empty()) return fail(HVQ_E_STATE, "nothing flushed yet");
+    if (!c->pending.empty()) return fail(HVQ_E_STATE, "pictures queued since the last flush");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; ++r)
+        for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, c->stream));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (gpu_ms) *gpu_ms = ms;
+    return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_read_picture(HvqContext *c, int sid, int ordinal, void *dst, size_t cap)
+{
+    if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
+    Stream &s = c->streams[sid];
+    if (ordinal < 0 || ordinal >= s.npics) return fail(HVQ_E_ARG, "bad picture ordinal %d", ordinal);
+    if (cap < s.pic_bytes) return fail(HVQ_E_ARG, "destination too small");
+    for (auto &p : c->pending)
+        if (p.stream == sid && p.ordinal == ordinal) return fail(HVQ_E_STATE, "picture %d is queued but not flushed", ordinal);
+    int slot = s.pic_slot[(size_t)ordinal];
+    if (slot < 0) return fail(HVQ_E_STATE, "picture %d is no longer resident (slot reused)", ordinal);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(dst, s.slot_ptr(slot), s.pic_bytes, hipMemcpyDeviceToHost));
+    return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_get_stats(HvqContext *c, HvqStats *out)
+{
+    if (!c || !out) return fail(HVQ_E_ARG, "bad arguments");
+    *out = c->stats;
+    out->parse_seconds = c->parse_seconds;
+    return HVQ_OK;
+}
+
+/* ------------------------------------------------------------------ SDK entry points */
+namespace {
+
+constexpr uint64_t SDK_MAGIC = 0x4856514d34414d44ull;   /* "HVQM4AMD" */
+
+struct SdkBinding {
+    HvqContext *ctx = nullptr;
+    int stream = -1;
+    int w = 0, h = 0, hs = 0, vs = 0, is15 = -1;
+    uint32_t pic_bytes = 0;
+};
+
+struct SdkHeader {          /* lives at the start of the caller's work buffer */
+    uint64_t magic;
+    SdkBinding *binding;
+};
+
+std::mutex g_sdk_mu;
+HvqContext *g_sdk_ctx = nullptr;
+std::set<SdkBinding *> g_bindings;
+
+void sdk_fail(int code)
+{
+    g_sdk_err = code;
+    fprintf(stderr, "hvqm4_amd: %s\n", g_err.c_str());
+}
+
+HvqContext *sdk_context()
+{
+    if (g_sdk_ctx) return g_sdk_ctx;
+    const char *dev = getenv("HVQM4_AMD_DEVICE");
+    int rc = hvq_context_create(dev ? atoi(dev) : 0, &g_sdk_ctx);
+    if (rc) { sdk_fail(rc); g_sdk_ctx = nullptr; }
+    return g_sdk_ctx;
+}
+
+void sdk_release_locked(SdkHeader *hd)
+{
+    if (hd->magic == SDK_MAGIC && g_bindings.count(hd->binding)) {
+        SdkBinding *b = hd->binding;
+        if (b->ctx && b->stream >= 0) hvq_stream_close(b->ctx, b->stream);
+        g_bindings.erase(b);
+        delete b;
+    }
+    hd->magic = 0; hd->binding = nullptr;
+}
+
+/* (re)open the device stream when the 1.3/1.5 switch byte changed (h4m:2414-2417) */
+SdkBinding *sdk_bind(SeqObj *seq)
+{
+    if (!seq || !seq->state) { fail(HVQ_E_ARG, "SeqObj has no work buffer (call HVQM4SetBuffer)"); sdk_fail(HVQ_E_ARG); return nullptr; }
+    SdkHeader *hd = (SdkHeader *)seq->state;
+    if (hd->magic != SDK_MAGIC || !g_bindings.count(hd->binding)) { fail(HVQ_E_STATE, "work buffer was not initialised by HVQM4SetBuffer"); sdk_fail(HVQ_E_STATE); return nullptr; }
+    SdkBinding *b = hd->binding;
+    int is15 = seq->state->padding[0] != 0;
+    if (b->stream >= 0 && b->is15 != is15) { hvq_stream_close(b->ctx, b->stream); b->stream = -1; }
+    if (b->stream < 0) {
+        HvqContext *ctx = sdk_context();
+        if (!ctx) return nullptr;
+        int sid = hvq_stream_open(ctx, b->w, b->h, b->hs, b->vs, is15, 3);
+        if (sid < 0) { sdk_fail(sid); return nullptr; }
+        b->ctx = ctx; b->stream = sid; b->is15 = is15;
+        b->pic_bytes = hvq_stream_pic_bytes(ctx, sid);
+    }
+    return b;
+}
+
+/* One synchronous picture: upload the caller's reference pictures, reconstruct, read back. */
+void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, const void *past, const void *future)
+{
+    std::lock_guard<std::mutex> lk(g_sdk_mu);
+    SdkBinding *b = sdk_bind(seq);
+    if (!b) return;
+    HvqContext *c = b->ctx;
+    Stream &s = c->streams[(size_t)b->stream];
+    /* host pictures are authoritative in the SDK contract: refresh the two reference slots */
+    auto put = [&](int slot, const void *src) -> bool {
+        hipError_t e = hipMemcpyAsync(s.slot_ptr(slot), src, s.pic_bytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { fail(HVQ_E_HIP, "upload of reference picture: %s", hipGetErrorString(e)); sdk_fail(HVQ_E_HIP); return false; }
+        return true;
+    };
+    s.anchor_old = -1; s.anchor_new = -1; s.ring = 2;
+    if (ftype == HVQ_FRAME_P) {
+        if (!put(0, past)) return;
+        s.anchor_old = -1; s.anchor_new = 0;            /* swapped to "past" by the submit's rotation */
+    } else if (ftype == HVQ_FRAME_B) {
+        if (!put(0, past) || !put(1, future)) return;
+        s.anchor_old = 0; s.anchor_new = 1;
+    }
+    int ord = hvq_stream_submit(c, b->stream, ftype, frame, 0x7FFFFFFF);
+    if (ord < 0) { sdk_fail(ord); return; }
+    int rc = hvq_flush(c);
+    if (rc) { sdk_fail(rc); return; }
+    rc = hvq_read_picture(c, b->stream, ord, present, s.pic_bytes);
+    if (rc) sdk_fail(rc);
+}
+
+}  // namespace
+
+HVQ_EXPORT void HVQM4InitDecoder(void)
+{
+    /* the reference fills divTable/mcdivTable here (h4m:265-278); ours are compile-time constants
+     * in the kernel.  Probe the device early so a missing GPU is reported at init time. */
+    std::lock_guard<std::mutex> lk(g_sdk_mu);
+    (void)sdk_context();
+}
+
+HVQ_EXPORT void HVQM4InitSeqObj(SeqObj *seqobj, VideoInfo *videoinfo)
+{
+    seqobj->width = videoinfo->hres;
+    seqobj->height = videoinfo->vres;
+    seqobj->h_samp = videoinfo->h_samp;
+    seqobj->v_samp = videoinfo->v_samp;
+}
+
+HVQ_EXPORT uint32_t HVQM4BuffSize(SeqObj *seqobj)
+{
+    /* same arithmetic as h4m:828-840 so callers allocate what they always did */
+    uint32_t hb = seqobj->width / 4, vb = seqobj->height / 4;
+    uint32_t yb = (hb + 2) * (vb + 2);
+    uint32_t uhb = seqobj->h_samp == 2 ? hb / 2 : hb, uvb = seqobj->v_samp == 2 ? vb / 2 : vb;
+    uint32_t uvblocks = (uhb + 2) * (uvb + 2);
+    return (uint32_t)sizeof(VideoState) + (yb + uvblocks * 2) * (uint32_t)sizeof(uint16_t);
+}
+
+HVQ_EXPORT void HVQM4SetBuffer(SeqObj *seqobj, void *workbuff)
+{
+    std::lock_guard<std::mutex> lk(g_sdk_mu);
+    SdkHeader *hd = (SdkHeader *)workbuff;
+    sdk_release_locked(hd);                 /* re-binding an already bound buffer must not leak */
+    seqobj->state = (VideoState *)workbuff;
+    SdkBinding *b = new SdkBinding();
+    b->w = seqobj->width; b->h = seqobj->height; b->hs = seqobj->h_samp; b->vs = seqobj->v_samp;
+    g_bindings.insert(b);
+    hd->magic = SDK_MAGIC;
+    hd->binding = b;
+}
+
+HVQ_EXPORT void HVQM4ReleaseBuffer(SeqObj *seqobj)
+{
+    std::lock_guard<std::mutex> lk(g_sdk_mu);
+    if (seqobj && seqobj->state) sdk_release_locked((SdkHeader *)seqobj->state);
+}
+
+HVQ_EXPORT void HVQM4SetVersion15(SeqObj *seqobj, int is15)
+{
+    if (seqobj && seqobj->state) seqobj->state->padding[0] = is15 ? 1 : 0;
+}
+
+HVQ_EXPORT void HVQM4DecodeIpic(SeqObj *seqobj, uint8_t const *frame, void *present)
+{
+    sdk_decode(seqobj, HVQ_FRAME_I, frame, present, nullptr, nullptr);
+}
+
+HVQ_EXPORT void HVQM4DecodePpic(SeqObj *seqobj, uint8_t const *frame, void *present, void *past)
+{
+    sdk_decode(seqobj, HVQ_FRAME_P, frame, present, past, nullptr);
+}
+
+HVQ_EXPORT void HVQM4DecodeBpic(SeqObj *seqobj, uint8_t const *frame, void *present, void *past, void *future)
+{
+    sdk_decode(seqobj, HVQ_FRAME_B, frame, present, past, future);
+}
+
+HVQ_EXPORT int HVQM4GetLastError(void)
+{
+    int e = g_sdk_err;
+    g_sdk_err = 0;
+    return e;
+}
+
+HVQ_EXPORT const char *HVQM4GetLastErrorString(void) { return g_err.c_str(); }

@@ -1,0 +1,89 @@
+/*
+ * hvqm4_amd.h -- batched, device-resident extension of the HVQM4 decode path.
+ *
+ * The SDK signatures (hvqm4.h) hand host pointers in and out, so every call pays PCIe for
+ * whole pictures.  This API is what a player/transcoder binds for throughput: pictures stay
+ * in HBM, any number of streams are decoded per launch, and the host entropy parse
+ * (h4m_audio_decode.c:1970-2056, serial per stream) overlaps GPU work.  It replaces the
+ * reference's `decode_video` loop (h4m:2078-2138): frame-buffer rotation becomes slot
+ * assignment, and pictures with no mutual dependency (across streams, and B pictures /
+ * the next anchor inside a stream) are reconstructed by ONE kernel launch.
+ *
+ * Plain C ABI: pointers and sizes only.  All functions return HVQ_OK (0) / a non-negative
+ * result, or a negative HVQ_E_* code; hvq_last_error_string() describes the last failure.
+ */
+#ifndef HVQM4_AMD_H
+#define HVQM4_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVQ_OK            0
+#define HVQ_E_ARG        -1
+#define HVQ_E_OVERFLOW   -2
+#define HVQ_E_GEOMETRY   -3
+#define HVQ_E_NOGPU      -4
+#define HVQ_E_HIP        -5
+#define HVQ_E_STATE      -6
+
+#define HVQ_FRAME_I 0x10   /* container frame ids, h4m:2065-2070 */
+#define HVQ_FRAME_P 0x20
+#define HVQ_FRAME_B 0x30
+
+typedef struct HvqContext HvqContext;
+
+typedef struct HvqStats {
+    uint64_t pictures;          /* pictures in the last flushed batch */
+    uint64_t luma_pixels;       /* sum of w*h over them */
+    uint64_t algorithmic_bytes; /* 1.5 B/px written + 1.5 B/px read for P/B */
+    uint64_t descriptor_bytes;  /* blob bytes uploaded (not credited in the roofline) */
+    uint32_t launches;          /* kernel launches (= dependency levels) per pass */
+    uint32_t workgroups;        /* total workgroups per pass */
+    double   parse_seconds;     /* host entropy-parse time accumulated by hvq_stream_submit */
+    uint32_t flags_or;          /* OR of all blob header flags (HVQ_F_*) */
+} HvqStats;
+
+int  hvq_context_create(int device, HvqContext **out);
+void hvq_context_destroy(HvqContext *ctx);
+
+/* A stream = one clip.  `nslots` >= 3 picture buffers stay resident in HBM per stream (the
+ * reference rotates exactly 3, h4m:2340-2350; more slots let later pictures start earlier). */
+int  hvq_stream_open(HvqContext *ctx, int width, int height, int h_samp, int v_samp, int is_1_5, int nslots);
+int  hvq_stream_close(HvqContext *ctx, int stream);
+
+/* Parse one picture (host) and queue it.  `pic` = picture data after the 4-byte disp_id,
+ * `len` its length.  Returns the picture's ordinal in the stream (decode order). */
+int  hvq_stream_submit(HvqContext *ctx, int stream, int frame_type, const uint8_t *pic, size_t len);
+
+/* Upload queued descriptors, group queued pictures into dependency levels, launch. Async. */
+int  hvq_flush(HvqContext *ctx);
+int  hvq_sync(HvqContext *ctx);
+
+/* Re-run the launches of the last flush `reps` times (descriptors already resident in HBM).
+ * *gpu_ms = elapsed time between HIP events recorded on the launch stream around all reps. */
+int  hvq_replay(HvqContext *ctx, int reps, float *gpu_ms);
+
+/* Copy a still-resident picture (Y|U|V, pic_bytes) to host memory; synchronises. */
+int  hvq_read_picture(HvqContext *ctx, int stream, int ordinal, void *dst, size_t cap);
+uint32_t hvq_stream_pic_bytes(HvqContext *ctx, int stream);
+
+int  hvq_get_stats(HvqContext *ctx, HvqStats *out);
+const char *hvq_last_error_string(void);
+
+/* Host-only pieces, usable without a GPU (parse is pixel-independent). */
+typedef struct HvqParser HvqParser;
+HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int is_1_5);
+void hvq_parser_destroy(HvqParser *p);
+size_t hvq_parser_blob_bound(const HvqParser *p);
+uint32_t hvq_parser_pic_bytes(const HvqParser *p);
+int  hvq_parse_picture(HvqParser *p, int frame_type, const uint8_t *pic, size_t len,
+                       uint8_t *blob, size_t cap, size_t *blob_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+/*
+ * oracle/hvq_desc_recon.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Scalar CPU interpreter of the product's descriptor blobs (hvqm4_amd/csrc/hvq_desc.h):
+ * blob + reference pictures -> reconstructed picture.  It is the executable specification
+ * of what the HIP kernels must compute from a blob, and lets the CPU test-suite check the
+ * host parse (hvq_parse.c) against the oracle/reference without a GPU.  Never linked into
+ * the product; the product has no CPU reconstruction path.
+ *
+ * Reference lines restated: block kinds h4m:1433-1455 / 1789-1827 / 1862-1910, AOT
+ * h4m:679-817, 1358-1420, motion compensation h4m:1242-1294, 1327-1355.
+ */
+#include <stdint.h>
+#include <string.h>
+
+#include "hvq_desc.h"
+
+#define API __attribute__((visibility("default")))
+
+static inline uint8_t clamp255(int32_t x) { return x < 0 ? 0 : x > 255 ? 255 : (uint8_t)x; }
+static inline uint8_t mean8(int32_t s) { return clamp255((int32_t)(((uint32_t)s + 4u) / 8u)); }
+
+typedef struct {
+    const uint8_t *blob;
+    const HvqPicHeader *h;
+    const uint8_t *nest;
+    int nest_w;
+    uint32_t slot_bytes;
+    int32_t divt[16];
+} Ctx;
+
+static inline uint8_t ref_px(const uint8_t *ref, int64_t a, uint32_t slot_bytes)
+{
+    if (a < 0) a = 0;
+    if (a > (int64_t)slot_bytes - 1) a = (int64_t)slot_bytes - 1;
+    return ref[a];
+}
+
+static void mc16(const Ctx *c, const uint8_t *ref, int64_t a, int stride, int hx, int hy, uint8_t m[16])
+{
+    for (int y = 0; y < 4; ++y)
+        for (int x = 0; x < 4; ++x) {
+            int64_t s = a + (int64_t)y * stride + x;
+            int p00 = ref_px(ref, s, c->slot_bytes), p01 = ref_px(ref, s + 1, c->slot_bytes);
+            int p10 = ref_px(ref, s + stride, c->slot_bytes), p11 = ref_px(ref, s + stride + 1, c->slot_bytes);
+            int v;
+            if (!hx && !hy) v = p00;
+            else if (hx && !hy) v = (p00 + p01 + 1) / 2;
+            else if (!hx) v = (p00 + p10 + 1) / 2;
+            else v = (p00 + p01 + p10 + p11 + 2) >> 2;
+            m[4 * y + x] = (uint8_t)v;
+        }
+}
+
+/* accumulate n bases; src = nest bytes (hi=0) or reference picture luma window (hi=1, clamped) */
+static int32_t aot(const Ctx *c, const uint32_t *bases, uint32_t n, const uint8_t *src, int64_t origin,
+                   int stride, int hi, uint32_t acc[16])
+{
+    int landscape = (c->h->flags & HVQ_F_LANDSCAPE) != 0;
+    memset(acc, 0, 64);
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t d = bases[k];
+        uint32_t ol = d & 0x3F, os = (d >> 6) & 0x1F, sl = (d >> 11) & 1, ss = (d >> 12) & 1, neg = (d >> 13) & 1;
+        uint32_t sum = d >> 14;
+        int64_t o; int xs, ys;
+        if (landscape) { o = origin + (int64_t)stride * os + ol; xs = 1 << sl; ys = stride << ss; }
+        else           { o = origin + (int64_t)stride * ol + os; xs = 1 << ss; ys = stride << sl; }
+        uint8_t e[16], lo = 255, hi_v = 0;
+        for (int y = 0; y < 4; ++y)
+            for (int x = 0; x < 4; ++x) {
+                uint8_t v = hi ? (uint8_t)((ref_px(src, o + (int64_t)y * ys + x * xs, c->slot_bytes) >> 4) & 0xF)
+                               : src[o + y * ys + x * xs];
+                e[4 * y + x] = v;
+                if (v < lo) lo = v;
+                if (v > hi_v) hi_v = v;
+            }
+        int32_t inv = c->divt[(hi_v - lo) & 15];
+        if (neg) inv = -inv;
+        uint32_t factor = sum * (uint32_t)inv;
+        for (int i = 0; i < 16; ++i) acc[i] += factor * e[i];
+    }
+    uint32_t total = 0;
+    for (int i = 0; i < 16; ++i) total += acc[i];
+    return (int32_t)total >> 4;
+}
+
+API int hvqd_recon(const uint8_t *blob, uint8_t *dst, const uint8_t *ref0, const uint8_t *ref1, uint32_t slot_bytes)
+{
+    static const int a4[4] = { 2, 0, -1, -1 };
+    const HvqPicHeader *h = (const HvqPicHeader *)blob;
+    if (h->magic != HVQ_MAGIC) return -1;
+    Ctx c = { blob, h, h->nest_off ? blob + h->nest_off : NULL, (h->flags & HVQ_F_LANDSCAPE) ? 70 : 38, slot_bytes, { 0 } };
+    for (int i = 1; i < 16; ++i) c.divt[i] = 0x1000 / (i * 16) * 16;
+    const uint32_t *pool = (const uint32_t *)(blob + h->pool_off);
+    const uint32_t *tile_base = (const uint32_t *)(blob + h->tile_base_off);
+    const int16_t *mvs = h->mv_off ? (const int16_t *)(blob + h->mv_off) : NULL;
+    int is_pb = h->pic_kind != HVQ_PIC_I, is15 = (h->flags & HVQ_F_IS15) != 0;
+    int lw = h->width;
+    for (int p = 0; p < 3; ++p) {
+        int hb = h->hb[p], vb = h->vb[p], stride = hb + 2;
+        int ws = p ? h->wshift : 0, hs = p ? h->hshift : 0;
+        int pw = h->width >> ws;
+        const uint8_t *map = blob + h->map_off[p];
+        uint8_t *plane = dst + h->plane_off[p];
+        uint32_t off = 0;
+        for (uint32_t b = 0; b < (uint32_t)hb * vb; ++b) {
+            if ((b % HVQ_TILE_BLOCKS) == 0) off = tile_base[h->tile_first[p] + b / HVQ_TILE_BLOCKS];
+            int by = (int)(b / hb), bx = (int)(b % hb);
+            const uint8_t *e = map + 2 * ((by + 1) * stride + bx + 1);
+            uint32_t V = e[0], T = e[1];
+            int I_luma = !is_pb && p == 0;
+            uint32_t n = hvq_payload_dwords(T, is_pb, I_luma);
+            const uint32_t *pay = pool + off;
+            off += n;
+            uint8_t out[16];
+            int inter = is_pb && (T & 0x60);
+            uint32_t kind = I_luma ? T : (T & 0xF);
+            if (!inter) {
+                if (kind == 0) {
+                    const uint8_t *t = e - 2 * stride, *bo = e + 2 * stride, *l = e - 2, *r = e + 2;
+                    int Tt = (t[1] & 0x77) ? (int)V : t[0], Bb = (bo[1] & 0x77) ? (int)V : bo[0];
+                    int Rr = (r[1] & 0x77) ? (int)V : r[0];
+                    int Ll = is_pb ? ((l[1] & 0x77) ? (int)V : l[0]) : ((l[1] == 0 || l[1] == 8) ? l[0] : (int)V);
+                    for (int y = 0; y < 4; ++y) {
+                        int rr = a4[y] * (Tt - (int)V) + a4[3 - y] * (Bb - (int)V);
+                        for (int x = 0; x < 4; ++x)
+                            out[4 * y + x] = mean8(8 * (int)V + rr + a4[x] * (Ll - (int)V) + a4[3 - x] * (Rr - (int)V));
+                    }
+                } else if (kind == 8) memset(out, (int)V, 16);
+                else if (kind == 6) memcpy(out, pay, 16);
+                else {
+                    uint32_t acc[16];
+                    int32_t mean = aot(&c, pay, kind, c.nest, 0, c.nest_w, 0, acc);
+                    uint32_t delta = (V << h->unk_shift) - (uint32_t)mean;
+                    for (int i = 0; i < 16; ++i) out[i] = clamp255((int32_t)(acc[i] + delta) >> h->unk_shift);
+                }
+            } else {
+                int mx = bx >> (1 - ws), my = by >> (1 - hs);
+                int32_t rx = mvs[2 * (my * (int)h->mcb_w + mx)], ry = mvs[2 * (my * (int)h->mcb_w + mx) + 1];
+                const uint8_t *ref = ((T >> 5) & 3) == 1 ? ref0 : ref1;
+                int32_t pdx = rx >> ws, pdy = ry >> hs;
+                int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
+                int64_t a = (int64_t)h->plane_off[p] + (int64_t)(pdy >> 1) * pw + (pdx >> 1)
+                          + (int64_t)(by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+                if ((T & 0x10) || kind == 0) mc16(&c, ref, a, pw, hx, hy, out);
+                else if (kind == 6) memcpy(out, pay, 16);
+                else {
+                    int64_t origin = (h->flags & HVQ_F_LANDSCAPE) ? (int64_t)(rx / 2) + (int64_t)(ry / 2 - 16) * lw - 32
+                                                                  : (int64_t)(rx / 2) + (int64_t)(ry / 2 - 32) * lw - 16;
+                    uint32_t acc[16];
+                    uint32_t mean_aot = (uint32_t)aot(&c, pay + 2, kind - 1, ref, origin, lw, 1, acc);
+                    uint8_t m[16];
+                    mc16(&c, ref, a, pw, hx, hy, m);
+                    int32_t s = 8, lo = 255, hi = 0;
+                    for (int i = 0; i < 16; ++i) { s += m[i]; if (m[i] < lo) lo = m[i]; if (m[i] > hi) hi = m[i]; }
+                    int32_t mean = s / 16;
+                    int32_t range = hi - lo;
+                    uint32_t addend = pay[0] - mean_aot;
+                    uint32_t factor = pay[1] * (uint32_t)(range ? 0x1000 / range : 0);
+                    for (int i = 0; i < 16; ++i) {
+                        uint32_t r = acc[i] + addend + (uint32_t)((int32_t)m[i] - mean) * factor;
+                        out[i] = clamp255(((int32_t)r >> h->unk_shift) + m[i]);
+                    }
+                }
+            }
+            for (int y = 0; y < 4; ++y) memcpy(plane + (size_t)(by * 4 + y) * pw + bx * 4, out + 4 * y, 4);
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,38 @@
+"""Seeded synthetic clip catalogue shared by the CPU and GPU suites."""
+from hvqm4_amd.synth import SynthConfig, make_clip
+
+# (name, config) -- small enough for the scalar oracle to finish in well under a second each
+SMALL = [
+    ("i16", SynthConfig(width=16, height=16, gop="I", seed=1)),
+    ("ip8", SynthConfig(width=8, height=8, gop="IPP", seed=2)),
+    ("ipb32", SynthConfig(width=32, height=32, gop="IPB", seed=3)),
+    ("gop64x48_15", SynthConfig(width=64, height=48, gop="IPBBPBB", seed=4, version="1.5")),
+    ("gop64x48_13", SynthConfig(width=64, height=48, gop="IPBBPBB", seed=5, version="1.3")),
+    ("portrait48x64", SynthConfig(width=48, height=64, gop="IPBB", seed=6)),
+    ("portrait152x280", SynthConfig(width=152, height=280, gop="IPB", seed=7)),
+    ("nest_exact280x152", SynthConfig(width=280, height=152, gop="IPB", seed=8)),
+    ("wide296x160", SynthConfig(width=296, height=160, gop="IPBB", seed=9, runoff_prob=0.5)),
+    ("weird128x96", SynthConfig(width=128, height=96, gop="IPPBB", seed=10, weird_kinds=True, version="1.3")),
+    ("weird64x64", SynthConfig(width=64, height=64, gop="IPBBP", seed=11, weird_kinds=True)),
+    ("realistic128x96", SynthConfig(width=128, height=96, gop="IPBBPBB", seed=12, preset="realistic")),
+    ("flat128x96", SynthConfig(width=128, height=96, gop="IPBBPBB", seed=13, preset="flat")),
+    ("ragged24x40", SynthConfig(width=24, height=40, gop="IPBB", seed=14)),
+    ("twogops64x48", SynthConfig(width=64, height=48, gop="IPBB", n_gops=3, seed=15)),
+    ("bigshift64x48", SynthConfig(width=64, height=48, gop="IPBB", seed=16, dc_shifts=(3, 4), unk_shifts=(4, 10, 12))),
+]
+
+MEDIUM = [
+    ("c2_320x240_I", SynthConfig(width=320, height=240, gop="I", n_gops=4, seed=20)),
+    ("c3_640x480", SynthConfig(width=640, height=480, gop="IPBBPBB", seed=21)),
+    ("qvga_13", SynthConfig(width=320, height=240, gop="IPBBPBB", seed=22, version="1.3")),
+    ("vga_realistic", SynthConfig(width=640, height=480, gop="IPBBPBB", seed=23, preset="realistic")),
+]
+
+_cache = {}
+
+
+def get(name_cfg):
+    name, cfg = name_cfg
+    if name not in _cache:
+        _cache[name] = make_clip(cfg)
+    return _cache[name]
