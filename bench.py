@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- HVQM4 picture-reconstruction throughput on MI355X.
+
+Metric (BASELINE.json): decoded Mpixels/s (bit-exact YUV) and % of the HBM roofline.
+Workload at every N (weak scaling, one rank per GPU, no collective on the data path): the per-GPU
+share of SURVEY.md's config C5 -- 128 concurrent 640x480 HVQM4 1.5 streams, GOP I P B B P B B ...
+(16 pictures), descriptors pre-parsed and resident in HBM.  One "step" = every stream decodes one
+full GOP (128 * 16 = 2048 pictures) through the batched path (hvq_replay): the launches of the
+dependency levels, nothing skipped.  `value` = luma pixels decoded by all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      algorithmic bytes (1.5 B/px written + 1.5 B/px read for P/B)
+                per launch / average launch duration from HIP events on the launch stream, vs 8 TB/s
+  cpu_baseline  the reference decoder (oracle/_ref, kind "reference") or this repo's scalar
+                restatement (kind "port") timed on one host core over a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=128, help="concurrent streams per GPU")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--gop", default="IPBBPBBPBBPBBPBB")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic clips per GPU (replicated over the streams)")
+    ap.add_argument("--preset", default="dense", choices=["dense", "realistic", "flat"])
+    ap.add_argument("--nslots", type=int, default=6)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # noqa: F811  (plumbing only: barrier + max over ranks)
+        import torch.distributed as dist  # noqa: F811
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    from hvqm4_amd import batch
+    from hvqm4_amd.container import video_pictures
+    from hvqm4_amd.synth import SynthConfig, make_clip
+
+    # ---- synthetic inputs (fixed seeds; clip i of rank r has seed 1000 + r*distinct + i) ----
+    t0 = time.time()
+    clips = [make_clip(SynthConfig(width=args.width, height=args.height, version="1.5", gop=args.gop,
+                                   seed=1000 + rank * args.distinct + i, preset=args.preset))
+             for i in range(args.distinct)]
+    gen_s = time.time() - t0
+    pics = [list(video_pictures(c.data)) for c in clips]
+    n_pic = len(args.gop)
+
+    ctx = batch.Context(local_rank)
+    sids = []
+    for s in range(args.streams):
+        sids.append(ctx.open_stream(args.width, args.height, 2, 2, True, args.nslots))
+    # decode-order interleave: picture k of every stream, then k+1 ... (the order a player would submit)
+    t0 = time.time()
+    for k in range(n_pic):
+        for s, sid in enumerate(sids):
+            ft, _d, pic = pics[s % args.distinct][k]
+            ctx.submit(sid, ft, pic)
+    submit_s = time.time() - t0
+    ctx.flush()
+    ctx.sync()
+    st = ctx.stats()
+
+    # ---- parity spot-check against the CPU oracle on what is still resident ----
+    verified = None
+    if not args.no_verify:
+        from oracle import bridge
+        verified = 0
+        for i in range(min(args.distinct, args.streams)):
+            want = bridge.oracle_decode(clips[i].data, n_pic)
+            for k in range(n_pic):
+                try:
+                    got = ctx.read_picture(sids[i], k)
+                except Exception:
+                    continue        # slot already reused by a later picture
+                if not np.array_equal(got, want[k]):
+                    raise SystemExit(f"PARITY FAILURE: stream {i} picture {k} differs from the oracle")
+                verified += 1
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.replay(1)
+    barrier()
+    t0 = time.perf_counter()
+    gpu_ms = ctx.replay(args.steps)          # K steps, timed by HIP events on the launch stream
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    px_step = int(st.luma_pixels)
+    value = px_step * args.steps * world / wall / 1e6
+    launches = int(st.launches)
+    avg_launch_s = gpu_ms * 1e-3 / (args.steps * launches)
+    achieved = st.algorithmic_bytes / launches / avg_launch_s / 1e9
+
+    out = {
+        "metric": "decoded Mpixels/s (bit-exact YUV)",
+        "value": round(value, 1),
+        "unit": "Mpixels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall * 1e3 / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": f"C5 share: {args.streams} concurrent {args.width}x{args.height} HVQM4 1.5 streams per GPU, "
+                        f"GOP {args.gop}, {args.preset} synthetic streams, descriptors resident in HBM",
+            "streams_per_gpu": args.streams, "pictures_per_step": int(st.pictures),
+            "distinct_clips_per_gpu": args.distinct, "launches_per_step": launches,
+            "workgroups_per_step": int(st.workgroups), "nslots": args.nslots, "sharding": "one clip per stream, streams split across GPUs, no collective",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "hvq_recon_kernel", "algorithmic_bytes_per_launch": int(st.algorithmic_bytes // launches),
+            "avg_launch_us": round(avg_launch_s * 1e6, 2),
+            "descriptor_bytes_per_launch": int(st.descriptor_bytes // launches),
+        },
+        "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
+        "host_parse_mpix_s": round(px_step / st.parse_seconds / 1e6, 1) if st.parse_seconds else None,
+        "verified_pictures": verified,
+        "flags_or": int(st.flags_or),
+    }
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(clips[0], args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(clip, budget_s: float):
+    """One host core, decode calls only, same clip as stream 0 of the GPU run."""
+    from oracle import bridge
+    if bridge.have_ref():
+        kind, timer = "reference", bridge.ref_time
+    else:
+        kind, timer = "port", bridge.oracle_time
+    t, px = timer(clip.data, 1)
+    reps = max(1, int(budget_s / max(t, 1e-6)))
+    t, px = timer(clip.data, reps)
+    return {"value": round(px / t / 1e6, 1), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+            "sample": f"{reps} passes over one {clip.width}x{clip.height} {len(clip.kinds)}-picture clip "
+                      f"(decode calls only, {t:.1f} s)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -109,41 +109,15 @@ __device__ __forceinline__ Blk mc_block(const uint8_t *ref, i32 a, i32 stride, i
     return o;
 }
 
-/* Sum of n AOT bases (h4m:679-817).  GATHER(off) returns one 4-bit nest value. */
-template <class Gather>
-__device__ __forceinline__ i32 aot_accumulate(const u32 *__restrict__ bases, u32 n, bool landscape, i32 stride,
-                                              u32 acc[16], Gather gather)
+/* exact floor(num / den) for num <= 4096, den <= 511 (0 -> 0): v_rcp_f32 estimate, integer fix-up.
+ * Replaces the reference's divTable / mcdivTable lookups (h4m:265-273) -- no memory access. */
+__device__ __forceinline__ u32 udiv_small(u32 num, u32 den)
 {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0;
-    for (u32 k = 0; k < n; ++k) {
-        u32 d = bases[k];
-        i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
-        u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
-        i32 o, xs, ys;
-        if (landscape) { o = stride * os + ol; xs = 1 << sl; ys = stride << ss; }
-        else           { o = stride * ol + os; xs = 1 << ss; ys = stride << sl; }
-        u32 e[16];
-        u32 lo = 255, hi = 0;
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                u32 v = gather(o + y * ys + x * xs);
-                e[4 * y + x] = v;
-                lo = min(lo, v);
-                hi = max(hi, v);
-            }
-        i32 inv = k_div16[(hi - lo) & 15];
-        if (d & 0x2000u) inv = -inv;
-        u32 factor = (d >> 14) * (u32)inv;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += factor * e[i];
-    }
-    u32 total = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) total += acc[i];
-    return (i32)total >> 4;
+    u32 q = (u32)((float)num * __builtin_amdgcn_rcpf((float)den));
+    i32 r = (i32)(num - __umul24(q, den));
+    if (r < 0) q -= 1;
+    else if ((u32)r >= den) q += 1;
+    return den ? q : 0u;
 }
 
 /* TOOLCHAIN HAZARD (ROCm 7.2 hipcc, gfx950): `clamp(x >> s, 0, 255)` pairs are pattern-matched into
@@ -163,6 +137,148 @@ __device__ __forceinline__ u32 pack4(i32 a, i32 b, i32 c, i32 d)
     return (u32)a | ((u32)b << 8) | ((u32)c << 16) | ((u32)d << 24);
 }
 
+/*
+ * One AOT basis into the 16 accumulators (h4m:679-732 / 734-773, 775-817).
+ *   reference: factor = (sum + off) * (+-divTable[max-min]);  acc[i] += factor * e[i]   (uint32 wrap)
+ * divTable[r] = 16 * (256 / r), so factor = 16 * s * q.  With <= 15 bases per block s < 2^14, q <= 256:
+ * g = +-s*q fits 24 bits and sum_k g_k * e_ki < 2^31 never wraps, so the MACs run as full-rate
+ * v_mad_i32_i24 and the wrap-exact value is (sum << 4).  BIG (I-luma type byte > 15, never produced by
+ * real encoders) keeps the generic 32-bit wrap arithmetic.
+ */
+template <bool BIG>
+__device__ __forceinline__ void aot_mac(u32 d, const u32 e[16], u32 lo, u32 hi, i32 acc[16])
+{
+    const u32 q = udiv_small(256u, (hi - lo) & 15u);
+    const u32 s = d >> 14;
+    if (!BIG) {
+        i32 g = (i32)__umul24(s, q);
+        if (d & 0x2000u) g = -g;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __mul24(g, (i32)e[i]) + acc[i];
+    } else {
+        u32 f = s * (q << 4);
+        if (d & 0x2000u) f = 0u - f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = (i32)((u32)acc[i] + f * e[i]);
+    }
+}
+
+/* intra AOT block (h4m:1358-1377): nest gathers from LDS */
+template <bool BIG>
+__device__ __forceinline__ Blk intra_aot(const u32 *__restrict__ pay, u32 n, bool landscape, const uint8_t *s_nest,
+                                         i32 V, i32 unk)
+{
+    i32 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    const i32 stride = landscape ? 70 : 38;
+    u32 d = pay[0];
+    for (u32 k = 0; k < n; ++k) {
+        const u32 dn = pay[min(k + 1, n - 1)];                     /* next basis in flight while this one computes */
+        i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
+        u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
+        i32 o, xs, ys;
+        if (landscape) { o = stride * os + ol; xs = 1 << sl; ys = stride << ss; }
+        else           { o = stride * ol + os; xs = 1 << ss; ys = stride << sl; }
+        u32 e[16], lo = 255, hi = 0;
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                u32 v = s_nest[o + y * ys + x * xs];
+                e[4 * y + x] = v;
+                lo = min(lo, v);
+                hi = max(hi, v);
+            }
+        aot_mac<BIG>(d, e, lo, hi, acc);
+        d = dn;
+    }
+    u32 r[16], total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { r[i] = BIG ? (u32)acc[i] : ((u32)acc[i] << 4); total += r[i]; }
+    const u32 delta = ((u32)V << unk) - (u32)((i32)total >> 4);
+    Blk o4;
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+        o4.r[y] = pack4(sar(r[4 * y] + delta, unk), sar(r[4 * y + 1] + delta, unk),
+                        sar(r[4 * y + 2] + delta, unk), sar(r[4 * y + 3] + delta, unk));
+    return o4;
+}
+
+/* MC + AOT residual block (h4m:1379-1420).  The nest is a 70x38 window of the reference LUMA plane
+ * (h4m:1865-1868); each basis row (4 samples at stride 1 or 2) is one unaligned 8-byte load. */
+__device__ __forceinline__ Blk predi_aot(const u32 *__restrict__ pay, u32 nb, bool landscape, const uint8_t *ref,
+                                         i32 origin, i32 lw, i32 slot, Blk m, i32 unk)
+{
+    i32 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    u32 d = nb ? pay[2] : 0u;
+    for (u32 k = 0; k < nb; ++k) {
+        const u32 dn = pay[2 + min(k + 1, nb - 1)];
+        i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
+        u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
+        i32 o, ys; u32 x2;
+        if (landscape) { o = lw * os + ol; x2 = sl; ys = lw << ss; }
+        else           { o = lw * ol + os; x2 = ss; ys = lw << sl; }
+        const u32 sel = x2 ? 0x06040200u : 0x03020100u;             /* stride 2: bytes 0,2,4,6 */
+        u32 e[16], lo = 255, hi = 0;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            uint64_t q = *(const u64u *)(ref + clampi(origin + o + y * ys, 0, slot - 8));
+            u32 w = __builtin_amdgcn_perm((u32)(q >> 32), (u32)q, sel);
+            w = (w >> 4) & 0x0F0F0F0Fu;                              /* upper nibble of each sample, h4m:756-761 */
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                u32 v = (w >> (8 * x)) & 0xFFu;
+                e[4 * y + x] = v;
+                lo = min(lo, v);
+                hi = max(hi, v);
+            }
+        }
+        aot_mac<false>(d, e, lo, hi, acc);
+        d = dn;
+    }
+    u32 total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) total += (u32)acc[i] << 4;
+    const u32 mean_aot = (u32)((i32)total >> 4);
+    u32 sum = 8;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) sum = __builtin_amdgcn_sad_u8(m.r[y], 0u, sum);
+    const i32 mean = (i32)(sum >> 4);
+    i32 px[16];
+    u32 lo = 255, hi = 0;
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            u32 v = (m.r[y] >> (8 * x)) & 0xFFu;
+            px[4 * y + x] = (i32)v;
+            lo = min(lo, v);
+            hi = max(hi, v);
+        }
+    const u32 addend = pay[0] - mean_aot;
+    const i32 gain = (i32)pay[1];
+    const u32 mcd = udiv_small(0x1000u, hi - lo);                    /* mcdivTable[max-min], h4m:272, 1407 */
+    const u32 factor = (u32)gain * mcd;
+    const bool small = gain > -2048 && gain < 2048;                  /* |factor| < 2^23: 24-bit multiply is exact */
+    Blk o4;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        i32 v[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int i = 4 * y + x;
+            u32 t = small ? (u32)__mul24(px[i] - mean, (i32)factor) : (u32)(px[i] - mean) * factor;
+            u32 r = ((u32)acc[i] << 4) + addend + t;
+            v[x] = sar(r, unk) + px[i];
+        }
+        o4.r[y] = pack4(v[0], v[1], v[2], v[3]);
+    }
+    return o4;
+}
+
 __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane)
 {
 #pragma unroll
@@ -173,11 +289,31 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane)
     return v;
 }
 
+/* per-block geometry and descriptors, recomputable from the block's index inside the tile */
+struct BlockCtx {
+    i32 bx, by;
+    const uint8_t *ent;     /* map entry {value, type} */
+    i32 V;
+    u32 T;
+};
+
+__device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, i32 &by)
+{
+    i32 q = (i32)((float)b * rhb);                 /* b < 2^22: estimate within +-1, fixed below */
+    i32 r = (i32)b - q * hb;
+    if (r < 0) { q -= 1; r += hb; }
+    else if (r >= hb) { q += 1; r -= hb; }
+    by = q; bx = r;
+}
+
 __global__ __launch_bounds__(HVQ_WG)
 void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[2672];
     __shared__ u32 s_wave_sum[HVQ_WG / 64];
+    __shared__ u32 s_bin[32];          /* per (class, basis count): count, then start */
+    __shared__ u32 s_total;
+    __shared__ u32 s_items[HVQ_WG];    /* queued expensive blocks: owner lane | payload offset << 10 */
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -190,11 +326,9 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 
     const int p = (tile >= h->tile_first[1]) + (tile >= h->tile_first[2]);
     const i32 hb = h->hb[p], vb = h->vb[p];
+    const float rhb = 1.0f / (float)hb;
     const u32 nblocks = (u32)hb * (u32)vb;
-    const u32 b = (tile - h->tile_first[p]) * HVQ_TILE_BLOCKS + (u32)tid;
-    const bool valid = b < nblocks;
-    const u32 bb = valid ? b : 0;
-    const i32 by = (i32)(bb / (u32)hb), bx = (i32)(bb - (u32)by * (u32)hb);
+    const u32 b0 = (tile - h->tile_first[p]) * HVQ_TILE_BLOCKS;
     const i32 ws = p ? h->wshift : 0, hs = p ? h->hshift : 0;
     const i32 pw = h->width >> ws;
     const u32 flags = h->flags;
@@ -202,119 +336,138 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const bool I_luma = !is_pb && p == 0;
     const i32 unk = h->unk_shift;
     const i32 mstride = hb + 2;
-
+    const bool landscape = flags & HVQ_F_LANDSCAPE;
+    const bool is15 = flags & HVQ_F_IS15;
     const uint8_t *map = blob + h->map_off[p];
+    const u32 *__restrict__ pool = (const u32 *)(blob + h->pool_off);
+    uint8_t *plane = (uint8_t *)job->dst + h->plane_off[p];
+
+    if (tid < 32) s_bin[tid] = 0;
+
+    /* ---- own block: descriptor, payload length, class ---- */
+    const u32 b = b0 + (u32)tid;
+    const bool valid = b < nblocks;
+    i32 bx, by;
+    block_coords(valid ? b : 0u, hb, rhb, bx, by);
     const uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
     const u32 e16 = *(const uint16_t *)ent;
     const i32 V = e16 & 0xFF;
     const u32 T = valid ? (e16 >> 8) : 0u;
     const bool inter = is_pb && (T & 0x60u);
     const u32 kind = I_luma ? T : (T & 0xFu);
-
-    /* payload offset: workgroup exclusive scan of the per-block payload lengths */
     const u32 npay = valid ? hvq_payload_dwords(T, is_pb, I_luma) : 0u;
+    /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual */
+    int cls = 0;
+    u32 nb = 0;
+    if (valid) {
+        if (!inter) { if (kind != 0 && kind != 8 && kind != 6) { cls = 1; nb = kind; } }
+        else if (!(T & 0x10u) && kind != 0 && kind != 6) { cls = 2; nb = kind - 1; }
+    }
+    const u32 key = cls == 1 ? min(nb, 15u) : 16u + nb;
+
     const u32 incl = wave_incl_scan(npay, lane);
     if (lane == 63) s_wave_sum[wave] = incl;
-    const bool need_nest = valid && !inter && kind != 0 && kind != 8 && kind != 6;
-    const int any_nest = __syncthreads_or(need_nest);
+    const int any_nest = __syncthreads_or(cls == 1);                         /* barrier 1 */
     u32 off = ((const u32 *)(blob + h->tile_base_off))[tile] + incl - npay;
 #pragma unroll
     for (int w = 0; w < HVQ_WG / 64 - 1; ++w)
         if (w < wave) off += s_wave_sum[w];
-    const u32 *__restrict__ pay = (const u32 *)(blob + h->pool_off) + off;
 
+    u32 pos = 0;
+    if (cls) pos = atomicAdd(&s_bin[key], 1u);
     if (any_nest) {
         const u32 *src = (const u32 *)(blob + h->nest_off);
         for (int i = tid; i < HVQ_NEST_BYTES / 4; i += HVQ_WG) ((u32 *)s_nest)[i] = src[i];
-        __syncthreads();
     }
-    if (!valid) return;
 
-    Blk o;
-    const bool landscape = flags & HVQ_F_LANDSCAPE;
-    if (!inter) {
-        if (kind == 0) {
-            /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
-             * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
-            u32 t = *(const uint16_t *)(ent - 2 * mstride), bt = *(const uint16_t *)(ent + 2 * mstride);
-            u32 l = *(const uint16_t *)(ent - 2), r = *(const uint16_t *)(ent + 2);
-            i32 Tt = (t & 0x7700u) ? V : (i32)(t & 0xFF);
-            i32 Bb = (bt & 0x7700u) ? V : (i32)(bt & 0xFF);
-            i32 Rr = (r & 0x7700u) ? V : (i32)(r & 0xFF);
-            bool lexp = is_pb ? !(l & 0x7700u) : ((l >> 8) == 0 || (l >> 8) == 8);
-            i32 Ll = lexp ? (i32)(l & 0xFF) : V;
-            o = weight_block(V, Tt, Bb, Ll, Rr);
-        } else if (kind == 8) {
-            u32 v = (u32)V * 0x01010101u;                                     /* h4m:281-286 */
-            o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
-        } else if (kind == 6) {
-            o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3];   /* h4m:543-549 */
-        } else {
-            /* intra AOT (h4m:1358-1377) */
-            u32 acc[16];
-            const i32 nw = landscape ? 70 : 38;
-            i32 mean = aot_accumulate(pay, kind, landscape, nw, acc, [&](i32 a) -> u32 { return s_nest[a]; });
-            u32 delta = ((u32)V << unk) - (u32)mean;
-#pragma unroll
-            for (int y = 0; y < 4; ++y)
-                o.r[y] = pack4(sar(acc[4 * y] + delta, unk), sar(acc[4 * y + 1] + delta, unk),
-                               sar(acc[4 * y + 2] + delta, unk), sar(acc[4 * y + 3] + delta, unk));
-        }
-    } else {
-        const i32 mx = bx >> (1 - ws), my = by >> (1 - hs);
-        const u32 mvw = ((const u32 *)(blob + h->mv_off))[my * (i32)h->mcb_w + mx];
-        const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-        const uint8_t *ref = (const uint8_t *)((((T >> 5) & 3u) == 1u) ? job->ref0 : job->ref1);
-        const i32 slot = (i32)job->slot_bytes;
-        const i32 pdx = rx >> ws, pdy = ry >> hs;
-        const bool is15 = flags & HVQ_F_IS15;
-        const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
-        const i32 a = (i32)h->plane_off[p] + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
-        if ((T & 0x10u) || kind == 0) {
-            o = mc_block(ref, a, pw, hx, hy, slot - 8);
-        } else if (kind == 6) {
+    /* ---- phase A: cheap kinds, in place ---- */
+    if (valid && cls == 0) {
+        Blk o;
+        const u32 *__restrict__ pay = pool + off;
+        if (!inter) {
+            if (kind == 0) {
+                /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
+                 * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
+                u32 t = *(const uint16_t *)(ent - 2 * mstride), bt = *(const uint16_t *)(ent + 2 * mstride);
+                u32 l = *(const uint16_t *)(ent - 2), r = *(const uint16_t *)(ent + 2);
+                i32 Tt = (t & 0x7700u) ? V : (i32)(t & 0xFF);
+                i32 Bb = (bt & 0x7700u) ? V : (i32)(bt & 0xFF);
+                i32 Rr = (r & 0x7700u) ? V : (i32)(r & 0xFF);
+                bool lexp = is_pb ? !(l & 0x7700u) : ((l >> 8) == 0 || (l >> 8) == 8);
+                i32 Ll = lexp ? (i32)(l & 0xFF) : V;
+                o = weight_block(V, Tt, Bb, Ll, Rr);
+            } else if (kind == 8) {
+                u32 v = (u32)V * 0x01010101u;                                 /* h4m:281-286 */
+                o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
+            } else {
+                o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3];   /* literal, h4m:543-549 */
+            }
+        } else if (!(T & 0x10u) && kind == 6) {
             o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3];
         } else {
-            /* MC + AOT residual (h4m:1379-1420); nest = window of the reference LUMA plane (h4m:1865-1868) */
-            const i32 lw = h->width;
-            const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
-            u32 acc[16];
-            u32 mean_aot = (u32)aot_accumulate(pay + 2, kind - 1, landscape, lw, acc,
-                                               [&](i32 g) -> u32 { return (u32)(ref[clampi(origin + g, 0, slot - 1)] >> 4) & 0xFu; });
-            Blk m = mc_block(ref, a, pw, hx, hy, slot - 8);
-            u32 sum = 8;
-#pragma unroll
-            for (int y = 0; y < 4; ++y) sum = __builtin_amdgcn_sad_u8(m.r[y], 0u, sum);
-            const i32 mean = (i32)(sum >> 4);
-            u32 lo = 255, hi = 0;
-#pragma unroll
-            for (int y = 0; y < 4; ++y)
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    u32 v = (m.r[y] >> (8 * x)) & 0xFFu;
-                    lo = min(lo, v);
-                    hi = max(hi, v);
-                }
-            const u32 range = hi - lo;
-            const u32 addend = pay[0] - mean_aot;
-            const u32 factor = pay[1] * (range ? 0x1000u / range : 0u);                /* mcdivTable, h4m:272 */
-#pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                i32 v[4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    i32 px = (i32)((m.r[y] >> (8 * x)) & 0xFFu);
-                    u32 r = acc[4 * y + x] + addend + (u32)(px - mean) * factor;
-                    v[x] = sar(r, unk) + px;
-                }
-                o.r[y] = pack4(v[0], v[1], v[2], v[3]);
-            }
+            const i32 mx = bx >> (1 - ws), my = by >> (1 - hs);
+            const u32 mvw = ((const u32 *)(blob + h->mv_off))[my * (i32)h->mcb_w + mx];
+            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+            const uint8_t *ref = (const uint8_t *)((((T >> 5) & 3u) == 1u) ? job->ref0 : job->ref1);
+            const i32 pdx = rx >> ws, pdy = ry >> hs;
+            const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
+            const i32 a = (i32)h->plane_off[p] + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+            o = mc_block(ref, a, pw, hx, hy, (i32)job->slot_bytes - 8);
         }
+        uint8_t *dst = plane + (size_t)(by * 4) * pw + bx * 4;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) *(u32 *)(dst + (size_t)y * pw) = o.r[y];
     }
 
-    uint8_t *dst = (uint8_t *)job->dst + h->plane_off[p] + (size_t)(by * 4) * pw + bx * 4;
+    __syncthreads();                                                           /* barrier 2: bins counted, nest staged */
+    if (wave == 0) {
+        u32 c = lane < 32 ? s_bin[lane] : 0u;
+        u32 inc = wave_incl_scan(c, lane);
+        if (lane < 32) s_bin[lane] = inc - c;
+        if (lane == 31) s_total = inc;
+    }
+    __syncthreads();                                                           /* barrier 3 */
+    const u32 total = s_total;
+    if (total == 0) return;
+    if (cls) s_items[s_bin[key] + pos] = (u32)tid | (off << 10);
+    __syncthreads();                                                           /* barrier 4 */
+    if ((u32)tid >= total) return;
+
+    /* ---- phase B: queued blocks, sorted by (class, basis count), one per lane ---- */
+    {
+        const u32 item = s_items[tid];
+        const u32 owner = item & 1023u;
+        const u32 *__restrict__ pay = pool + (item >> 10);
+        i32 qx, qy;
+        block_coords(b0 + owner, hb, rhb, qx, qy);
+        const uint8_t *qent = map + 2 * ((qy + 1) * mstride + qx + 1);
+        const u32 q16 = *(const uint16_t *)qent;
+        const i32 QV = q16 & 0xFF;
+        const u32 QT = q16 >> 8;
+        const bool qinter = is_pb && (QT & 0x60u);
+        const u32 qkind = I_luma ? QT : (QT & 0xFu);
+        Blk o;
+        if (!qinter) {
+            if (flags & HVQ_F_BIG_AOT) o = intra_aot<true>(pay, qkind, landscape, s_nest, QV, unk);
+            else                       o = intra_aot<false>(pay, qkind, landscape, s_nest, QV, unk);
+        } else {
+            const i32 mx = qx >> (1 - ws), my = qy >> (1 - hs);
+            const u32 mvw = ((const u32 *)(blob + h->mv_off))[my * (i32)h->mcb_w + mx];
+            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+            const uint8_t *ref = (const uint8_t *)((((QT >> 5) & 3u) == 1u) ? job->ref0 : job->ref1);
+            const i32 slot = (i32)job->slot_bytes;
+            const i32 pdx = rx >> ws, pdy = ry >> hs;
+            const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
+            const i32 a = (i32)h->plane_off[p] + (pdy >> 1) * pw + (pdx >> 1) + (qy & (1 - hs)) * 4 * pw + (qx & (1 - ws)) * 4;
+            const i32 lw = h->width;
+            const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
+            Blk m = mc_block(ref, a, pw, hx, hy, slot - 8);
+            o = predi_aot(pay, qkind - 1, landscape, ref, origin, lw, slot, m, unk);
+        }
+        uint8_t *dst = plane + (size_t)(qy * 4) * pw + qx * 4;
 #pragma unroll
-    for (int y = 0; y < 4; ++y) *(u32 *)(dst + (size_t)y * pw) = o.r[y];
+        for (int y = 0; y < 4; ++y) *(u32 *)(dst + (size_t)y * pw) = o.r[y];
+    }
 }
 
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles, hipStream_t stream)

@@ -443,7 +443,7 @@ static int parse_ipic(HvqParser *p, const uint8_t *pic, uint8_t *blob, size_t ca
     size_t total = (size_t)p->fixed_bytes + 4u * (size_t)pool_dwords;
     if (p->flags & HVQ_F_HAS_NEST) total = ALIGN16(total) + ALIGN16(HVQ_NEST_BYTES);
     total = ALIGN16(total);
-    if (total > cap) return HVQ_E_OVERFLOW;
+    if (total > cap || pool_dwords >= (1u << 22)) return HVQ_E_OVERFLOW;   /* kernel packs offsets in 22 bits */
     fill_header(p, blob, HVQ_PIC_I, pool_dwords, (uint32_t)total);
 
     /* payloads: plane raster order == reference consumption order (h4m:2011-2015) */
@@ -583,7 +583,7 @@ static int parse_pbpic(HvqParser *p, int is_P, const uint8_t *pic, uint8_t *blob
     size_t total = (size_t)p->fixed_bytes + 4u * (size_t)pool_dwords;
     if (p->flags & HVQ_F_HAS_NEST) total = ALIGN16(total) + ALIGN16(HVQ_NEST_BYTES);
     total = ALIGN16(total);
-    if (total > cap) return HVQ_E_OVERFLOW;
+    if (total > cap || pool_dwords >= (1u << 22)) return HVQ_E_OVERFLOW;
     fill_header(p, blob, is_P ? HVQ_PIC_P : HVQ_PIC_B, pool_dwords, (uint32_t)total);
 
     /* pass 2 (h4m:1919-1967): macroblock raster order, planes interleaved */
