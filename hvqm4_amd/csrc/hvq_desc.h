@@ -15,10 +15,11 @@
  *   mv          P/B only: per 8x8 macroblock {i16 ref_x, i16 ref_y}, the ABSOLUTE half-sample
  *               position of the macroblock in the reference picture (h4m:1954-1955); the
  *               predictor chain of getMVector (h4m:1846-1860) is resolved on the host.
- *   tile_base   one u32 per tile: dword index into `pool` of the tile's first payload.
+ *   wave_base   one u32 per 64 blocks (HVQ_TILE_BLOCKS/64 per tile): dword index into `pool`
+ *               of the first payload of that run of 64 blocks.
  *   pool        u32[]: block payloads in (plane, raster) order.  A block's payload length is a
- *               pure function of its map type (hvq_payload_dwords), so a tile finds each
- *               block's payload with one prefix scan -- no per-block offsets are stored.
+ *               pure function of its map type (hvq_payload_dwords), so a wavefront finds each
+ *               block's payload with one 64-lane prefix scan -- no per-block offsets are stored.
  *                 literal block (kind 6)      : 4 dwords = the 16 samples, row-major
  *                 AOT basis                   : 1 dword  = HVQ_BASIS(word, coef_sum)
  *                 MC-residual ("predi") block : 2 dwords {i32 dc_part, i32 gain_part} + bases
@@ -66,7 +67,7 @@ typedef struct HvqPicHeader {
     uint32_t pic_bytes;            /* Y|U|V size */
     uint32_t map_off[3];
     uint32_t mv_off;               /* 0 for I pictures */
-    uint32_t tile_base_off;
+    uint32_t wave_base_off;
     uint32_t pool_off;
     uint32_t pool_dwords;
     uint32_t nest_off;             /* 0 when absent */
@@ -108,15 +109,32 @@ HVQ_HD static inline uint32_t hvq_payload_dwords(uint32_t type, int is_pb, int i
     return (kind == 0 || kind == 8) ? 0u : kind == 6 ? 4u : kind;
 }
 
-/* one reconstruction job = one picture of one stream (device-visible) */
+/* one reconstruction job = one picture of one stream (device-visible).  The runtime copies the
+ * geometry out of the blob header so that a workgroup reaches its map with two dependent loads
+ * (tile table -> job -> map) instead of three. */
 typedef struct HvqJob {
     uint64_t blob;                 /* device address of the descriptor blob */
     uint64_t dst;                  /* device address of the picture being written */
     uint64_t ref0;                 /* "past"   (macroblock type 1) */
     uint64_t ref1;                 /* "future" (macroblock type 2) */
     uint32_t slot_bytes;           /* readable bytes at ref0/ref1 (>= pic_bytes + 8) */
-    uint32_t pad[7];
+    uint32_t flags;
+    uint16_t width, height;
+    uint8_t  pic_kind, unk_shift, wshift, hshift;
+    uint16_t hb[3], vb[3];
+    uint32_t plane_off[3];
+    uint32_t map_off[3];
+    uint32_t mv_off, wave_base_off, pool_off, nest_off;
+    uint32_t tile_first[4];
+    uint32_t mcb_w;
+    uint32_t pad[2];
 } HvqJob;
+
+#if defined(__cplusplus)
+static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
+#else
+_Static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
+#endif
 
 /* one workgroup = one tile */
 typedef struct HvqTileRef {

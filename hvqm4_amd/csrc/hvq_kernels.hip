@@ -279,23 +279,23 @@ __device__ __forceinline__ Blk predi_aot(const u32 *__restrict__ pay, u32 nb, bo
     return o4;
 }
 
-__device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane)
+/* wave64 inclusive prefix sum on the DPP network: Kogge-Stone inside each row of 16 lanes
+ * (row_shr 1,2,4,8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3. */
+__device__ __forceinline__ u32 wave_incl_scan(u32 v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
     return v;
 }
 
-/* per-block geometry and descriptors, recomputable from the block's index inside the tile */
-struct BlockCtx {
-    i32 bx, by;
-    const uint8_t *ent;     /* map entry {value, type} */
-    i32 V;
-    u32 T;
-};
+__device__ __forceinline__ u32 lanes_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
 
 __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, i32 &by)
 {
@@ -306,51 +306,82 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
     by = q; bx = r;
 }
 
+#define HVQ_NW (HVQ_WG / 64)
+
+/*
+ * Workgroup = tile of 256 consecutive blocks of one plane.
+ *   phase A  every lane owns one block: descriptors are fetched with independent loads (own map
+ *            entry, four neighbours, macroblock vector), cheap kinds (flat, weighted-DC, literal,
+ *            plain MC) are reconstructed at once into the LDS tile; AOT blocks are queued.
+ *   phase B  the queue (intra-AOT items first, then MC-residual items; entries carry everything the
+ *            owner already fetched) is re-dealt one item per lane, so the expensive divergent paths
+ *            run on densely packed wavefronts.
+ *   phase C  the finished tile leaves LDS as 16-byte row segments: one store instruction of a wave
+ *            writes four complete 256-byte runs of the destination plane (full cache lines, written
+ *            once -- phase B results never reach HBM as partial lines).
+ */
 __global__ __launch_bounds__(HVQ_WG)
 void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[2672];
-    __shared__ u32 s_wave_sum[HVQ_WG / 64];
-    __shared__ u32 s_bin[32];          /* per (class, basis count): count, then start */
-    __shared__ u32 s_total;
-    __shared__ u32 s_items[HVQ_WG];    /* queued expensive blocks: owner lane | payload offset << 10 */
+    __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];   /* [sample row][block] packed dwords */
+    __shared__ u32 s_item0[HVQ_WG];    /* owner lane | payload offset << 10 */
+    __shared__ u32 s_item1[HVQ_WG];    /* map entry {value, type} */
+    __shared__ u32 s_item2[HVQ_WG];    /* macroblock vector */
+    __shared__ u32 s_cnt[HVQ_NW][2];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const u32 job_id = __builtin_amdgcn_readfirstlane(tiles[blockIdx.x].job);
     const u32 tile = __builtin_amdgcn_readfirstlane(tiles[blockIdx.x].tile);
     if (job_id == 0xFFFFFFFFu) return;            /* padding entry of the XCD-dealt tile table (uniform exit) */
-    const HvqJob *job = jobs + job_id;
-    const uint8_t *__restrict__ blob = (const uint8_t *)job->blob;
-    const HvqPicHeader *__restrict__ h = (const HvqPicHeader *)blob;
+    const HvqJob *__restrict__ J = jobs + job_id;
+    const uint8_t *__restrict__ blob = (const uint8_t *)J->blob;
 
-    const int p = (tile >= h->tile_first[1]) + (tile >= h->tile_first[2]);
-    const i32 hb = h->hb[p], vb = h->vb[p];
+    /* TOOLCHAIN HAZARD (ROCm 7.2 hipcc, gfx950): a wave-uniform but run-time index into these small
+     * arrays was lowered to s_load_dword with base (J + 2p) and soffset 2p; for p = 1 neither part is
+     * dword aligned and the scalar memory unit truncates them separately -> element 0 is read.  All
+     * per-plane fields are therefore fetched with constant indices and selected. */
+#define PSEL(a) (p == 0 ? (a)[0] : p == 1 ? (a)[1] : (a)[2])
+    const u32 tf1 = J->tile_first[1], tf2 = J->tile_first[2];
+    const int p = (tile >= tf1) + (tile >= tf2);
+    const u32 tf = p == 0 ? 0u : p == 1 ? tf1 : tf2;
+    const i32 hb = PSEL(J->hb), vb = PSEL(J->vb);
     const float rhb = 1.0f / (float)hb;
     const u32 nblocks = (u32)hb * (u32)vb;
-    const u32 b0 = (tile - h->tile_first[p]) * HVQ_TILE_BLOCKS;
-    const i32 ws = p ? h->wshift : 0, hs = p ? h->hshift : 0;
-    const i32 pw = h->width >> ws;
-    const u32 flags = h->flags;
-    const bool is_pb = h->pic_kind != HVQ_PIC_I;
+    const u32 b0 = (tile - tf) * HVQ_TILE_BLOCKS;
+    const i32 ws = p ? J->wshift : 0, hs = p ? J->hshift : 0;
+    const i32 pw = J->width >> ws;
+    const u32 flags = J->flags;
+    const bool is_pb = J->pic_kind != HVQ_PIC_I;
     const bool I_luma = !is_pb && p == 0;
-    const i32 unk = h->unk_shift;
+    const i32 unk = J->unk_shift;
     const i32 mstride = hb + 2;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
-    const uint8_t *map = blob + h->map_off[p];
-    const u32 *__restrict__ pool = (const u32 *)(blob + h->pool_off);
-    uint8_t *plane = (uint8_t *)job->dst + h->plane_off[p];
+    const uint8_t *map = blob + PSEL(J->map_off);
+    const u32 *__restrict__ pool = (const u32 *)(blob + J->pool_off);
+    const u32 *__restrict__ mvs = (const u32 *)(blob + J->mv_off);
+    const i32 plane_off = (i32)PSEL(J->plane_off);
+    uint8_t *plane = (uint8_t *)J->dst + plane_off;
+    const i32 slot = (i32)J->slot_bytes;
+    const i32 mcb_w = (i32)J->mcb_w;
+#undef PSEL
 
-    if (tid < 32) s_bin[tid] = 0;
-
-    /* ---- own block: descriptor, payload length, class ---- */
+    /* ---- phase A: own block ---- */
     const u32 b = b0 + (u32)tid;
     const bool valid = b < nblocks;
     i32 bx, by;
     block_coords(valid ? b : 0u, hb, rhb, bx, by);
     const uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
+    /* independent loads first: own entry, four neighbours, vector, wave payload base */
     const u32 e16 = *(const uint16_t *)ent;
+    const u32 nt = *(const uint16_t *)(ent - 2 * mstride), nbt = *(const uint16_t *)(ent + 2 * mstride);
+    const u32 nl = *(const uint16_t *)(ent - 2), nr = *(const uint16_t *)(ent + 2);
+    u32 mvw = 0;
+    if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
+    const u32 wbase = ((const u32 *)(blob + J->wave_base_off))[tile * HVQ_NW + (u32)wave];
+
     const i32 V = e16 & 0xFF;
     const u32 T = valid ? (e16 >> 8) : 0u;
     const bool inter = is_pb && (T & 0x60u);
@@ -358,29 +389,14 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const u32 npay = valid ? hvq_payload_dwords(T, is_pb, I_luma) : 0u;
     /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual */
     int cls = 0;
-    u32 nb = 0;
     if (valid) {
-        if (!inter) { if (kind != 0 && kind != 8 && kind != 6) { cls = 1; nb = kind; } }
-        else if (!(T & 0x10u) && kind != 0 && kind != 6) { cls = 2; nb = kind - 1; }
+        if (!inter) { if (kind != 0 && kind != 8 && kind != 6) cls = 1; }
+        else if (!(T & 0x10u) && kind != 0 && kind != 6) cls = 2;
     }
-    const u32 key = cls == 1 ? min(nb, 15u) : 16u + nb;
+    const u32 off = wbase + wave_incl_scan(npay) - npay;
+    const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+    if (lane == 0) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); }
 
-    const u32 incl = wave_incl_scan(npay, lane);
-    if (lane == 63) s_wave_sum[wave] = incl;
-    const int any_nest = __syncthreads_or(cls == 1);                         /* barrier 1 */
-    u32 off = ((const u32 *)(blob + h->tile_base_off))[tile] + incl - npay;
-#pragma unroll
-    for (int w = 0; w < HVQ_WG / 64 - 1; ++w)
-        if (w < wave) off += s_wave_sum[w];
-
-    u32 pos = 0;
-    if (cls) pos = atomicAdd(&s_bin[key], 1u);
-    if (any_nest) {
-        const u32 *src = (const u32 *)(blob + h->nest_off);
-        for (int i = tid; i < HVQ_NEST_BYTES / 4; i += HVQ_WG) ((u32 *)s_nest)[i] = src[i];
-    }
-
-    /* ---- phase A: cheap kinds, in place ---- */
     if (valid && cls == 0) {
         Blk o;
         const u32 *__restrict__ pay = pool + off;
@@ -388,13 +404,11 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             if (kind == 0) {
                 /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
                  * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
-                u32 t = *(const uint16_t *)(ent - 2 * mstride), bt = *(const uint16_t *)(ent + 2 * mstride);
-                u32 l = *(const uint16_t *)(ent - 2), r = *(const uint16_t *)(ent + 2);
-                i32 Tt = (t & 0x7700u) ? V : (i32)(t & 0xFF);
-                i32 Bb = (bt & 0x7700u) ? V : (i32)(bt & 0xFF);
-                i32 Rr = (r & 0x7700u) ? V : (i32)(r & 0xFF);
-                bool lexp = is_pb ? !(l & 0x7700u) : ((l >> 8) == 0 || (l >> 8) == 8);
-                i32 Ll = lexp ? (i32)(l & 0xFF) : V;
+                i32 Tt = (nt & 0x7700u) ? V : (i32)(nt & 0xFF);
+                i32 Bb = (nbt & 0x7700u) ? V : (i32)(nbt & 0xFF);
+                i32 Rr = (nr & 0x7700u) ? V : (i32)(nr & 0xFF);
+                bool lexp = is_pb ? !(nl & 0x7700u) : ((nl >> 8) == 0 || (nl >> 8) == 8);
+                i32 Ll = lexp ? (i32)(nl & 0xFF) : V;
                 o = weight_block(V, Tt, Bb, Ll, Rr);
             } else if (kind == 8) {
                 u32 v = (u32)V * 0x01010101u;                                 /* h4m:281-286 */
@@ -405,68 +419,85 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         } else if (!(T & 0x10u) && kind == 6) {
             o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3];
         } else {
-            const i32 mx = bx >> (1 - ws), my = by >> (1 - hs);
-            const u32 mvw = ((const u32 *)(blob + h->mv_off))[my * (i32)h->mcb_w + mx];
             const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-            const uint8_t *ref = (const uint8_t *)((((T >> 5) & 3u) == 1u) ? job->ref0 : job->ref1);
+            const uint8_t *ref = (const uint8_t *)((((T >> 5) & 3u) == 1u) ? J->ref0 : J->ref1);
             const i32 pdx = rx >> ws, pdy = ry >> hs;
             const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
-            const i32 a = (i32)h->plane_off[p] + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
-            o = mc_block(ref, a, pw, hx, hy, (i32)job->slot_bytes - 8);
+            const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+            o = mc_block(ref, a, pw, hx, hy, slot - 8);
         }
-        uint8_t *dst = plane + (size_t)(by * 4) * pw + bx * 4;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) *(u32 *)(dst + (size_t)y * pw) = o.r[y];
+        for (int y = 0; y < 4; ++y) s_out[y][tid] = o.r[y];
     }
 
-    __syncthreads();                                                           /* barrier 2: bins counted, nest staged */
-    if (wave == 0) {
-        u32 c = lane < 32 ? s_bin[lane] : 0u;
-        u32 inc = wave_incl_scan(c, lane);
-        if (lane < 32) s_bin[lane] = inc - c;
-        if (lane == 31) s_total = inc;
+    __syncthreads();                                                           /* barrier 1: queue counts */
+    u32 nI = 0, nP = 0, myI = 0, myP = 0;
+#pragma unroll
+    for (int w = 0; w < HVQ_NW; ++w) {
+        const u32 ci = s_cnt[w][0], cp = s_cnt[w][1];
+        if (w < wave) { myI += ci; myP += cp; }
+        nI += ci; nP += cp;
     }
-    __syncthreads();                                                           /* barrier 3 */
-    const u32 total = s_total;
-    if (total == 0) return;
-    if (cls) s_items[s_bin[key] + pos] = (u32)tid | (off << 10);
-    __syncthreads();                                                           /* barrier 4 */
-    if ((u32)tid >= total) return;
+    const u32 total = nI + nP;
+    if (cls) {
+        const u32 slotq = cls == 1 ? myI + lanes_below(m1) : nI + myP + lanes_below(m2);
+        s_item0[slotq] = (u32)tid | (off << 10);
+        s_item1[slotq] = e16;
+        s_item2[slotq] = mvw;
+    }
+    if (nI) {
+        const u32 *src = (const u32 *)(blob + J->nest_off);
+        for (int i = tid; i < HVQ_NEST_BYTES / 4; i += HVQ_WG) ((u32 *)s_nest)[i] = src[i];
+    }
+    if (total) __syncthreads();                                                /* barrier 2: queue + nest staged */
 
-    /* ---- phase B: queued blocks, sorted by (class, basis count), one per lane ---- */
-    {
-        const u32 item = s_items[tid];
+    /* ---- phase B: queued blocks, one per lane ---- */
+    if ((u32)tid < total) {
+        const u32 item = s_item0[tid];
         const u32 owner = item & 1023u;
         const u32 *__restrict__ pay = pool + (item >> 10);
-        i32 qx, qy;
-        block_coords(b0 + owner, hb, rhb, qx, qy);
-        const uint8_t *qent = map + 2 * ((qy + 1) * mstride + qx + 1);
-        const u32 q16 = *(const uint16_t *)qent;
+        const u32 q16 = s_item1[tid];
         const i32 QV = q16 & 0xFF;
         const u32 QT = q16 >> 8;
-        const bool qinter = is_pb && (QT & 0x60u);
-        const u32 qkind = I_luma ? QT : (QT & 0xFu);
         Blk o;
-        if (!qinter) {
+        if ((u32)tid < nI) {
+            const u32 qkind = I_luma ? QT : (QT & 0xFu);
             if (flags & HVQ_F_BIG_AOT) o = intra_aot<true>(pay, qkind, landscape, s_nest, QV, unk);
             else                       o = intra_aot<false>(pay, qkind, landscape, s_nest, QV, unk);
         } else {
-            const i32 mx = qx >> (1 - ws), my = qy >> (1 - hs);
-            const u32 mvw = ((const u32 *)(blob + h->mv_off))[my * (i32)h->mcb_w + mx];
-            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-            const uint8_t *ref = (const uint8_t *)((((QT >> 5) & 3u) == 1u) ? job->ref0 : job->ref1);
-            const i32 slot = (i32)job->slot_bytes;
+            i32 qx, qy;
+            block_coords(b0 + owner, hb, rhb, qx, qy);
+            const u32 qmv = s_item2[tid];
+            const i32 rx = (i32)(int16_t)(qmv & 0xFFFF), ry = (i32)(int16_t)(qmv >> 16);
+            const uint8_t *ref = (const uint8_t *)((((QT >> 5) & 3u) == 1u) ? J->ref0 : J->ref1);
             const i32 pdx = rx >> ws, pdy = ry >> hs;
             const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
-            const i32 a = (i32)h->plane_off[p] + (pdy >> 1) * pw + (pdx >> 1) + (qy & (1 - hs)) * 4 * pw + (qx & (1 - ws)) * 4;
-            const i32 lw = h->width;
+            const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (qy & (1 - hs)) * 4 * pw + (qx & (1 - ws)) * 4;
+            const i32 lw = J->width;
             const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
             Blk m = mc_block(ref, a, pw, hx, hy, slot - 8);
-            o = predi_aot(pay, qkind - 1, landscape, ref, origin, lw, slot, m, unk);
+            o = predi_aot(pay, (QT & 0xFu) - 1u, landscape, ref, origin, lw, slot, m, unk);
         }
-        uint8_t *dst = plane + (size_t)(qy * 4) * pw + qx * 4;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) *(u32 *)(dst + (size_t)y * pw) = o.r[y];
+        for (int y = 0; y < 4; ++y) s_out[y][owner] = o.r[y];
+    }
+    if (total) __syncthreads();                                                /* barrier 3: tile complete in LDS */
+
+    /* ---- phase C: tile -> HBM ---- */
+    if ((hb & 3) == 0) {
+        /* lane (g, r): sample row r of blocks 4g..4g+3 = 16 contiguous bytes of the plane */
+        const int g = wave * 16 + (lane & 15), r = lane >> 4;
+        const u32 gb = b0 + 4u * (u32)g;
+        if (gb < nblocks) {
+            i32 gx, gy;
+            block_coords(gb, hb, rhb, gx, gy);
+            const uint4 v = *(const uint4 *)&s_out[r][4 * g];
+            *(uint4 *)(plane + (size_t)(gy * 4 + r) * pw + gx * 4) = v;
+        }
+    } else if (valid) {
+        uint8_t *dst = plane + (size_t)(by * 4) * pw + bx * 4;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) *(u32 *)(dst + (size_t)y * pw) = s_out[y][tid];
     }
 }
 

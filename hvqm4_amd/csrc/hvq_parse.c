@@ -150,7 +150,7 @@ struct HvqParser {
     int unk_shift, dc_shift;
     int32_t dc_lo, dc_hi;
     uint32_t *blk_off[3];        /* per-block pool offsets (P/B pass 2 writes out of raster order) */
-    uint32_t map_off[3], mv_off, tile_base_off, fixed_bytes, pic_bytes, plane_off[3];
+    uint32_t map_off[3], mv_off, wave_base_off, fixed_bytes, pic_bytes, plane_off[3];
     uint32_t total_tiles;
     uint32_t flags;
     size_t bound;
@@ -190,8 +190,8 @@ HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int 
     p->pic_bytes = poff;
     p->mv_off = off;
     off = ALIGN16(off + 4u * (width / 8) * (height / 8));
-    p->tile_base_off = off;
-    off = ALIGN16(off + 4u * p->total_tiles);
+    p->wave_base_off = off;
+    off = ALIGN16(off + 4u * p->total_tiles * (HVQ_TILE_BLOCKS / 64));
     p->fixed_bytes = off;
     p->bound = (size_t)off + 64u * blocks + ALIGN16(HVQ_NEST_BYTES) + 64;
     return p;
@@ -288,18 +288,18 @@ static void init_maps(const HvqParser *p, uint8_t *blob)                        
     }
 }
 
-/* raster scan of the type maps: per-block pool offsets, per-tile bases, flags; returns pool dwords */
+/* raster scan of the type maps: per-block pool offsets, per-64-block bases, flags; returns pool dwords */
 static uint32_t layout_pool(HvqParser *p, uint8_t *blob, int is_pb)
 {
-    uint32_t *tile_base = (uint32_t *)(blob + p->tile_base_off);
-    uint32_t off = 0, tile = 0;
+    uint32_t *wave_base = (uint32_t *)(blob + p->wave_base_off);
+    uint32_t off = 0, wv = 0;
     for (int i = 0; i < 3; ++i) {
         const PPlane *q = &p->pl[i];
         uint32_t b = 0;
         for (int by = 0; by < q->vb; ++by) {
             const uint8_t *row = map_ent(p, blob, i, by, 0);
             for (int bx = 0; bx < q->hb; ++bx, ++b) {
-                if ((b % HVQ_TILE_BLOCKS) == 0) tile_base[tile++] = off;
+                if ((b & 63u) == 0) wave_base[wv++] = off;
                 uint32_t t = row[2 * bx + 1];
                 p->blk_off[i][b] = off;
                 uint32_t n = hvq_payload_dwords(t, is_pb, !is_pb && i == 0);
@@ -314,6 +314,8 @@ static uint32_t layout_pool(HvqParser *p, uint8_t *blob, int is_pb)
                 off += n;
             }
         }
+        /* the last tile of a plane may be ragged: its unused runs point at the plane's end */
+        while (wv % (HVQ_TILE_BLOCKS / 64)) wave_base[wv++] = off;
     }
     return off;
 }
@@ -341,7 +343,7 @@ static void fill_header(const HvqParser *p, uint8_t *blob, int kind, uint32_t po
     h->tile_first[3] = t;
     h->pic_bytes = p->pic_bytes;
     h->mv_off = kind == HVQ_PIC_I ? 0 : p->mv_off;
-    h->tile_base_off = p->tile_base_off;
+    h->wave_base_off = p->wave_base_off;
     h->pool_off = p->fixed_bytes;
     h->pool_dwords = pool_dwords;
     h->nest_off = (p->flags & HVQ_F_HAS_NEST) ? ALIGN16(p->fixed_bytes + 4u * pool_dwords) : 0;

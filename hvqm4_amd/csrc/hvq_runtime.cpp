@@ -284,6 +284,16 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         j.ref0 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref0);
         j.ref1 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref1);
         j.slot_bytes = s.slot_bytes;
+        const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + p.blob_off);
+        j.flags = hd->flags; j.width = hd->width; j.height = hd->height;
+        j.pic_kind = hd->pic_kind; j.unk_shift = hd->unk_shift; j.wshift = hd->wshift; j.hshift = hd->hshift;
+        for (int k = 0; k < 3; ++k) {
+            j.hb[k] = hd->hb[k]; j.vb[k] = hd->vb[k];
+            j.plane_off[k] = hd->plane_off[k]; j.map_off[k] = hd->map_off[k];
+        }
+        j.mv_off = hd->mv_off; j.wave_base_off = hd->wave_base_off; j.pool_off = hd->pool_off; j.nest_off = hd->nest_off;
+        for (int k = 0; k < 4; ++k) j.tile_first[k] = hd->tile_first[k];
+        j.mcb_w = hd->mcb_w;
         st.pictures++;
         st.luma_pixels += (uint64_t)p.w * p.h;
         st.algorithmic_bytes += (uint64_t)s.pic_bytes * (p.kind == HVQ_PIC_I ? 1u : 2u);

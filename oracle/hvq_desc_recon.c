@@ -92,7 +92,7 @@ API int hvqd_recon(const uint8_t *blob, uint8_t *dst, const uint8_t *ref0, const
     Ctx c = { blob, h, h->nest_off ? blob + h->nest_off : NULL, (h->flags & HVQ_F_LANDSCAPE) ? 70 : 38, slot_bytes, { 0 } };
     for (int i = 1; i < 16; ++i) c.divt[i] = 0x1000 / (i * 16) * 16;
     const uint32_t *pool = (const uint32_t *)(blob + h->pool_off);
-    const uint32_t *tile_base = (const uint32_t *)(blob + h->tile_base_off);
+    const uint32_t *wave_base = (const uint32_t *)(blob + h->wave_base_off);
     const int16_t *mvs = h->mv_off ? (const int16_t *)(blob + h->mv_off) : NULL;
     int is_pb = h->pic_kind != HVQ_PIC_I, is15 = (h->flags & HVQ_F_IS15) != 0;
     int lw = h->width;
@@ -104,7 +104,7 @@ API int hvqd_recon(const uint8_t *blob, uint8_t *dst, const uint8_t *ref0, const
         uint8_t *plane = dst + h->plane_off[p];
         uint32_t off = 0;
         for (uint32_t b = 0; b < (uint32_t)hb * vb; ++b) {
-            if ((b % HVQ_TILE_BLOCKS) == 0) off = tile_base[h->tile_first[p] + b / HVQ_TILE_BLOCKS];
+            if ((b % 64) == 0) off = wave_base[h->tile_first[p] * (HVQ_TILE_BLOCKS / 64) + b / 64];
             int by = (int)(b / hb), bx = (int)(b % hb);
             const uint8_t *e = map + 2 * ((by + 1) * stride + bx + 1);
             uint32_t V = e[0], T = e[1];
