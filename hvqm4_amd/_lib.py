@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhvqm4_amd.so")
+LIB_PATH = os.environ.get("HVQM4_AMD_LIB") or os.path.join(HERE, "libhvqm4_amd.so")   # override: ablation builds only
 
 HVQ_OK, HVQ_E_ARG, HVQ_E_OVERFLOW, HVQ_E_GEOMETRY, HVQ_E_NOGPU, HVQ_E_HIP, HVQ_E_STATE = 0, -1, -2, -3, -4, -5, -6
 ERROR_NAMES = {HVQ_E_ARG: "HVQ_E_ARG", HVQ_E_OVERFLOW: "HVQ_E_OVERFLOW", HVQ_E_GEOMETRY: "HVQ_E_GEOMETRY",

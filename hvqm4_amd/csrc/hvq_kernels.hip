@@ -36,6 +36,12 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 #define HVQ_WG 256
 
+/* ablation builds only (tools/ablate.sh): 1 = no phase B, 2 = no MC loads, 3 = no stores, 4 = descriptors only,
+ * 5 = no cheap-kind compute */
+#ifndef HVQ_ABL
+#define HVQ_ABL 0
+#endif
+
 /* divTable of h4m:265-273: 0x1000 / (i*16) * 16 */
 __device__ __constant__ uint16_t k_div16[16] = { 0, 4096, 2048, 1360, 1024, 816, 672, 576, 512, 448, 400, 368, 336, 304, 288, 272 };
 
@@ -72,11 +78,19 @@ __device__ __forceinline__ i32 clampi(i32 v, i32 lo, i32 hi) { return min(max(v,
 
 /* 4x4 motion-compensated block (h4m:1242-1294).  `a` = linear byte offset of the top-left
  * source sample inside the reference picture buffer. */
-__device__ __forceinline__ Blk mc_block(const uint8_t *ref, i32 a, i32 stride, int hx, int hy, i32 amax8)
+struct McRows { uint64_t q[5]; };
+
+__device__ __forceinline__ McRows mc_load(const uint8_t *ref, i32 a, i32 stride, i32 amax8)
 {
-    uint64_t q[5];
+    McRows r;
 #pragma unroll
-    for (int y = 0; y < 5; ++y) q[y] = *(const u64u *)(ref + clampi(a + y * stride, 0, amax8));
+    for (int y = 0; y < 5; ++y) r.q[y] = *(const u64u *)(ref + clampi(a + y * stride, 0, amax8));
+    return r;
+}
+
+__device__ __forceinline__ Blk mc_filter(const McRows &rows, int hx, int hy)
+{
+    const uint64_t *q = rows.q;
     Blk o;
     if (!hy) {
         if (!hx) {
@@ -109,6 +123,11 @@ __device__ __forceinline__ Blk mc_block(const uint8_t *ref, i32 a, i32 stride, i
     return o;
 }
 
+__device__ __forceinline__ Blk mc_block(const uint8_t *ref, i32 a, i32 stride, int hx, int hy, i32 amax8)
+{
+    return mc_filter(mc_load(ref, a, stride, amax8), hx, hy);
+}
+
 /* exact floor(num / den) for num <= 4096, den <= 511 (0 -> 0): v_rcp_f32 estimate, integer fix-up.
  * Replaces the reference's divTable / mcdivTable lookups (h4m:265-273) -- no memory access. */
 __device__ __forceinline__ u32 udiv_small(u32 num, u32 den)
@@ -138,64 +157,96 @@ __device__ __forceinline__ u32 pack4(i32 a, i32 b, i32 c, i32 d)
 }
 
 /*
- * One AOT basis into the 16 accumulators (h4m:679-732 / 734-773, 775-817).
- *   reference: factor = (sum + off) * (+-divTable[max-min]);  acc[i] += factor * e[i]   (uint32 wrap)
- * divTable[r] = 16 * (256 / r), so factor = 16 * s * q.  With <= 15 bases per block s < 2^14, q <= 256:
- * g = +-s*q fits 24 bits and sum_k g_k * e_ki < 2^31 never wraps, so the MACs run as full-rate
- * v_mad_i32_i24 and the wrap-exact value is (sum << 4).  BIG (I-luma type byte > 15, never produced by
- * real encoders) keeps the generic 32-bit wrap arithmetic.
+ * AOT arithmetic (h4m:679-817).  reference: factor = (sum + off) * (+-divTable[max-min]);
+ * acc[i] += factor * e[i] (uint32 wrap).  divTable[r] = 16 * (256 / r), so factor = 16 * s * q.
+ * With <= 15 bases per block s < 2^14 and q <= 256: g = +-s*q fits 24 bits and sum_k g_k * e_ki < 2^31
+ * never wraps, so products are full-rate 24-bit multiplies and the wrap-exact value is (sum << 4).
+ * BIG (I-luma type byte > 15, never produced by real encoders) keeps generic 32-bit wrap arithmetic.
+ * The host stores the running coefficient sum in every basis dword, so bases are independent and are
+ * processed one per lane; their products meet in LDS with ds_add_u32.
  */
-template <bool BIG>
-__device__ __forceinline__ void aot_mac(u32 d, const u32 e[16], u32 lo, u32 hi, i32 acc[16])
+__device__ __forceinline__ i32 basis_gain(u32 d, u32 lo, u32 hi, bool big)
 {
     const u32 q = udiv_small(256u, (hi - lo) & 15u);
     const u32 s = d >> 14;
-    if (!BIG) {
-        i32 g = (i32)__umul24(s, q);
-        if (d & 0x2000u) g = -g;
+    i32 g = big ? (i32)(s * (q << 4)) : (i32)__umul24(s, q);
+    return (d & 0x2000u) ? -g : g;
+}
+
+__device__ __forceinline__ void basis_scatter(i32 g, const u32 e[16], bool big, i32 *acc_lds)
+{
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = __mul24(g, (i32)e[i]) + acc[i];
-    } else {
-        u32 f = s * (q << 4);
-        if (d & 0x2000u) f = 0u - f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = (i32)((u32)acc[i] + f * e[i]);
+    for (int i = 0; i < 16; ++i) {
+        const i32 t = big ? (i32)((u32)g * e[i]) : __mul24(g, (i32)e[i]);
+        __hip_atomic_fetch_add(acc_lds + i * HVQ_WG, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-/* intra AOT block (h4m:1358-1377): nest gathers from LDS */
-template <bool BIG>
-__device__ __forceinline__ Blk intra_aot(const u32 *__restrict__ pay, u32 n, bool landscape, const uint8_t *s_nest,
-                                         i32 V, i32 unk)
+/* nest gather for one basis, intra (h4m:713-725).  The LDS nest holds two 4-bit values per byte at the
+ * reference's linear index (nibble n of the array = nest_data[n]); a basis row spans at most 7 values,
+ * so one unaligned 8-byte LDS read per row replaces four byte reads. */
+__device__ __forceinline__ void gather_nest(u32 d, bool landscape, const uint8_t *s_nest, u32 e[16], u32 &lo, u32 &hi)
 {
-    i32 acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0;
     const i32 stride = landscape ? 70 : 38;
-    u32 d = pay[0];
-    for (u32 k = 0; k < n; ++k) {
-        const u32 dn = pay[min(k + 1, n - 1)];                     /* next basis in flight while this one computes */
-        i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
-        u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
-        i32 o, xs, ys;
-        if (landscape) { o = stride * os + ol; xs = 1 << sl; ys = stride << ss; }
-        else           { o = stride * ol + os; xs = 1 << ss; ys = stride << sl; }
-        u32 e[16], lo = 255, hi = 0;
+    i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
+    u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
+    i32 o, ys; u32 x2;
+    if (landscape) { o = stride * os + ol; x2 = sl; ys = stride << ss; }
+    else           { o = stride * ol + os; x2 = ss; ys = stride << sl; }
+    const u32 sh = x2 ? 8u : 4u;                                     /* bits between consecutive samples */
+    lo = 255; hi = 0;
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+    for (int y = 0; y < 4; ++y) {
+        const i32 n = o + y * ys;
+        uint64_t q = *(const u64u *)(s_nest + (n >> 1));
+        q >>= 4 * (n & 1);
+        const u32 w0 = (u32)q;
+        /* samples at bits 0, sh, 2sh, 3sh (sh = 4 or 8): all inside the low dword */
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                u32 v = s_nest[o + y * ys + x * xs];
-                e[4 * y + x] = v;
-                lo = min(lo, v);
-                hi = max(hi, v);
-            }
-        aot_mac<BIG>(d, e, lo, hi, acc);
-        d = dn;
+        for (int x = 0; x < 4; ++x) {
+            u32 v = (w0 >> (sh * x)) & 15u;
+            e[4 * y + x] = v;
+            lo = min(lo, v);
+            hi = max(hi, v);
+        }
     }
-    u32 r[16], total = 0;
+}
+
+/* nest gather for one basis, MC residual: the nest is a 70x38 window of the reference LUMA plane
+ * (h4m:1865-1868, 734-765); each basis row (4 samples at stride 1 or 2) is one unaligned 8-byte load */
+__device__ __forceinline__ void gather_window(u32 d, bool landscape, const uint8_t *ref, i32 origin, i32 lw, i32 slot,
+                                              u32 e[16], u32 &lo, u32 &hi)
+{
+    i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
+    u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
+    i32 o, ys; u32 x2;
+    if (landscape) { o = lw * os + ol; x2 = sl; ys = lw << ss; }
+    else           { o = lw * ol + os; x2 = ss; ys = lw << sl; }
+    const u32 sel = x2 ? 0x06040200u : 0x03020100u;                 /* stride 2: bytes 0,2,4,6 */
+    uint64_t q[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { r[i] = BIG ? (u32)acc[i] : ((u32)acc[i] << 4); total += r[i]; }
+    for (int y = 0; y < 4; ++y) q[y] = *(const u64u *)(ref + clampi(origin + o + y * ys, 0, slot - 8));
+    lo = 255; hi = 0;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        u32 w = __builtin_amdgcn_perm((u32)(q[y] >> 32), (u32)q[y], sel);
+        w = (w >> 4) & 0x0F0F0F0Fu;                                  /* upper nibble of each sample */
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            u32 v = (w >> (8 * x)) & 0xFFu;
+            e[4 * y + x] = v;
+            lo = min(lo, v);
+            hi = max(hi, v);
+        }
+    }
+}
+
+/* intra AOT epilogue (h4m:1367-1376): r = wrap-exact accumulators */
+__device__ __forceinline__ Blk intra_finish(const u32 r[16], i32 V, i32 unk)
+{
+    u32 total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) total += r[i];
     const u32 delta = ((u32)V << unk) - (u32)((i32)total >> 4);
     Blk o4;
 #pragma unroll
@@ -205,43 +256,12 @@ __device__ __forceinline__ Blk intra_aot(const u32 *__restrict__ pay, u32 n, boo
     return o4;
 }
 
-/* MC + AOT residual block (h4m:1379-1420).  The nest is a 70x38 window of the reference LUMA plane
- * (h4m:1865-1868); each basis row (4 samples at stride 1 or 2) is one unaligned 8-byte load. */
-__device__ __forceinline__ Blk predi_aot(const u32 *__restrict__ pay, u32 nb, bool landscape, const uint8_t *ref,
-                                         i32 origin, i32 lw, i32 slot, Blk m, i32 unk)
+/* MC residual epilogue (h4m:1385-1419): m = motion-compensated block, p0/p1 = host-resolved scalars */
+__device__ __forceinline__ Blk predi_finish(const u32 r[16], Blk m, u32 p0, u32 p1, i32 unk)
 {
-    i32 acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0;
-    u32 d = nb ? pay[2] : 0u;
-    for (u32 k = 0; k < nb; ++k) {
-        const u32 dn = pay[2 + min(k + 1, nb - 1)];
-        i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
-        u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
-        i32 o, ys; u32 x2;
-        if (landscape) { o = lw * os + ol; x2 = sl; ys = lw << ss; }
-        else           { o = lw * ol + os; x2 = ss; ys = lw << sl; }
-        const u32 sel = x2 ? 0x06040200u : 0x03020100u;             /* stride 2: bytes 0,2,4,6 */
-        u32 e[16], lo = 255, hi = 0;
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            uint64_t q = *(const u64u *)(ref + clampi(origin + o + y * ys, 0, slot - 8));
-            u32 w = __builtin_amdgcn_perm((u32)(q >> 32), (u32)q, sel);
-            w = (w >> 4) & 0x0F0F0F0Fu;                              /* upper nibble of each sample, h4m:756-761 */
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                u32 v = (w >> (8 * x)) & 0xFFu;
-                e[4 * y + x] = v;
-                lo = min(lo, v);
-                hi = max(hi, v);
-            }
-        }
-        aot_mac<false>(d, e, lo, hi, acc);
-        d = dn;
-    }
     u32 total = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) total += (u32)acc[i] << 4;
+    for (int i = 0; i < 16; ++i) total += r[i];
     const u32 mean_aot = (u32)((i32)total >> 4);
     u32 sum = 8;
 #pragma unroll
@@ -258,8 +278,8 @@ __device__ __forceinline__ Blk predi_aot(const u32 *__restrict__ pay, u32 nb, bo
             lo = min(lo, v);
             hi = max(hi, v);
         }
-    const u32 addend = pay[0] - mean_aot;
-    const i32 gain = (i32)pay[1];
+    const u32 addend = p0 - mean_aot;
+    const i32 gain = (i32)p1;
     const u32 mcd = udiv_small(0x1000u, hi - lo);                    /* mcdivTable[max-min], h4m:272, 1407 */
     const u32 factor = (u32)gain * mcd;
     const bool small = gain > -2048 && gain < 2048;                  /* |factor| < 2^23: 24-bit multiply is exact */
@@ -271,8 +291,7 @@ __device__ __forceinline__ Blk predi_aot(const u32 *__restrict__ pay, u32 nb, bo
         for (int x = 0; x < 4; ++x) {
             const int i = 4 * y + x;
             u32 t = small ? (u32)__mul24(px[i] - mean, (i32)factor) : (u32)(px[i] - mean) * factor;
-            u32 r = ((u32)acc[i] << 4) + addend + t;
-            v[x] = sar(r, unk) + px[i];
+            v[x] = sar(r[i] + addend + t, unk) + px[i];
         }
         o4.r[y] = pack4(v[0], v[1], v[2], v[3]);
     }
@@ -307,28 +326,35 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 }
 
 #define HVQ_NW (HVQ_WG / 64)
+#define HVQ_NESTP_BYTES (2660 / 2 + 16)   /* linear nibble index = the reference's byte index (stride 70 / 38) */
+#define HVQ_PAIR_CAP 1024            /* (block, basis) pairs handled basis-parallel per tile; beyond: serial fallback */
 
 /*
  * Workgroup = tile of 256 consecutive blocks of one plane.
- *   phase A  every lane owns one block: descriptors are fetched with independent loads (own map
- *            entry, four neighbours, macroblock vector), cheap kinds (flat, weighted-DC, literal,
- *            plain MC) are reconstructed at once into the LDS tile; AOT blocks are queued.
- *   phase B  the queue (intra-AOT items first, then MC-residual items; entries carry everything the
- *            owner already fetched) is re-dealt one item per lane, so the expensive divergent paths
- *            run on densely packed wavefronts.
- *   phase C  the finished tile leaves LDS as 16-byte row segments: one store instruction of a wave
- *            writes four complete 256-byte runs of the destination plane (full cache lines, written
- *            once -- phase B results never reach HBM as partial lines).
+ *   phase A   every lane owns one block: descriptors are fetched with independent loads (own map
+ *             entry, four neighbours, macroblock vector); cheap kinds (flat, weighted-DC, literal,
+ *             plain MC) are reconstructed at once into the LDS tile; AOT blocks are queued
+ *             (intra items first, then MC-residual items; entries carry what the owner fetched) and
+ *             every basis of every queued block becomes one (item, basis) pair.
+ *   phase B1  one lane per PAIR: nest gather, min/max, gain, 16 products -> ds_add into the item's
+ *             accumulators.  The serial per-block basis loop of the reference (h4m:782-788) becomes one
+ *             parallel step; lane utilisation is independent of how basis counts are distributed.
+ *   phase B2  one lane per queued block: accumulators -> samples (h4m:1367-1376 / 1385-1419).
+ *   phase C   the finished tile leaves LDS as 16-byte row segments: one store instruction of a wave
+ *             writes four complete 256-byte runs of the destination plane (full lines, written once).
  */
 __global__ __launch_bounds__(HVQ_WG)
 void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_nest[2672];
+    __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES];   /* nest packed two 4-bit values per byte */
     __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];   /* [sample row][block] packed dwords */
+    __shared__ i32 s_acc[16][HVQ_WG];      /* AOT accumulators, [sample][queued block]: lanes of one ds_add
+                                              hit consecutive banks (a [block][16] layout is a 32-way conflict) */
     __shared__ u32 s_item0[HVQ_WG];    /* owner lane | payload offset << 10 */
     __shared__ u32 s_item1[HVQ_WG];    /* map entry {value, type} */
     __shared__ u32 s_item2[HVQ_WG];    /* macroblock vector */
-    __shared__ u32 s_cnt[HVQ_NW][2];
+    __shared__ u32 s_pair[HVQ_PAIR_CAP];   /* item | pool index of the basis << 9 */
+    __shared__ u32 s_cnt[HVQ_NW][3];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -359,6 +385,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const i32 mstride = hb + 2;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
+    const bool big = flags & HVQ_F_BIG_AOT;
     const uint8_t *map = blob + PSEL(J->map_off);
     const u32 *__restrict__ pool = (const u32 *)(blob + J->pool_off);
     const u32 *__restrict__ mvs = (const u32 *)(blob + J->mv_off);
@@ -366,6 +393,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     uint8_t *plane = (uint8_t *)J->dst + plane_off;
     const i32 slot = (i32)J->slot_bytes;
     const i32 mcb_w = (i32)J->mcb_w;
+    const i32 lw = J->width;
 #undef PSEL
 
     /* ---- phase A: own block ---- */
@@ -381,23 +409,27 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     u32 mvw = 0;
     if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
     const u32 wbase = ((const u32 *)(blob + J->wave_base_off))[tile * HVQ_NW + (u32)wave];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_acc[i][tid] = 0;
 
     const i32 V = e16 & 0xFF;
     const u32 T = valid ? (e16 >> 8) : 0u;
     const bool inter = is_pb && (T & 0x60u);
     const u32 kind = I_luma ? T : (T & 0xFu);
     const u32 npay = valid ? hvq_payload_dwords(T, is_pb, I_luma) : 0u;
-    /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual */
+    /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual; nb = bases */
     int cls = 0;
+    u32 nb = 0;
     if (valid) {
-        if (!inter) { if (kind != 0 && kind != 8 && kind != 6) cls = 1; }
-        else if (!(T & 0x10u) && kind != 0 && kind != 6) cls = 2;
+        if (!inter) { if (kind != 0 && kind != 8 && kind != 6) { cls = 1; nb = kind; } }
+        else if (!(T & 0x10u) && kind != 0 && kind != 6) { cls = 2; nb = kind - 1; }
     }
     const u32 off = wbase + wave_incl_scan(npay) - npay;
+    const u32 pincl = wave_incl_scan(nb);
     const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
-    if (lane == 0) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); }
+    if (lane == 63) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = pincl; }
 
-    if (valid && cls == 0) {
+    if (HVQ_ABL != 4 && HVQ_ABL != 5 && valid && cls == 0) {
         Blk o;
         const u32 *__restrict__ pay = pool + off;
         if (!inter) {
@@ -424,75 +456,147 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             const i32 pdx = rx >> ws, pdy = ry >> hs;
             const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
             const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
-            o = mc_block(ref, a, pw, hx, hy, slot - 8);
+            if (HVQ_ABL == 2) { o.r[0] = o.r[1] = o.r[2] = o.r[3] = (u32)(a + hx + hy); }
+            else o = mc_block(ref, a, pw, hx, hy, slot - 8);
         }
 #pragma unroll
         for (int y = 0; y < 4; ++y) s_out[y][tid] = o.r[y];
     }
 
     __syncthreads();                                                           /* barrier 1: queue counts */
-    u32 nI = 0, nP = 0, myI = 0, myP = 0;
+    u32 nI = 0, nP = 0, myI = 0, myP = 0, npairs = 0, pbefore = 0;
 #pragma unroll
     for (int w = 0; w < HVQ_NW; ++w) {
-        const u32 ci = s_cnt[w][0], cp = s_cnt[w][1];
-        if (w < wave) { myI += ci; myP += cp; }
-        nI += ci; nP += cp;
+        const u32 ci = s_cnt[w][0], cp = s_cnt[w][1], cb = s_cnt[w][2];
+        if (w < wave) { myI += ci; myP += cp; pbefore += cb; }
+        nI += ci; nP += cp; npairs += cb;
     }
-    const u32 total = nI + nP;
+    const u32 total = (HVQ_ABL == 1 || HVQ_ABL == 4) ? 0u : nI + nP;
+    const bool parallel = npairs <= HVQ_PAIR_CAP;
     if (cls) {
         const u32 slotq = cls == 1 ? myI + lanes_below(m1) : nI + myP + lanes_below(m2);
         s_item0[slotq] = (u32)tid | (off << 10);
         s_item1[slotq] = e16;
         s_item2[slotq] = mvw;
+        if (parallel) {
+            const u32 pstart = pbefore + pincl - nb, bidx = off + (cls == 2 ? 2u : 0u);
+            for (u32 k = 0; k < nb; ++k) s_pair[pstart + k] = slotq | ((bidx + k) << 9);
+        }
     }
     if (nI) {
+        /* 4 nest bytes (values 0..15) -> 2 packed bytes */
         const u32 *src = (const u32 *)(blob + J->nest_off);
-        for (int i = tid; i < HVQ_NEST_BYTES / 4; i += HVQ_WG) ((u32 *)s_nest)[i] = src[i];
+        for (int i = tid; i < HVQ_NEST_BYTES / 4; i += HVQ_WG) {
+            const u32 v = src[i];
+            ((uint16_t *)s_nest)[i] = (uint16_t)((v & 0xFu) | ((v >> 4) & 0xF0u) | ((v >> 8) & 0xF00u) | ((v >> 12) & 0xF000u));
+        }
     }
     if (total) __syncthreads();                                                /* barrier 2: queue + nest staged */
 
-    /* ---- phase B: queued blocks, one per lane ---- */
-    if ((u32)tid < total) {
-        const u32 item = s_item0[tid];
-        const u32 owner = item & 1023u;
-        const u32 *__restrict__ pay = pool + (item >> 10);
-        const u32 q16 = s_item1[tid];
-        const i32 QV = q16 & 0xFF;
-        const u32 QT = q16 >> 8;
-        Blk o;
-        if ((u32)tid < nI) {
-            const u32 qkind = I_luma ? QT : (QT & 0xFu);
-            if (flags & HVQ_F_BIG_AOT) o = intra_aot<true>(pay, qkind, landscape, s_nest, QV, unk);
-            else                       o = intra_aot<false>(pay, qkind, landscape, s_nest, QV, unk);
-        } else {
+    if (total) {
+        /* the queued block this lane finishes in phase B2: fetch its motion-compensated rows and the two
+         * residual scalars now, so they arrive while phase B1 runs */
+        const bool has_item = (u32)tid < total;
+        const bool item_mc = has_item && (u32)tid >= nI;
+        u32 owner = 0, q16 = 0, p0 = 0, p1 = 0;
+        int qhx = 0, qhy = 0;
+        McRows rows;
+#pragma unroll
+        for (int y = 0; y < 5; ++y) rows.q[y] = 0;
+        const u32 *__restrict__ qpay = pool;
+        if (has_item) {
+            const u32 item = s_item0[tid];
+            owner = item & 1023u;
+            qpay = pool + (item >> 10);
+            q16 = s_item1[tid];
+        }
+        if (item_mc) {
             i32 qx, qy;
             block_coords(b0 + owner, hb, rhb, qx, qy);
             const u32 qmv = s_item2[tid];
             const i32 rx = (i32)(int16_t)(qmv & 0xFFFF), ry = (i32)(int16_t)(qmv >> 16);
-            const uint8_t *ref = (const uint8_t *)((((QT >> 5) & 3u) == 1u) ? J->ref0 : J->ref1);
+            const uint8_t *ref = (const uint8_t *)(((q16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
             const i32 pdx = rx >> ws, pdy = ry >> hs;
-            const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
+            qhx = is15 ? (pdx & 1) : (rx & 1); qhy = is15 ? (pdy & 1) : (ry & 1);
             const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (qy & (1 - hs)) * 4 * pw + (qx & (1 - ws)) * 4;
-            const i32 lw = J->width;
-            const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
-            Blk m = mc_block(ref, a, pw, hx, hy, slot - 8);
-            o = predi_aot(pay, (QT & 0xFu) - 1u, landscape, ref, origin, lw, slot, m, unk);
+            rows = mc_load(ref, a, pw, slot - 8);
+            p0 = qpay[0]; p1 = qpay[1];
         }
+
+        u32 r[16];
+        if (parallel) {
+            /* ---- phase B1: one lane per (item, basis) pair ---- */
+            for (u32 pi = (u32)tid; pi < npairs; pi += HVQ_WG) {
+                const u32 pr = s_pair[pi];
+                const u32 it = pr & 511u;
+                const u32 d = pool[pr >> 9];
+                u32 e[16], lo, hi;
+                if (it < nI) {
+                    gather_nest(d, landscape, s_nest, e, lo, hi);
+                } else {
+                    const u32 t16 = s_item1[it], mv = s_item2[it];
+                    const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
+                    const uint8_t *ref = (const uint8_t *)(((t16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
+                    const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
+                    gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
+                }
+                basis_scatter(basis_gain(d, lo, hi, big), e, big, &s_acc[0][it]);
+            }
+            __syncthreads();                                                   /* barrier 3: accumulators complete */
+            if (has_item) {
 #pragma unroll
-        for (int y = 0; y < 4; ++y) s_out[y][owner] = o.r[y];
+                for (int i = 0; i < 16; ++i) r[i] = (u32)s_acc[i][tid];
+            }
+        } else if (has_item) {
+            /* serial fallback for tiles with more than HVQ_PAIR_CAP bases (pathological streams) */
+            i32 acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0;
+            const bool intra_item = (u32)tid < nI;
+            const u32 n = intra_item ? (I_luma ? (q16 >> 8) : ((q16 >> 8) & 0xFu)) : ((q16 >> 8) & 0xFu) - 1u;
+            const u32 *bases = qpay + (intra_item ? 0 : 2);
+            const u32 mv = s_item2[tid];
+            const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
+            const uint8_t *ref = (const uint8_t *)(((q16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
+            const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
+            for (u32 k = 0; k < n; ++k) {
+                const u32 d = bases[k];
+                u32 e[16], lo, hi;
+                if (intra_item) gather_nest(d, landscape, s_nest, e, lo, hi);
+                else gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
+                const i32 g = basis_gain(d, lo, hi, big);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += big ? (i32)((u32)g * e[i]) : __mul24(g, (i32)e[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i] = (u32)acc[i];
+        }
+
+        /* ---- phase B2: one lane per queued block ---- */
+        if (has_item) {
+            if (!big) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) r[i] <<= 4;
+            }
+            Blk o = item_mc ? predi_finish(r, mc_filter(rows, qhx, qhy), p0, p1, unk)
+                            : intra_finish(r, (i32)(q16 & 0xFF), unk);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) s_out[y][owner] = o.r[y];
+        }
+        __syncthreads();                                                       /* barrier 4: tile complete in LDS */
     }
-    if (total) __syncthreads();                                                /* barrier 3: tile complete in LDS */
 
     /* ---- phase C: tile -> HBM ---- */
+    if (HVQ_ABL == 3 || HVQ_ABL == 4) return;
     if ((hb & 3) == 0) {
         /* lane (g, r): sample row r of blocks 4g..4g+3 = 16 contiguous bytes of the plane */
-        const int g = wave * 16 + (lane & 15), r = lane >> 4;
+        const int g = wave * 16 + (lane & 15), rr = lane >> 4;
         const u32 gb = b0 + 4u * (u32)g;
         if (gb < nblocks) {
             i32 gx, gy;
             block_coords(gb, hb, rhb, gx, gy);
-            const uint4 v = *(const uint4 *)&s_out[r][4 * g];
-            *(uint4 *)(plane + (size_t)(gy * 4 + r) * pw + gx * 4) = v;
+            const uint4 v = *(const uint4 *)&s_out[rr][4 * g];
+            *(uint4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
         }
     } else if (valid) {
         uint8_t *dst = plane + (size_t)(by * 4) * pw + bx * 4;

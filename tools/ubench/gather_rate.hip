@@ -1,0 +1,67 @@
+// Microbenchmark: how many scattered small loads per clock does one MI355X CU sustain?
+// Each lane reads N x 8 bytes (unaligned) from pseudo-random places of a buffer that fits the L2/MALL.
+// mode 0: every lane its own random address; mode 1: lane pairs (2k,2k+1) read addresses 4 bytes apart;
+// mode 2: 16 consecutive lanes read consecutive 8-byte words (coalesced 128 B); mode 3: as 0 but 4-byte loads;
+// mode 4: as 0 but 16-byte loads.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef uint64_t __attribute__((aligned(1))) u64u;
+typedef uint32_t __attribute__((aligned(1))) u32u;
+struct __attribute__((aligned(4))) q16 { uint32_t a, b, c, d; };
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(const uint8_t* buf, uint32_t mask, uint32_t* out, int iters)
+{
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t key = MODE == 1 ? (t >> 1) : MODE == 2 ? (t >> 4) : t;
+    uint32_t x = key * 2654435761u + 12345u;
+    uint64_t acc = 0;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x = x * 1664525u + 1013904223u;
+            uint32_t off = (x >> 4) & mask;
+            if (MODE == 1) off += (t & 1) * 4;
+            if (MODE == 2) off = (off & ~127u) + (t & 15) * 8;
+            if (MODE == 3) acc += *(const u32u*)(buf + off);
+            else if (MODE == 4) { q16 v = *(const q16*)(buf + (off & ~3u)); acc += v.a + v.b + v.c + v.d; }
+            else acc += *(const u64u*)(buf + off);
+        }
+    }
+    out[t] = (uint32_t)acc + (uint32_t)(acc >> 32);
+}
+
+template <int MODE> void run(const uint8_t* buf, uint32_t mask, uint32_t* out, const char* name)
+{
+    const int blocks = 256 * 8, iters = 64;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<blocks, 256>>>(buf, mask, out, 4);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<MODE><<<blocks, 256>>>(buf, mask, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double loads = (double)blocks * 256 * iters * 8;
+    printf("%-34s %8.3f ms  %7.2f Glane-loads/s  %6.2f lane-loads/clk/CU (2.4GHz, 256 CU)\n", name, ms, loads / ms * 1e-6,
+           loads / (ms * 1e-3) / 2.4e9 / 256);
+}
+
+int main()
+{
+    for (uint32_t mb : { 2u, 64u }) {
+        uint32_t bytes = mb << 20, mask = bytes - 1 - 255;
+        uint8_t* buf; uint32_t* out;
+        hipMalloc(&buf, bytes + 4096); hipMemset(buf, 1, bytes + 4096);
+        hipMalloc(&out, 256 * 8 * 256 * 4);
+        printf("buffer %u MB\n", mb);
+        run<0>(buf, mask, out, "random 8B per lane");
+        run<1>(buf, mask, out, "lane pairs 4B apart (8B loads)");
+        run<2>(buf, mask, out, "16 lanes x 8B consecutive");
+        run<3>(buf, mask, out, "random 4B per lane");
+        run<4>(buf, mask, out, "random 16B per lane");
+        hipFree(buf); hipFree(out);
+    }
+    return 0;
+}
