@@ -45,20 +45,11 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from hvqm4_amd.distrib import Group
+    grp = Group()                       # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     if world != args.gpus and world > 1:
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
-
-    dist = None
-    torch = None
-    if world > 1:
-        import torch  # noqa: F811  (plumbing only: barrier + max over ranks)
-        import torch.distributed as dist  # noqa: F811
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import numpy as np
     from hvqm4_amd import batch
@@ -107,9 +98,7 @@ def main():
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        grp.barrier()
 
     for _ in range(args.warmup):
         ctx.replay(1)
@@ -117,11 +106,7 @@ def main():
     t0 = time.perf_counter()
     gpu_ms = ctx.replay(args.steps)          # K steps, timed by HIP events on the launch stream
     barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    wall = grp.max(time.perf_counter() - t0)
 
     px_step = int(st.luma_pixels)
     value = px_step * args.steps * world / wall / 1e6
@@ -167,8 +152,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 def cpu_baseline(clip, budget_s: float):

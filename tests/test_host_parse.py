@@ -1,0 +1,94 @@
+"""CPU: the product's host entropy parse (hvq_parse.c, through the C ABI) + the descriptor-blob
+specification (oracle/hvq_desc_recon.c interprets blobs on the CPU) against the oracle.  This checks
+everything the GPU kernels are fed with, without a GPU."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from tests import clips
+
+I_FRAME, P_FRAME, B_FRAME = 0x10, 0x20, 0x30
+
+
+def decode_via_descriptors(clip, truncate=None):
+    from hvqm4_amd._lib import lib
+    from oracle import bridge
+    l = lib()
+    o = bridge.oracle()
+    o.hvqd_recon.restype = C.c_int
+    o.hvqd_recon.argtypes = [C.c_void_p] * 4 + [C.c_uint32]
+    ps = clip.picsize
+    slot = ps + 64
+    prs = l.hvq_parser_create(clip.width, clip.height, 2, 2, 1 if clip.version == "1.5" else 0)
+    assert prs
+    bound = l.hvq_parser_blob_bound(prs)
+    blob = np.zeros(bound, dtype=np.uint8)
+    bufs = [np.zeros(slot, dtype=np.uint8) for _ in range(3)]        # past, present, future
+    out, flags = [], 0
+    for ft, pic in zip(clip.kinds, clip.pictures):
+        if ft != B_FRAME:
+            bufs[0], bufs[2] = bufs[2], bufs[0]
+        n = C.c_size_t(0)
+        data = pic if truncate is None else pic[:truncate]
+        rc = l.hvq_parse_picture(prs, ft, data + b"\0" * 8, len(data), blob.ctypes.data, bound, C.byref(n))
+        assert rc == 0, rc
+        hdr = blob[:128].tobytes()
+        assert struct.unpack_from("<I", hdr, 0)[0] == 0x34515648
+        assert struct.unpack_from("<I", hdr, 4)[0] == n.value
+        flags |= struct.unpack_from("<I", hdr, 20)[0]
+        ref1 = bufs[1] if ft == P_FRAME else bufs[2]
+        assert o.hvqd_recon(blob.ctypes.data, bufs[1].ctypes.data, bufs[0].ctypes.data, ref1.ctypes.data, slot) == 0
+        out.append(bufs[1][:ps].copy())
+        if ft != B_FRAME:
+            bufs[1], bufs[2] = bufs[2], bufs[1]
+    l.hvq_parser_destroy(prs)
+    return np.stack(out), flags
+
+
+@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM[:2], ids=lambda c: c[0])
+def test_parse_plus_descriptor_spec_matches_oracle(case):
+    from oracle import bridge
+    clip = clips.get(case)
+    want = bridge.oracle_decode(clip.data, clip.n_pictures)
+    got, flags = decode_via_descriptors(clip)
+    assert np.array_equal(got, want)
+    assert not flags & 0x28, "legal streams must not be flagged SELF_REF / CLAMPED"
+
+
+def test_big_aot_flag_only_for_weird_streams():
+    _, f_plain = decode_via_descriptors(clips.get(clips.SMALL[3]))
+    _, f_weird = decode_via_descriptors(clips.get(clips.SMALL[9]))
+    assert not f_plain & 0x10
+    assert f_weird & 0x10          # I-luma type bytes > 15 present
+
+
+def test_truncated_pictures_do_not_crash_the_parser():
+    """malformed input: the reference has no validation at all; ours must stay in bounds"""
+    clip = clips.get(clips.SMALL[3])
+    for cut in (0x60, 0x80, 200, 400):
+        decode_via_descriptors(clip, truncate=cut)
+
+
+def test_random_garbage_pictures_do_not_crash_the_parser():
+    from hvqm4_amd._lib import lib
+    l = lib()
+    rng = np.random.default_rng(5)
+    prs = l.hvq_parser_create(64, 48, 2, 2, 1)
+    bound = l.hvq_parser_blob_bound(prs)
+    blob = np.zeros(bound, dtype=np.uint8)
+    for i in range(200):
+        junk = rng.integers(0, 256, int(rng.integers(100, 3000)), dtype=np.uint8).tobytes()
+        n = C.c_size_t(0)
+        rc = l.hvq_parse_picture(prs, (0x10, 0x20, 0x30)[i % 3], junk + b"\0" * 8, len(junk), blob.ctypes.data, bound, C.byref(n))
+        assert rc in (0, -2)
+    l.hvq_parser_destroy(prs)
+
+
+def test_unsupported_geometry_is_rejected():
+    from hvqm4_amd._lib import lib
+    l = lib()
+    assert not l.hvq_parser_create(60, 48, 2, 2, 1)       # width not a multiple of 8 (h4m:1749-1752)
+    assert not l.hvq_parser_create(64, 48, 2, 1, 1)       # sampling the reference itself handles inconsistently
+    assert not l.hvq_parser_create(0, 0, 2, 2, 1)

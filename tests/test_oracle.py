@@ -1,0 +1,98 @@
+"""CPU: the oracle (oracle/hvq_oracle.c) against the golden vectors generated from the reference, against
+the live compiled reference when it is present, and known-answer tests of the pixel primitives."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import clips
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+
+
+@pytest.mark.parametrize("name", [n for n, e in MANIFEST["clips"].items() if "file" in e])
+def test_oracle_matches_golden_small(name):
+    from oracle import bridge
+    e = MANIFEST["clips"][name]
+    data = open(os.path.join(GOLD, e["file"]), "rb").read()
+    assert hashlib.sha256(data).hexdigest() == e["clip_sha256"]
+    pics = bridge.oracle_decode(data, len(e["frame_types"]))
+    got = [hashlib.sha256(p.tobytes()).hexdigest() for p in pics]
+    assert got == e["picture_sha256"]
+
+
+@pytest.mark.parametrize("case", clips.MEDIUM, ids=lambda c: c[0])
+def test_oracle_matches_golden_full_size(case):
+    """320x240 / 640x480 clips are regenerated from their seed; the manifest pins clip bytes and output."""
+    from oracle import bridge
+    e = MANIFEST["clips"][case[0]]
+    clip = clips.get(case)
+    if hashlib.sha256(clip.data).hexdigest() != e["clip_sha256"]:
+        pytest.skip("synthetic generator output drifted from the committed manifest (numpy RNG?)")
+    pics = bridge.oracle_decode(clip.data, clip.n_pictures)
+    assert [hashlib.sha256(p.tobytes()).hexdigest() for p in pics] == e["picture_sha256"]
+
+
+def test_small_fixture_files_equal_generator_output():
+    for case in clips.SMALL:
+        e = MANIFEST["clips"][case[0]]
+        assert hashlib.sha256(clips.get(case).data).hexdigest() == e["clip_sha256"], case[0]
+
+
+@pytest.mark.parametrize("case", clips.SMALL, ids=lambda c: c[0])
+def test_oracle_matches_live_reference(case):
+    from oracle import bridge
+    if not bridge.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    clip = clips.get(case)
+    want, probe = bridge.ref_decode(clip.data, clip.n_pictures, probe=True)
+    got = bridge.oracle_decode(clip.data, clip.n_pictures)
+    assert np.array_equal(got, want)
+    # the writer predicted where the reference's 20 bit-buffer cursors stop
+    for i, cur in enumerate(clip.cursors):
+        for s, c in enumerate(cur):
+            if c >= 0:
+                assert probe[i, s] == c, (i, s)
+
+
+def test_weight_block_known_answers(oracle_lib):
+    for kat in MANIFEST["weight_block_kat"]:
+        out = np.zeros(16, dtype=np.uint8)
+        oracle_lib.hvqo_weight_block(out.ctypes.data, *kat["in"])
+        assert out.tolist() == kat["out"], kat["in"]
+    # sums below -4 wrap through uint32 and saturate to 255
+    out = np.zeros(16, dtype=np.uint8)
+    oracle_lib.hvqo_weight_block(out.ctypes.data, 0, 0, 255, 0, 255)
+    assert out[:4].tolist() == [255, 255, 255, 32]
+
+
+def test_motion_comp_known_answers(oracle_lib):
+    kat = MANIFEST["motion_comp_kat"]
+    src = np.array(kat["src8x8"], dtype=np.uint8)
+    for c in kat["cases"]:
+        out = np.zeros(16, dtype=np.uint8)
+        oracle_lib.hvqo_motion_comp(out.ctypes.data, src.ctypes.data, 8, c["hx"], c["hy"])
+        assert out.tolist() == c["out"], (c["hx"], c["hy"])
+
+
+def test_tables(oracle_lib):
+    d16 = np.zeros(16, dtype=np.int32)
+    m512 = np.zeros(512, dtype=np.int32)
+    oracle_lib.hvqo_tables(d16.ctypes.data, m512.ctypes.data)
+    assert d16.tolist() == MANIFEST["divTable"]
+    assert d16.tolist() == [0, 4096, 2048, 1360, 1024, 816, 672, 576, 512, 448, 400, 368, 336, 304, 288, 272]
+    assert hashlib.sha256(m512.tobytes()).hexdigest() == MANIFEST["mcdivTable_sha256"]
+
+
+def test_idempotent_and_stateless_across_clips():
+    """decoding A, then B, then A again gives the same A (no state leaks between decoder instances)"""
+    from oracle import bridge
+    a, b = clips.get(clips.SMALL[3]), clips.get(clips.SMALL[4])
+    first = bridge.oracle_decode(a.data, a.n_pictures)
+    bridge.oracle_decode(b.data, b.n_pictures)
+    again = bridge.oracle_decode(a.data, a.n_pictures)
+    assert np.array_equal(first, again)
