@@ -373,9 +373,10 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const int p = (tile >= tf1) + (tile >= tf2);
     const u32 tf = p == 0 ? 0u : p == 1 ? tf1 : tf2;
     const i32 hb = PSEL(J->hb), vb = PSEL(J->vb);
-    const float rhb = 1.0f / (float)hb;
-    const u32 nblocks = (u32)hb * (u32)vb;
-    const u32 b0 = (tile - tf) * HVQ_TILE_BLOCKS;
+    const u32 tiles_x = PSEL(J->tiles_x);
+    const u32 tloc = tile - tf;
+    const i32 tyi = (i32)(tloc / tiles_x), txi = (i32)(tloc - (u32)tyi * tiles_x);   /* wave-uniform */
+    const i32 bx0 = txi * HVQ_TILE_W, by0 = tyi * HVQ_TILE_H;
     const i32 ws = p ? J->wshift : 0, hs = p ? J->hshift : 0;
     const i32 pw = J->width >> ws;
     const u32 flags = J->flags;
@@ -397,10 +398,9 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 #undef PSEL
 
     /* ---- phase A: own block ---- */
-    const u32 b = b0 + (u32)tid;
-    const bool valid = b < nblocks;
-    i32 bx, by;
-    block_coords(valid ? b : 0u, hb, rhb, bx, by);
+    const i32 lx = tid & (HVQ_TILE_W - 1), ly = tid >> 4;
+    const bool valid = bx0 + lx < hb && by0 + ly < vb;
+    const i32 bx = valid ? bx0 + lx : 0, by = valid ? by0 + ly : 0;
     const uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
     /* independent loads first: own entry, four neighbours, vector, wave payload base */
     const u32 e16 = *(const uint16_t *)ent;
@@ -511,8 +511,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             q16 = s_item1[tid];
         }
         if (item_mc) {
-            i32 qx, qy;
-            block_coords(b0 + owner, hb, rhb, qx, qy);
+            const i32 qx = bx0 + (i32)(owner & 15u), qy = by0 + (i32)(owner >> 4);
             const u32 qmv = s_item2[tid];
             const i32 rx = (i32)(int16_t)(qmv & 0xFFFF), ry = (i32)(int16_t)(qmv >> 16);
             const uint8_t *ref = (const uint8_t *)(((q16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
@@ -589,13 +588,12 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     /* ---- phase C: tile -> HBM ---- */
     if (HVQ_ABL == 3 || HVQ_ABL == 4) return;
     if ((hb & 3) == 0) {
-        /* lane (g, r): sample row r of blocks 4g..4g+3 = 16 contiguous bytes of the plane */
-        const int g = wave * 16 + (lane & 15), rr = lane >> 4;
-        const u32 gb = b0 + 4u * (u32)g;
-        if (gb < nblocks) {
-            i32 gx, gy;
-            block_coords(gb, hb, rhb, gx, gy);
-            const uint4 v = *(const uint4 *)&s_out[rr][4 * g];
+        /* lane = (block row ly, sample row rr, 16-byte segment seg): consecutive lanes write the consecutive
+         * 16-byte segments of one 64-byte row of the tile */
+        const int seg = tid & 3, rr = (tid >> 2) & 3, cy = tid >> 4;
+        const i32 gx = bx0 + 4 * seg, gy = by0 + cy;
+        if (gx < hb && gy < vb) {
+            const uint4 v = *(const uint4 *)&s_out[rr][cy * HVQ_TILE_W + 4 * seg];
             *(uint4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
         }
     } else if (valid) {

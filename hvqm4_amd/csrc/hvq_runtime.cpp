@@ -294,6 +294,8 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         j.mv_off = hd->mv_off; j.wave_base_off = hd->wave_base_off; j.pool_off = hd->pool_off; j.nest_off = hd->nest_off;
         for (int k = 0; k < 4; ++k) j.tile_first[k] = hd->tile_first[k];
         j.mcb_w = hd->mcb_w;
+        for (int k = 0; k < 3; ++k) j.tiles_x[k] = hd->tiles_x[k];
+        for (int k = 0; k < 4; ++k) j.mv_bits[k] = hd->mv_bits[k];
         st.pictures++;
         st.luma_pixels += (uint64_t)p.w * p.h;
         st.algorithmic_bytes += (uint64_t)s.pic_bytes * (p.kind == HVQ_PIC_I ? 1u : 2u);
