@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--nslots", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--mv-bits", default="0,1,2", help="vector residual-bit choices of the synthetic P/B pictures (reach = 16 << bits samples)")
     args = ap.parse_args()
 
     from hvqm4_amd.distrib import Group
@@ -59,7 +60,8 @@ def main():
     # ---- synthetic inputs (fixed seeds; clip i of rank r has seed 1000 + r*distinct + i) ----
     t0 = time.time()
     clips = [make_clip(SynthConfig(width=args.width, height=args.height, version="1.5", gop=args.gop,
-                                   seed=1000 + rank * args.distinct + i, preset=args.preset))
+                                   seed=1000 + rank * args.distinct + i, preset=args.preset,
+                                   mv_res_bits=tuple(int(x) for x in args.mv_bits.split(","))))
              for i in range(args.distinct)]
     gen_s = time.time() - t0
     pics = [list(video_pictures(c.data)) for c in clips]

@@ -136,7 +136,7 @@ typedef struct HvqJob {
     uint32_t tile_first[4];
     uint32_t mcb_w;
     uint8_t  tiles_x[3];
-    uint8_t  pad0;
+    uint8_t  job_flags;            /* HVQ_JF_* */
     uint8_t  mv_bits[4];
 } HvqJob;
 
@@ -145,6 +145,27 @@ static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
 #else
 _Static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
 #endif
+
+/* job flags (runtime -> kernel) */
+#define HVQ_JF_STAGE0   0x1u      /* stage the ref0 ("past")   source region of every inter tile in LDS */
+#define HVQ_JF_STAGE1   0x2u      /* same for ref1 ("future") */
+
+/* LDS staging of motion-compensation sources.  Vectors reach [-2^(bits+5), 2^(bits+5)) half samples
+ * (h4m:1848-1859), i.e. [-R, R-1] samples with R = 2^(bits+4) >> plane shift, so all 5x8-byte source rows of
+ * a 64x64-sample tile lie inside a (64+2R+8) x (64+2R+5) rectangle of the reference plane. */
+#define HVQ_STAGE_DYN_MIN   (16 * HVQ_TILE_BLOCKS * 4 + 4096)   /* phase-B accumulators + pair list share the region */
+#define HVQ_STAGE_DYN_CAP   (48 * 1024)
+
+HVQ_HD static inline uint32_t hvq_stage_reach(uint32_t bits, uint32_t shift)
+{
+    return ((16u << (bits > 8u ? 8u : bits)) >> shift);
+}
+HVQ_HD static inline uint32_t hvq_stage_pitch(uint32_t rx) { return (HVQ_TILE_W * 4u + 2u * rx + 8u + 15u + 15u) & ~15u; }   /* x0 rounded down, x1 up to 16 */
+HVQ_HD static inline uint32_t hvq_stage_rows(uint32_t ry) { return HVQ_TILE_H * 4u + 2u * ry + 5u; }
+HVQ_HD static inline uint32_t hvq_stage_bytes(uint32_t bits_h, uint32_t bits_v, uint32_t ws, uint32_t hs)
+{
+    return ((hvq_stage_pitch(hvq_stage_reach(bits_h, ws)) * hvq_stage_rows(hvq_stage_reach(bits_v, hs))) + 15u) & ~15u;
+}
 
 /* one workgroup = one tile */
 typedef struct HvqTileRef {

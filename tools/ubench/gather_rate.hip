@@ -2,7 +2,8 @@
 // Each lane reads N x 8 bytes (unaligned) from pseudo-random places of a buffer that fits the L2/MALL.
 // mode 0: every lane its own random address; mode 1: lane pairs (2k,2k+1) read addresses 4 bytes apart;
 // mode 2: 16 consecutive lanes read consecutive 8-byte words (coalesced 128 B); mode 3: as 0 but 4-byte loads;
-// mode 4: as 0 but 16-byte loads.
+// mode 4: as 0 but 16-byte loads; mode 5: every lane its own random 128-byte line, 8 loads inside that line
+// (1 miss + 7 L1 hits); mode 6: as 5 but 4 loads per line (two lines per 8 loads).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -19,10 +20,12 @@ __global__ __launch_bounds__(256) void k(const uint8_t* buf, uint32_t mask, uint
     uint32_t x = key * 2654435761u + 12345u;
     uint64_t acc = 0;
     for (int i = 0; i < iters; ++i) {
+        uint32_t line = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             x = x * 1664525u + 1013904223u;
             uint32_t off = (x >> 4) & mask;
+            if (MODE == 5 || MODE == 6) { if (j % (MODE == 5 ? 8 : 4) == 0) line = off & ~127u; off = line + ((j * 24 + (t & 7)) & 119); }
             if (MODE == 1) off += (t & 1) * 4;
             if (MODE == 2) off = (off & ~127u) + (t & 15) * 8;
             if (MODE == 3) acc += *(const u32u*)(buf + off);
@@ -61,6 +64,8 @@ int main()
         run<2>(buf, mask, out, "16 lanes x 8B consecutive");
         run<3>(buf, mask, out, "random 4B per lane");
         run<4>(buf, mask, out, "random 16B per lane");
+        run<5>(buf, mask, out, "8 x 8B inside one private line");
+        run<6>(buf, mask, out, "4 x 8B inside one private line");
         hipFree(buf); hipFree(out);
     }
     return 0;
