@@ -17,7 +17,7 @@
  *               predictor chain of getMVector (h4m:1846-1860) is resolved on the host.
  *   wave_base   one u32 per 64 blocks (HVQ_TILE_BLOCKS/64 per tile): dword index into `pool`
  *               of the first payload of that run of 64 blocks.
- *   pool        u32[]: block payloads in (plane, tile, raster-in-tile) order.  A block's payload length is a
+ *   pool        u32[]: block payloads in (plane, raster) order.  A block's payload length is a
  *               pure function of its map type (hvq_payload_dwords), so a wavefront finds each
  *               block's payload with one 64-lane prefix scan -- no per-block offsets are stored.
  *                 literal block (kind 6)      : 4 dwords = the 16 samples, row-major
@@ -26,10 +26,8 @@
  *   nest        70*38 bytes (I pictures, and P/B pictures that contain intra AOT blocks; the
  *               nest of the most recent I picture, h4m:1823 -> 1367).
  *
- * A tile is a 16x16 array of 4x4 blocks (64x64 samples) of ONE plane; tiles are numbered in raster
- * order over the plane, blocks in raster order inside the tile (lane = ty*16 + tx); blocks outside the
- * plane (ragged right/bottom tiles) carry no payload.  One workgroup reconstructs one tile.  The square
- * shape keeps the union of the motion-compensation source windows of a tile small enough to stage in LDS.
+ * A tile is HVQ_TILE_BLOCKS consecutive 4x4 blocks of ONE plane in raster order; one
+ * workgroup reconstructs one tile.
  */
 #ifndef HVQ_DESC_H
 #define HVQ_DESC_H
@@ -38,8 +36,6 @@
 
 #define HVQ_MAGIC        0x34515648u   /* "HVQ4" */
 #define HVQ_TILE_BLOCKS  256
-#define HVQ_TILE_W       16            /* blocks */
-#define HVQ_TILE_H       16
 #define HVQ_NEST_BYTES   (70 * 38)
 
 #define HVQ_PIC_I 0
@@ -77,11 +73,7 @@ typedef struct HvqPicHeader {
     uint32_t nest_off;             /* 0 when absent */
     uint32_t tile_first[4];        /* first tile index of plane 0,1,2 and the total */
     uint32_t mcb_w, mcb_h;
-    uint8_t  tiles_x[3];           /* tiles per tile-row of each plane */
-    uint8_t  mv_bits[4];           /* residual bits of the vector streams: h/v for past, h/v for future (h4m:2023-2026):
-                                      vectors reach +-2^(bits+5) half samples */
-    uint8_t  pad1;
-    uint32_t reserved[3];
+    uint32_t reserved[5];
 } HvqPicHeader;
 
 #if defined(__cplusplus)
@@ -135,9 +127,7 @@ typedef struct HvqJob {
     uint32_t mv_off, wave_base_off, pool_off, nest_off;
     uint32_t tile_first[4];
     uint32_t mcb_w;
-    uint8_t  tiles_x[3];
-    uint8_t  job_flags;            /* HVQ_JF_* */
-    uint8_t  mv_bits[4];
+    uint32_t pad[2];
 } HvqJob;
 
 #if defined(__cplusplus)
@@ -145,27 +135,6 @@ static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
 #else
 _Static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
 #endif
-
-/* job flags (runtime -> kernel) */
-#define HVQ_JF_STAGE0   0x1u      /* stage the ref0 ("past")   source region of every inter tile in LDS */
-#define HVQ_JF_STAGE1   0x2u      /* same for ref1 ("future") */
-
-/* LDS staging of motion-compensation sources.  Vectors reach [-2^(bits+5), 2^(bits+5)) half samples
- * (h4m:1848-1859), i.e. [-R, R-1] samples with R = 2^(bits+4) >> plane shift, so all 5x8-byte source rows of
- * a 64x64-sample tile lie inside a (64+2R+8) x (64+2R+5) rectangle of the reference plane. */
-#define HVQ_STAGE_DYN_MIN   (16 * HVQ_TILE_BLOCKS * 4 + 4096)   /* phase-B accumulators + pair list share the region */
-#define HVQ_STAGE_DYN_CAP   (48 * 1024)
-
-HVQ_HD static inline uint32_t hvq_stage_reach(uint32_t bits, uint32_t shift)
-{
-    return ((16u << (bits > 8u ? 8u : bits)) >> shift);
-}
-HVQ_HD static inline uint32_t hvq_stage_pitch(uint32_t rx) { return (HVQ_TILE_W * 4u + 2u * rx + 8u + 15u + 15u) & ~15u; }   /* x0 rounded down, x1 up to 16 */
-HVQ_HD static inline uint32_t hvq_stage_rows(uint32_t ry) { return HVQ_TILE_H * 4u + 2u * ry + 5u; }
-HVQ_HD static inline uint32_t hvq_stage_bytes(uint32_t bits_h, uint32_t bits_v, uint32_t ws, uint32_t hs)
-{
-    return ((hvq_stage_pitch(hvq_stage_reach(bits_h, ws)) * hvq_stage_rows(hvq_stage_reach(bits_v, hs))) + 15u) & ~15u;
-}
 
 /* one workgroup = one tile */
 typedef struct HvqTileRef {

@@ -329,37 +329,33 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 #define HVQ_NESTP_BYTES (2660 / 2 + 16)   /* linear nibble index = the reference's byte index (stride 70 / 38) */
 #define HVQ_PAIR_CAP 1024            /* (block, basis) pairs handled basis-parallel per tile; beyond: serial fallback */
 
-/* staged rectangle of one reference plane: samples [x0,x1) x [y0,y1), LDS byte offset `base`, row pitch */
-struct Stage { i32 x0, y0, x1, y1, pitch; u32 base; bool on; };
-
 /*
- * Workgroup = tile of 16x16 blocks (64x64 samples) of one plane.
- *   stage     P/B tiles: the union of all motion-compensation source windows of the tile (tile rectangle
- *             grown by the vector reach of the picture header) is copied once from each reference plane
- *             into LDS with coalesced row loads -- ~1 L2 request per block instead of 5 scattered ones
- *             (tools/ubench/gather_rate.hip: a CU retires only ~0.43 scattered lines per clock).
- *   phase A   every lane owns one block: independent descriptor loads; cheap kinds (flat, weighted-DC,
- *             literal, plain MC) are reconstructed at once into the LDS tile; the MC part of MC-residual
- *             blocks too; AOT blocks are queued and every basis becomes one (item, basis) pair.
+ * Workgroup = tile of 256 consecutive blocks of one plane.
+ *   phase A   every lane owns one block: descriptors are fetched with independent loads (own map
+ *             entry, four neighbours, macroblock vector); cheap kinds (flat, weighted-DC, literal,
+ *             plain MC) and the MC part of MC-residual blocks are reconstructed at once into the LDS
+ *             tile; AOT blocks are queued
+ *             (intra items first, then MC-residual items; entries carry what the owner fetched) and
+ *             every basis of every queued block becomes one (item, basis) pair.
  *   phase B1  one lane per PAIR: nest gather, min/max, gain, 16 products -> ds_add into the item's
- *             accumulators (aliases the staging region, which is dead by then).
+ *             accumulators.  The serial per-block basis loop of the reference (h4m:782-788) becomes one
+ *             parallel step; lane utilisation is independent of how basis counts are distributed.
  *   phase B2  one lane per queued block: accumulators -> samples (h4m:1367-1376 / 1385-1419).
- *   phase C   the finished tile leaves LDS as 16-byte row segments (every output line written once).
- * Source windows that leave the staged rectangle (vectors pointing across the picture edge: the reference
- * addresses the picture linearly, h4m:1344) are read from global memory with the linear address.
+ *   phase C   the finished tile leaves LDS as 16-byte row segments: one store instruction of a wave
+ *             writes four complete 256-byte runs of the destination plane (full lines, written once).
  */
 __global__ __launch_bounds__(HVQ_WG)
 void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];            /* staging | accumulators + pairs */
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES];   /* nest packed two 4-bit values per byte */
     __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];   /* [sample row][block] packed dwords */
+    __shared__ i32 s_acc[16][HVQ_WG];      /* AOT accumulators, [sample][queued block]: lanes of one ds_add
+                                              hit consecutive banks (a [block][16] layout is a 32-way conflict) */
     __shared__ u32 s_item0[HVQ_WG];    /* owner lane | payload offset << 10 */
     __shared__ u32 s_item1[HVQ_WG];    /* map entry {value, type} */
     __shared__ u32 s_item2[HVQ_WG];    /* macroblock vector */
+    __shared__ u32 s_pair[HVQ_PAIR_CAP];   /* item | pool index of the basis << 9 */
     __shared__ u32 s_cnt[HVQ_NW][3];
-    i32 (*s_acc)[HVQ_WG] = (i32 (*)[HVQ_WG])s_dyn;                 /* [16][256]: [sample][queued block] */
-    u32 *s_pair = (u32 *)(s_dyn + 16 * HVQ_WG * 4);                /* item | pool index of the basis << 9 */
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -378,12 +374,11 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const int p = (tile >= tf1) + (tile >= tf2);
     const u32 tf = p == 0 ? 0u : p == 1 ? tf1 : tf2;
     const i32 hb = PSEL(J->hb), vb = PSEL(J->vb);
-    const u32 tiles_x = PSEL(J->tiles_x);
-    const u32 tloc = tile - tf;
-    const i32 tyi = (i32)(tloc / tiles_x), txi = (i32)(tloc - (u32)tyi * tiles_x);   /* wave-uniform */
-    const i32 bx0 = txi * HVQ_TILE_W, by0 = tyi * HVQ_TILE_H;
+    const float rhb = 1.0f / (float)hb;
+    const u32 nblocks = (u32)hb * (u32)vb;
+    const u32 b0 = (tile - tf) * HVQ_TILE_BLOCKS;
     const i32 ws = p ? J->wshift : 0, hs = p ? J->hshift : 0;
-    const i32 pw = J->width >> ws, ph = J->height >> hs;
+    const i32 pw = J->width >> ws;
     const u32 flags = J->flags;
     const bool is_pb = J->pic_kind != HVQ_PIC_I;
     const bool I_luma = !is_pb && p == 0;
@@ -402,53 +397,11 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const i32 lw = J->width;
 #undef PSEL
 
-    /* ---- stage the MC source regions of both references ---- */
-    Stage st[2];
-    {
-        const u32 jf = is_pb ? J->job_flags : 0u;
-        u32 base = 0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const u32 bh = k ? J->mv_bits[2] : J->mv_bits[0], bv = k ? J->mv_bits[3] : J->mv_bits[1];
-            const i32 rx = (i32)hvq_stage_reach(bh, (u32)ws), ry = (i32)hvq_stage_reach(bv, (u32)hs);
-            Stage &S = st[k];
-            S.on = (jf >> k) & 1u;
-            S.x0 = max(bx0 * 4 - rx, 0) & ~15;                   /* 16-byte columns */
-            S.x1 = min(bx0 * 4 + HVQ_TILE_W * 4 + rx + 8, pw);
-            S.y0 = max(by0 * 4 - ry, 0);
-            S.y1 = min(by0 * 4 + HVQ_TILE_H * 4 + ry + 5, ph);
-            S.pitch = (i32)hvq_stage_pitch((u32)rx);
-            S.base = base;
-            if (S.on) {
-                /* lane = (row within a group of 4, 16-byte column): one wave instruction copies 4 rows; four
-                 * groups are in flight before their LDS stores (the copy is latency-, not bandwidth-critical).
-                 * The last column may run past the row end: that is the next row (linear buffer, slot-padded). */
-                const uint8_t *src = (const uint8_t *)(k ? J->ref1 : J->ref0) + plane_off + S.x0;
-                const int nq = (S.x1 - S.x0 + 15) >> 4;          /* <= 15 */
-                const int nrows = S.y1 - S.y0, q = lane & 15, sub = lane >> 4;
-                uint8_t *dstl = s_dyn + S.base + 16 * q;
-                for (int r0 = wave * 4 + sub; r0 < nrows; r0 += HVQ_NW * 4 * 4) {
-                    uint4 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int row = r0 + u * HVQ_NW * 4;
-                        if (row < nrows && q < nq) v[u] = *(const uint4 *)(src + (size_t)(S.y0 + row) * pw + 16 * q);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int row = r0 + u * HVQ_NW * 4;
-                        if (row < nrows && q < nq) *(uint4 *)(dstl + (u32)(row * S.pitch)) = v[u];
-                    }
-                }
-                base += hvq_stage_bytes(bh, bv, (u32)ws, (u32)hs);
-            }
-        }
-    }
-
     /* ---- phase A: own block ---- */
-    const i32 lx = tid & (HVQ_TILE_W - 1), ly = tid >> 4;
-    const bool valid = bx0 + lx < hb && by0 + ly < vb;
-    const i32 bx = valid ? bx0 + lx : 0, by = valid ? by0 + ly : 0;
+    const u32 b = b0 + (u32)tid;
+    const bool valid = b < nblocks;
+    i32 bx, by;
+    block_coords(valid ? b : 0u, hb, rhb, bx, by);
     const uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
     /* independent loads first: own entry, four neighbours, vector, wave payload base */
     const u32 e16 = *(const uint16_t *)ent;
@@ -457,6 +410,8 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     u32 mvw = 0;
     if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
     const u32 wbase = ((const u32 *)(blob + J->wave_base_off))[tile * HVQ_NW + (u32)wave];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_acc[i][tid] = 0;
 
     const i32 V = e16 & 0xFF;
     const u32 T = valid ? (e16 >> 8) : 0u;
@@ -475,32 +430,19 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
     if (lane == 63) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = pincl; }
 
-    if (st[0].on || st[1].on) __syncthreads();                                 /* barrier 0: staged rows visible */
-
     if (HVQ_ABL != 4 && HVQ_ABL != 5 && valid && cls != 1) {
         Blk o;
         const u32 *__restrict__ pay = pool + off;
         const bool needs_mc = inter && (cls == 2 || (T & 0x10u) || kind == 0);
         if (needs_mc) {
+            /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
             const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-            const int k = (((T >> 5) & 3u) == 1u) ? 0 : 1;
+            const uint8_t *ref = (const uint8_t *)((((T >> 5) & 3u) == 1u) ? J->ref0 : J->ref1);
             const i32 pdx = rx >> ws, pdy = ry >> hs;
             const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
-            const i32 sx = (pdx >> 1) + (bx & (1 - ws)) * 4, sy = (pdy >> 1) + (by & (1 - hs)) * 4;
-            const Stage &S = st[k];
-            McRows rows;
-            if (HVQ_ABL == 2) {
-#pragma unroll
-                for (int y = 0; y < 5; ++y) rows.q[y] = (uint64_t)(sx + sy + y);
-            } else if (S.on && sx >= S.x0 && sx + 8 <= S.x1 && sy >= S.y0 && sy + 5 <= S.y1) {
-                const uint8_t *l = s_dyn + S.base + (u32)((sy - S.y0) * S.pitch + (sx - S.x0));
-#pragma unroll
-                for (int y = 0; y < 5; ++y) rows.q[y] = *(const u64u *)(l + y * S.pitch);
-            } else {
-                const uint8_t *ref = (const uint8_t *)(k ? J->ref1 : J->ref0);
-                rows = mc_load(ref, plane_off + sy * pw + sx, pw, slot - 8);
-            }
-            o = mc_filter(rows, hx, hy);
+            const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+            if (HVQ_ABL == 2) { o.r[0] = o.r[1] = o.r[2] = o.r[3] = (u32)(a + hx + hy); }
+            else o = mc_block(ref, a, pw, hx, hy, slot - 8);
         } else if (!inter && kind == 0) {
             /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
              * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
@@ -520,7 +462,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         for (int y = 0; y < 4; ++y) s_out[y][tid] = o.r[y];
     }
 
-    __syncthreads();                                                           /* barrier 1: queue counts; staging dead */
+    __syncthreads();                                                           /* barrier 1: queue counts */
     u32 nI = 0, nP = 0, myI = 0, myP = 0, npairs = 0, pbefore = 0;
 #pragma unroll
     for (int w = 0; w < HVQ_NW; ++w) {
@@ -530,10 +472,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     }
     const u32 total = (HVQ_ABL == 1 || HVQ_ABL == 4) ? 0u : nI + nP;
     const bool parallel = npairs <= HVQ_PAIR_CAP;
-    if (total) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s_acc[i][tid] = 0;
-    }
     if (cls) {
         const u32 slotq = cls == 1 ? myI + lanes_below(m1) : nI + myP + lanes_below(m2);
         s_item0[slotq] = (u32)tid | (off << 10);
@@ -640,12 +578,13 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     /* ---- phase C: tile -> HBM ---- */
     if (HVQ_ABL == 3 || HVQ_ABL == 4) return;
     if ((hb & 3) == 0) {
-        /* lane = (block row cy, sample row rr, 16-byte segment seg): consecutive lanes write the consecutive
-         * 16-byte segments of one 64-byte row of the tile */
-        const int seg = tid & 3, rr = (tid >> 2) & 3, cy = tid >> 4;
-        const i32 gx = bx0 + 4 * seg, gy = by0 + cy;
-        if (gx < hb && gy < vb) {
-            const uint4 v = *(const uint4 *)&s_out[rr][cy * HVQ_TILE_W + 4 * seg];
+        /* lane (g, r): sample row r of blocks 4g..4g+3 = 16 contiguous bytes of the plane */
+        const int g = wave * 16 + (lane & 15), rr = lane >> 4;
+        const u32 gb = b0 + 4u * (u32)g;
+        if (gb < nblocks) {
+            i32 gx, gy;
+            block_coords(gb, hb, rhb, gx, gy);
+            const uint4 v = *(const uint4 *)&s_out[rr][4 * g];
             *(uint4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
         }
     } else if (valid) {
@@ -655,10 +594,9 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     }
 }
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
-                                       uint32_t dyn_lds, hipStream_t stream)
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles, hipStream_t stream)
 {
     if (ntiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), dyn_lds, stream, jobs_dev, tiles_dev);
+    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), 0, stream, jobs_dev, tiles_dev);
     return hipGetLastError();
 }

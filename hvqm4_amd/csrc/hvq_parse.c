@@ -137,7 +137,6 @@ typedef struct {
     int bx_per, by_per, nblk;    /* blocks of this plane per macroblock */
     int moff[4];                 /* block offsets inside a macroblock, order TL, BL, BR, TR (h4m:447-455, 862-865) */
     uint32_t nblocks, ntiles;
-    int tiles_x, tiles_y;
 } PPlane;
 
 struct HvqParser {
@@ -154,7 +153,6 @@ struct HvqParser {
     uint32_t map_off[3], mv_off, wave_base_off, fixed_bytes, pic_bytes, plane_off[3];
     uint32_t total_tiles;
     uint32_t flags;
-    uint8_t mv_bits[4];
     size_t bound;
 };
 
@@ -180,9 +178,7 @@ HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int 
         q->bx_per = 2 >> ws; q->by_per = 2 >> hs; q->nblk = q->bx_per * q->by_per;
         q->moff[0] = 0; q->moff[1] = q->stride; q->moff[2] = q->stride + 1; q->moff[3] = 1;
         q->nblocks = (uint32_t)q->hb * q->vb;
-        q->tiles_x = (q->hb + HVQ_TILE_W - 1) / HVQ_TILE_W;
-        q->tiles_y = (q->vb + HVQ_TILE_H - 1) / HVQ_TILE_H;
-        q->ntiles = (uint32_t)q->tiles_x * q->tiles_y;
+        q->ntiles = (q->nblocks + HVQ_TILE_BLOCKS - 1) / HVQ_TILE_BLOCKS;
         p->total_tiles += q->ntiles;
         p->map_off[i] = off;
         off = ALIGN16(off + 2u * q->stride * (q->vb + 2));
@@ -292,38 +288,34 @@ static void init_maps(const HvqParser *p, uint8_t *blob)                        
     }
 }
 
-/* walk the type maps in (plane, tile, raster-in-tile) order: per-block pool offsets, per-wave (64 lanes)
- * bases, flags; returns pool dwords */
+/* raster scan of the type maps: per-block pool offsets, per-64-block bases, flags; returns pool dwords */
 static uint32_t layout_pool(HvqParser *p, uint8_t *blob, int is_pb)
 {
     uint32_t *wave_base = (uint32_t *)(blob + p->wave_base_off);
     uint32_t off = 0, wv = 0;
     for (int i = 0; i < 3; ++i) {
         const PPlane *q = &p->pl[i];
-        for (int ty = 0; ty < q->tiles_y; ++ty)
-            for (int tx = 0; tx < q->tiles_x; ++tx)
-                for (int ly = 0; ly < HVQ_TILE_H; ++ly) {
-                    const int by = ty * HVQ_TILE_H + ly;
-                    if ((ly & 3) == 0) wave_base[wv++] = off;        /* 4 tile rows of 16 blocks = one wavefront */
-                    if (by >= q->vb) continue;
-                    const uint8_t *row = map_ent(p, blob, i, by, 0);
-                    for (int lx = 0; lx < HVQ_TILE_W; ++lx) {
-                        const int bx = tx * HVQ_TILE_W + lx;
-                        if (bx >= q->hb) break;
-                        uint32_t t = row[2 * bx + 1];
-                        p->blk_off[i][(uint32_t)by * q->hb + bx] = off;
-                        uint32_t n = hvq_payload_dwords(t, is_pb, !is_pb && i == 0);
-                        if (n) {
-                            int inter = is_pb && (t & 0x60u);
-                            uint32_t kind = (!is_pb && i == 0) ? t : (t & 0xFu);
-                            if (!inter && kind != 6) {
-                                p->flags |= HVQ_F_HAS_NEST;
-                                if (kind > 15) p->flags |= HVQ_F_BIG_AOT;
-                            }
-                        }
-                        off += n;
+        uint32_t b = 0;
+        for (int by = 0; by < q->vb; ++by) {
+            const uint8_t *row = map_ent(p, blob, i, by, 0);
+            for (int bx = 0; bx < q->hb; ++bx, ++b) {
+                if ((b & 63u) == 0) wave_base[wv++] = off;
+                uint32_t t = row[2 * bx + 1];
+                p->blk_off[i][b] = off;
+                uint32_t n = hvq_payload_dwords(t, is_pb, !is_pb && i == 0);
+                if (n) {
+                    int inter = is_pb && (t & 0x60u);
+                    uint32_t kind = (!is_pb && i == 0) ? t : (t & 0xFu);
+                    if (!inter && kind != 6) {
+                        p->flags |= HVQ_F_HAS_NEST;
+                        if (kind > 15) p->flags |= HVQ_F_BIG_AOT;
                     }
                 }
+                off += n;
+            }
+        }
+        /* the last tile of a plane may be ragged: its unused runs point at the plane's end */
+        while (wv % (HVQ_TILE_BLOCKS / 64)) wave_base[wv++] = off;
     }
     return off;
 }
@@ -356,8 +348,6 @@ static void fill_header(const HvqParser *p, uint8_t *blob, int kind, uint32_t po
     h->pool_dwords = pool_dwords;
     h->nest_off = (p->flags & HVQ_F_HAS_NEST) ? ALIGN16(p->fixed_bytes + 4u * pool_dwords) : 0;
     h->mcb_w = (uint32_t)p->w / 8; h->mcb_h = (uint32_t)p->h / 8;
-    for (int i = 0; i < 3; ++i) h->tiles_x[i] = (uint8_t)p->pl[i].tiles_x;
-    memcpy(h->mv_bits, p->mv_bits, 4);
 }
 
 /* ------------------------------------------------------------------ I pictures */
@@ -436,7 +426,6 @@ static int parse_ipic(HvqParser *p, const uint8_t *pic, uint8_t *blob, size_t ca
 {
     p->dc_shift = pic[0];
     p->unk_shift = pic[1];
-    memset(p->mv_bits, 0, 4);
     int nx = (int)be16(pic + 4), ny = (int)be16(pic + 6);
     const uint8_t *tab = pic + 8, *data = pic + 8 + 0x40;
     common_sections(p, data, tab);
@@ -575,7 +564,6 @@ static int parse_pbpic(HvqParser *p, int is_P, const uint8_t *pic, uint8_t *blob
     p->dc_shift = pic[0];
     p->unk_shift = pic[1];
     uint8_t res[6] = { pic[2], pic[4], pic[3], pic[5], 0, 0 };     /* h0 h1 v0 v1 (h4m:2023-2026) */
-    p->mv_bits[0] = pic[2]; p->mv_bits[1] = pic[3]; p->mv_bits[2] = pic[4]; p->mv_bits[3] = pic[5];
     const uint8_t *tab = pic + 8, *data = pic + 8 + 0x44;
     common_sections(p, data, tab);
     p->mvh = section_bits(p, data, tab, 13);

@@ -31,7 +31,7 @@
 #include "hvq_desc.h"
 #include "hvq_parse.h"
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles, uint32_t dyn_lds, hipStream_t stream);
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles, hipStream_t stream);
 
 #define HVQ_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -89,7 +89,7 @@ struct Pending {
 };
 
 struct Launch {
-    uint32_t first_tile, ntiles, dyn_lds;
+    uint32_t first_tile, ntiles;
 };
 
 struct HvqContext {
@@ -271,7 +271,6 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
     int max_level = 0;
     for (auto &p : c->pending) max_level = std::max(max_level, p.level);
     std::vector<HvqJob> jobs(c->pending.size());
-    std::vector<uint32_t> stage_need(c->pending.size(), 0);
     std::vector<HvqTileRef> tiles;
     c->launches.clear();
     HvqStats st{};
@@ -295,18 +294,6 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         j.mv_off = hd->mv_off; j.wave_base_off = hd->wave_base_off; j.pool_off = hd->pool_off; j.nest_off = hd->nest_off;
         for (int k = 0; k < 4; ++k) j.tile_first[k] = hd->tile_first[k];
         j.mcb_w = hd->mcb_w;
-        for (int k = 0; k < 3; ++k) j.tiles_x[k] = hd->tiles_x[k];
-        for (int k = 0; k < 4; ++k) j.mv_bits[k] = hd->mv_bits[k];
-        /* LDS staging of the MC source regions (luma is the largest plane region): enable per reference
-         * while the workgroup's dynamic LDS stays under the cap */
-        if (hd->pic_kind != HVQ_PIC_I && !getenv("HVQM4_AMD_NO_STAGE")) {
-            uint32_t need0 = hvq_stage_bytes(hd->mv_bits[0], hd->mv_bits[1], 0, 0);
-            uint32_t need1 = hd->pic_kind == HVQ_PIC_B ? hvq_stage_bytes(hd->mv_bits[2], hd->mv_bits[3], 0, 0) : 0;
-            uint32_t used = 0;
-            if (need0 <= HVQ_STAGE_DYN_CAP) { j.job_flags |= HVQ_JF_STAGE0; used = need0; }
-            if (need1 && used + need1 <= HVQ_STAGE_DYN_CAP) { j.job_flags |= HVQ_JF_STAGE1; used += need1; }
-            stage_need[i] = used;
-        }
         st.pictures++;
         st.luma_pixels += (uint64_t)p.w * p.h;
         st.algorithmic_bytes += (uint64_t)s.pic_bytes * (p.kind == HVQ_PIC_I ? 1u : 2u);
@@ -316,16 +303,14 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
     for (int lvl = 0; lvl <= max_level; ++lvl) {
         std::vector<HvqTileRef> bins[8];
         int nb = 0;
-        uint32_t dyn = HVQ_STAGE_DYN_MIN;
         for (size_t i = 0; i < c->pending.size(); ++i) {
             const Pending &p = c->pending[i];
             if (p.level != lvl) continue;
-            dyn = std::max(dyn, stage_need[i]);
             auto &bin = bins[nb++ & 7];
             for (uint32_t t = 0; t < p.ntiles; ++t) bin.push_back(HvqTileRef{ (uint32_t)i, t });
         }
         if (!nb) continue;
-        Launch L{ (uint32_t)tiles.size(), 0, dyn };
+        Launch L{ (uint32_t)tiles.size(), 0 };
         if (nb < 8) {
             /* too few pictures to give every XCD its own: plain order, no padding */
             for (int x = 0; x < nb; ++x) tiles.insert(tiles.end(), bins[x].begin(), bins[x].end());
@@ -359,7 +344,7 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
     HIPCHK(hipMemcpyAsync(c->tiles_dev, tiles.data(), tiles.size() * sizeof(HvqTileRef), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     /* 3. one launch per level */
-    for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.dyn_lds, c->stream));
+    for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, c->stream));
     c->stats = st;
     /* the batch is in flight: levels restart from zero for whatever is queued next */
     for (auto &s : c->streams)
@@ -385,7 +370,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; ++r)
-        for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.dyn_lds, c->stream));
+        for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0;

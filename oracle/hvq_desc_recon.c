@@ -103,12 +103,9 @@ API int hvqd_recon(const uint8_t *blob, uint8_t *dst, const uint8_t *ref0, const
         const uint8_t *map = blob + h->map_off[p];
         uint8_t *plane = dst + h->plane_off[p];
         uint32_t off = 0;
-        const int tiles_x = h->tiles_x[p], tiles_y = (vb + HVQ_TILE_H - 1) / HVQ_TILE_H;
-        for (int t = 0; t < tiles_x * tiles_y; ++t)
-        for (int l = 0; l < HVQ_TILE_BLOCKS; ++l) {
-            if ((l & 63) == 0) off = wave_base[(h->tile_first[p] + t) * (HVQ_TILE_BLOCKS / 64) + l / 64];
-            int by = (t / tiles_x) * HVQ_TILE_H + l / HVQ_TILE_W, bx = (t % tiles_x) * HVQ_TILE_W + l % HVQ_TILE_W;
-            if (by >= vb || bx >= hb) continue;
+        for (uint32_t b = 0; b < (uint32_t)hb * vb; ++b) {
+            if ((b % 64) == 0) off = wave_base[h->tile_first[p] * (HVQ_TILE_BLOCKS / 64) + b / 64];
+            int by = (int)(b / hb), bx = (int)(b % hb);
             const uint8_t *e = map + 2 * ((by + 1) * stride + bx + 1);
             uint32_t V = e[0], T = e[1];
             int I_luma = !is_pb && p == 0;
