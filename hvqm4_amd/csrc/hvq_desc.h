@@ -73,7 +73,10 @@ typedef struct HvqPicHeader {
     uint32_t nest_off;             /* 0 when absent */
     uint32_t tile_first[4];        /* first tile index of plane 0,1,2 and the total */
     uint32_t mcb_w, mcb_h;
-    uint32_t reserved[5];
+    uint16_t max_items;            /* most queued (AOT) blocks in any tile: sizes the kernel's LDS accumulators */
+    uint16_t pad1;
+    uint32_t max_pairs;            /* most (block, basis) pairs in any tile */
+    uint32_t reserved[3];
 } HvqPicHeader;
 
 #if defined(__cplusplus)

@@ -80,11 +80,13 @@ __device__ __forceinline__ i32 clampi(i32 v, i32 lo, i32 hi) { return min(max(v,
  * source sample inside the reference picture buffer. */
 struct McRows { uint64_t q[5]; };
 
-__device__ __forceinline__ McRows mc_load(const uint8_t *ref, i32 a, i32 stride, i32 amax8)
+__device__ __forceinline__ McRows mc_load(const uint8_t *ref, i32 a, i32 stride, int hy, i32 amax8)
 {
     McRows r;
 #pragma unroll
-    for (int y = 0; y < 5; ++y) r.q[y] = *(const u64u *)(ref + clampi(a + y * stride, 0, amax8));
+    for (int y = 0; y < 4; ++y) r.q[y] = *(const u64u *)(ref + clampi(a + y * stride, 0, amax8));
+    r.q[4] = 0;
+    if (hy) r.q[4] = *(const u64u *)(ref + clampi(a + 4 * stride, 0, amax8));   /* 5th row only for vertical half samples */
     return r;
 }
 
@@ -125,7 +127,7 @@ __device__ __forceinline__ Blk mc_filter(const McRows &rows, int hx, int hy)
 
 __device__ __forceinline__ Blk mc_block(const uint8_t *ref, i32 a, i32 stride, int hx, int hy, i32 amax8)
 {
-    return mc_filter(mc_load(ref, a, stride, amax8), hx, hy);
+    return mc_filter(mc_load(ref, a, stride, hy, amax8), hx, hy);
 }
 
 /* exact floor(num / den) for num <= 4096, den <= 511 (0 -> 0): v_rcp_f32 estimate, integer fix-up.
@@ -173,12 +175,12 @@ __device__ __forceinline__ i32 basis_gain(u32 d, u32 lo, u32 hi, bool big)
     return (d & 0x2000u) ? -g : g;
 }
 
-__device__ __forceinline__ void basis_scatter(i32 g, const u32 e[16], bool big, i32 *acc_lds)
+__device__ __forceinline__ void basis_scatter(i32 g, const u32 e[16], bool big, i32 *acc_lds, u32 stride)
 {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const i32 t = big ? (i32)((u32)g * e[i]) : __mul24(g, (i32)e[i]);
-        __hip_atomic_fetch_add(acc_lds + i * HVQ_WG, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(acc_lds + i * stride, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -345,16 +347,17 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
  *             writes four complete 256-byte runs of the destination plane (full lines, written once).
  */
 __global__ __launch_bounds__(HVQ_WG)
-void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles)
+void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles, u32 items_cap, u32 pair_cap)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];   /* accumulators [16][items_cap] + pair list [pair_cap] */
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES];   /* nest packed two 4-bit values per byte */
     __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];   /* [sample row][block] packed dwords */
-    __shared__ i32 s_acc[16][HVQ_WG];      /* AOT accumulators, [sample][queued block]: lanes of one ds_add
-                                              hit consecutive banks (a [block][16] layout is a 32-way conflict) */
+    i32 *s_acc = (i32 *)s_dyn;             /* AOT accumulators, [sample][queued block]: lanes of one ds_add hit
+                                              consecutive banks (a [block][16] layout is a 32-way conflict) */
+    u32 *s_pair = (u32 *)(s_dyn + 64u * items_cap);   /* item | pool index of the basis << 9 */
     __shared__ u32 s_item0[HVQ_WG];    /* owner lane | payload offset << 10 */
     __shared__ u32 s_item1[HVQ_WG];    /* map entry {value, type} */
     __shared__ u32 s_item2[HVQ_WG];    /* macroblock vector */
-    __shared__ u32 s_pair[HVQ_PAIR_CAP];   /* item | pool index of the basis << 9 */
     __shared__ u32 s_cnt[HVQ_NW][3];
 
     const int tid = threadIdx.x;
@@ -410,8 +413,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     u32 mvw = 0;
     if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
     const u32 wbase = ((const u32 *)(blob + J->wave_base_off))[tile * HVQ_NW + (u32)wave];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s_acc[i][tid] = 0;
 
     const i32 V = e16 & 0xFF;
     const u32 T = valid ? (e16 >> 8) : 0u;
@@ -471,7 +472,11 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         nI += ci; nP += cp; npairs += cb;
     }
     const u32 total = (HVQ_ABL == 1 || HVQ_ABL == 4) ? 0u : nI + nP;
-    const bool parallel = npairs <= HVQ_PAIR_CAP;
+    const bool parallel = npairs <= pair_cap && total <= items_cap;
+    if (total && parallel && (u32)tid < items_cap) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s_acc[i * items_cap + tid] = 0;
+    }
     if (cls) {
         const u32 slotq = cls == 1 ? myI + lanes_below(m1) : nI + myP + lanes_below(m2);
         s_item0[slotq] = (u32)tid | (off << 10);
@@ -522,12 +527,12 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
                     const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
                     gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
                 }
-                basis_scatter(basis_gain(d, lo, hi, big), e, big, &s_acc[0][it]);
+                basis_scatter(basis_gain(d, lo, hi, big), e, big, s_acc + it, items_cap);
             }
             __syncthreads();                                                   /* barrier 3: accumulators complete */
             if (has_item) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) r[i] = (u32)s_acc[i][tid];
+                for (int i = 0; i < 16; ++i) r[i] = (u32)s_acc[i * items_cap + tid];
             }
         } else if (has_item) {
             /* serial fallback for tiles with more than HVQ_PAIR_CAP bases (pathological streams) */
@@ -594,9 +599,11 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     }
 }
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles, hipStream_t stream)
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
+                                       uint32_t items_cap, uint32_t pair_cap, hipStream_t stream)
 {
     if (ntiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), 0, stream, jobs_dev, tiles_dev);
+    const uint32_t dyn = 64u * items_cap + 4u * pair_cap;
+    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), dyn, stream, jobs_dev, tiles_dev, items_cap, pair_cap);
     return hipGetLastError();
 }

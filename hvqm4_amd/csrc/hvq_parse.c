@@ -153,6 +153,7 @@ struct HvqParser {
     uint32_t map_off[3], mv_off, wave_base_off, fixed_bytes, pic_bytes, plane_off[3];
     uint32_t total_tiles;
     uint32_t flags;
+    uint32_t max_items, max_pairs;
     size_t bound;
 };
 
@@ -293,13 +294,15 @@ static uint32_t layout_pool(HvqParser *p, uint8_t *blob, int is_pb)
 {
     uint32_t *wave_base = (uint32_t *)(blob + p->wave_base_off);
     uint32_t off = 0, wv = 0;
+    p->max_items = 0; p->max_pairs = 0;
     for (int i = 0; i < 3; ++i) {
         const PPlane *q = &p->pl[i];
-        uint32_t b = 0;
+        uint32_t b = 0, items = 0, pairs = 0;
         for (int by = 0; by < q->vb; ++by) {
             const uint8_t *row = map_ent(p, blob, i, by, 0);
             for (int bx = 0; bx < q->hb; ++bx, ++b) {
                 if ((b & 63u) == 0) wave_base[wv++] = off;
+                if ((b % HVQ_TILE_BLOCKS) == 0) items = pairs = 0;
                 uint32_t t = row[2 * bx + 1];
                 p->blk_off[i][b] = off;
                 uint32_t n = hvq_payload_dwords(t, is_pb, !is_pb && i == 0);
@@ -309,6 +312,11 @@ static uint32_t layout_pool(HvqParser *p, uint8_t *blob, int is_pb)
                     if (!inter && kind != 6) {
                         p->flags |= HVQ_F_HAS_NEST;
                         if (kind > 15) p->flags |= HVQ_F_BIG_AOT;
+                    }
+                    if (kind != 6) {                      /* queued by the kernel: intra AOT or MC residual */
+                        items += 1; pairs += inter ? kind - 1 : kind;
+                        if (items > p->max_items) p->max_items = items;
+                        if (pairs > p->max_pairs) p->max_pairs = pairs;
                     }
                 }
                 off += n;
@@ -348,6 +356,7 @@ static void fill_header(const HvqParser *p, uint8_t *blob, int kind, uint32_t po
     h->pool_dwords = pool_dwords;
     h->nest_off = (p->flags & HVQ_F_HAS_NEST) ? ALIGN16(p->fixed_bytes + 4u * pool_dwords) : 0;
     h->mcb_w = (uint32_t)p->w / 8; h->mcb_h = (uint32_t)p->h / 8;
+    h->max_items = (uint16_t)p->max_items; h->max_pairs = p->max_pairs;
 }
 
 /* ------------------------------------------------------------------ I pictures */

@@ -31,7 +31,8 @@
 #include "hvq_desc.h"
 #include "hvq_parse.h"
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles, hipStream_t stream);
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
+                                       uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
 
 #define HVQ_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -81,6 +82,7 @@ struct Stream {
 };
 
 struct Pending {
+    uint32_t max_items, max_pairs;
     int stream, ordinal, level;
     size_t blob_off, blob_len;
     int dst, ref0, ref1;
@@ -90,6 +92,7 @@ struct Pending {
 
 struct Launch {
     uint32_t first_tile, ntiles;
+    uint32_t items_cap, pair_cap;      /* LDS sizing of the launch: max over its pictures */
 };
 
 struct HvqContext {
@@ -240,6 +243,7 @@ HVQ_EXPORT int hvq_stream_submit(HvqContext *c, int sid, int frame_type, const u
     q.stream = sid; q.ordinal = s.npics; q.blob_off = off; q.blob_len = blen;
     const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + off);
     q.ntiles = hd->tile_first[3]; q.kind = hd->pic_kind; q.w = hd->width; q.h = hd->height;
+    q.max_items = hd->max_items; q.max_pairs = hd->max_pairs;
     if (frame_type != HVQ_FRAME_B) std::swap(s.anchor_old, s.anchor_new);   /* past <-> future */
     q.dst = alloc_slot(s);
     if (frame_type == HVQ_FRAME_I) { q.ref0 = -1; q.ref1 = -1; }
@@ -303,14 +307,18 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
     for (int lvl = 0; lvl <= max_level; ++lvl) {
         std::vector<HvqTileRef> bins[8];
         int nb = 0;
+        uint32_t mi = 0, mp = 0;
         for (size_t i = 0; i < c->pending.size(); ++i) {
             const Pending &p = c->pending[i];
             if (p.level != lvl) continue;
+            mi = std::max(mi, p.max_items); mp = std::max(mp, p.max_pairs);
             auto &bin = bins[nb++ & 7];
             for (uint32_t t = 0; t < p.ntiles; ++t) bin.push_back(HvqTileRef{ (uint32_t)i, t });
         }
         if (!nb) continue;
-        Launch L{ (uint32_t)tiles.size(), 0 };
+        /* accumulators: 16 dwords per queued block, rows padded to 32 entries (LDS banks); pairs above the cap
+         * take the kernel's serial fallback */
+        Launch L{ (uint32_t)tiles.size(), 0, std::max(32u, (mi + 31u) & ~31u), std::min(1024u, (mp + 63u) & ~63u) };
         if (nb < 8) {
             /* too few pictures to give every XCD its own: plain order, no padding */
             for (int x = 0; x < nb; ++x) tiles.insert(tiles.end(), bins[x].begin(), bins[x].end());
@@ -344,7 +352,7 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
     HIPCHK(hipMemcpyAsync(c->tiles_dev, tiles.data(), tiles.size() * sizeof(HvqTileRef), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     /* 3. one launch per level */
-    for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, c->stream));
+    for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.items_cap, L.pair_cap, c->stream));
     c->stats = st;
     /* the batch is in flight: levels restart from zero for whatever is queued next */
     for (auto &s : c->streams)
@@ -370,7 +378,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     for (int r = 0; r < reps; ++r)
-        for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, c->stream));
+        for (auto &L : c->launches) HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.items_cap, L.pair_cap, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0;
