@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--nslots", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--parse-threads", type=int, default=0, help="host parse threads for the end-to-end pass (0 = all cores, max 64)")
     ap.add_argument("--mv-bits", default="0,1,2", help="vector residual-bit choices of the synthetic P/B pictures (reach = 16 << bits samples)")
     args = ap.parse_args()
 
@@ -67,19 +68,27 @@ def main():
     pics = [list(video_pictures(c.data)) for c in clips]
     n_pic = len(args.gop)
 
-    ctx = batch.Context(local_rank)
+    # one rank per GPU; HVQM4_BENCH_SHARE_GPU=1 lets several ranks share device 0 (rehearsal on a 1-GPU box only)
+    ctx = batch.Context(0 if os.environ.get("HVQM4_BENCH_SHARE_GPU") else local_rank)
     sids = []
     for s in range(args.streams):
         sids.append(ctx.open_stream(args.width, args.height, 2, 2, True, args.nslots))
-    # decode-order interleave: picture k of every stream, then k+1 ... (the order a player would submit)
-    t0 = time.time()
+    # decode-order interleave: picture k of every stream, then k+1 ... (the order a player would submit).
+    # This first pass is also the END-TO-END measurement: host entropy parse (thread pool) + descriptor upload
+    # + all launches, from bitstreams in host memory to pictures in HBM.
+    threads = max(1, min(args.parse_threads or (os.cpu_count() or 1), 64))
+    a_sid, a_ft, a_pic = [], [], []
     for k in range(n_pic):
         for s, sid in enumerate(sids):
             ft, _d, pic = pics[s % args.distinct][k]
-            ctx.submit(sid, ft, pic)
-    submit_s = time.time() - t0
+            a_sid.append(sid); a_ft.append(ft); a_pic.append(pic)
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.submit_many(a_sid, a_ft, a_pic, threads)
+    t_parse = time.perf_counter() - t0
     ctx.flush()
     ctx.sync()
+    t_e2e = time.perf_counter() - t0
     st = ctx.stats()
 
     # ---- parity spot-check against the CPU oracle on what is still resident ----
@@ -144,7 +153,9 @@ def main():
             "descriptor_bytes_per_launch": int(st.descriptor_bytes // launches),
         },
         "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
-        "host_parse_mpix_s": round(px_step / st.parse_seconds / 1e6, 1) if st.parse_seconds else None,
+        "end_to_end": {"value": round(px_step / t_e2e / 1e6, 1), "unit": "Mpixels/s", "parse_threads": threads,
+                       "parse_only_mpix_s": round(px_step / t_parse / 1e6, 1),
+                       "what": "first pass: host entropy parse + descriptor H2D + kernels, bitstreams in host memory -> pictures in HBM"},
         "verified_pictures": verified,
         "flags_or": int(st.flags_or),
     }

@@ -66,6 +66,8 @@ SYMBOLS = {
     "hvq_stream_open": (C.c_int, [C.c_void_p] + [C.c_int] * 6),
     "hvq_stream_close": (C.c_int, [C.c_void_p, C.c_int]),
     "hvq_stream_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "hvq_submit_many": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p),
+                                  C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)]),
     "hvq_flush": (C.c_int, [C.c_void_p]),
     "hvq_sync": (C.c_int, [C.c_void_p]),
     "hvq_replay": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),

@@ -24,6 +24,17 @@ class Context:
     def submit(self, sid: int, frame_type: int, picture: bytes) -> int:
         return check(lib().hvq_stream_submit(self._h, sid, frame_type, picture, len(picture)))
 
+    def submit_many(self, sids, frame_types, pictures, threads: int = 1):
+        """parse `pictures` on a host thread pool (per-stream order kept) and queue them in list order"""
+        n = len(pictures)
+        a_s = (C.c_int * n)(*sids)
+        a_t = (C.c_int * n)(*frame_types)
+        a_p = (C.c_char_p * n)(*pictures)
+        a_l = (C.c_size_t * n)(*[len(p) for p in pictures])
+        a_o = (C.c_int * n)()
+        check(lib().hvq_submit_many(self._h, n, a_s, a_t, a_p, a_l, threads, a_o))
+        return list(a_o)
+
     def flush(self) -> None:
         check(lib().hvq_flush(self._h))
 

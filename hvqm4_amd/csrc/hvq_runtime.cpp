@@ -23,6 +23,8 @@
 #include <cstring>
 #include <mutex>
 #include <set>
+#include <thread>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -220,25 +222,11 @@ static int alloc_slot(Stream &s)
     return -1;
 }
 
-HVQ_EXPORT int hvq_stream_submit(HvqContext *c, int sid, int frame_type, const uint8_t *pic, size_t len)
+/* queue one parsed picture (blob already in the host arena at `off`): slot assignment == picture rotation of
+ * h4m:2087-2093 / 2131-2137, then the dependency level */
+static int enqueue_picture(HvqContext *c, int sid, int frame_type, size_t off, size_t blen)
 {
-    if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
-    if (!pic || len < 8 + 0x44 + 4) return fail(HVQ_E_ARG, "picture too short (%zu bytes)", len);
-    if (frame_type != HVQ_FRAME_I && frame_type != HVQ_FRAME_P && frame_type != HVQ_FRAME_B)
-        return fail(HVQ_E_ARG, "unknown frame type 0x%x", frame_type);
-    HIPCHK(hipSetDevice(c->device));
-    Stream &s = c->streams[sid];
-    size_t bound = align_up(hvq_parser_blob_bound(s.parser), 256);
-    int rc = arena_reserve(c, bound);
-    if (rc) return rc;
-    size_t off = c->arena_used, blen = 0;
-    auto t0 = std::chrono::steady_clock::now();
-    rc = hvq_parse_picture(s.parser, frame_type, pic, len, c->host_arena + off, bound, &blen);
-    c->parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (rc) return fail(rc, "parse failed (%d) for stream %d picture %d", rc, sid, s.npics);
-    c->arena_used = off + align_up(blen, 256);
-
-    /* slot assignment == picture rotation of h4m:2087-2093 / 2131-2137 */
+    Stream &s = c->streams[(size_t)sid];
     Pending q{};
     q.stream = sid; q.ordinal = s.npics; q.blob_off = off; q.blob_len = blen;
     const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + off);
@@ -262,6 +250,94 @@ HVQ_EXPORT int hvq_stream_submit(HvqContext *c, int sid, int frame_type, const u
     if (frame_type != HVQ_FRAME_B) s.anchor_new = q.dst;     /* present <-> future: newest anchor becomes "future" */
     c->pending.push_back(q);
     return s.npics++;
+}
+
+static int check_submit_args(HvqContext *c, int sid, int frame_type, const uint8_t *pic, size_t len)
+{
+    if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
+    if (!pic || len < 8 + 0x44 + 4) return fail(HVQ_E_ARG, "picture too short (%zu bytes)", len);
+    if (frame_type != HVQ_FRAME_I && frame_type != HVQ_FRAME_P && frame_type != HVQ_FRAME_B)
+        return fail(HVQ_E_ARG, "unknown frame type 0x%x", frame_type);
+    return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_stream_submit(HvqContext *c, int sid, int frame_type, const uint8_t *pic, size_t len)
+{
+    int rc = check_submit_args(c, sid, frame_type, pic, len);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    Stream &s = c->streams[sid];
+    size_t bound = align_up(hvq_parser_blob_bound(s.parser), 256);
+    rc = arena_reserve(c, bound);
+    if (rc) return rc;
+    size_t off = c->arena_used, blen = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = hvq_parse_picture(s.parser, frame_type, pic, len, c->host_arena + off, bound, &blen);
+    c->parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc) return fail(rc, "parse failed (%d) for stream %d picture %d", rc, sid, s.npics);
+    c->arena_used = off + align_up(blen, 256);
+    return enqueue_picture(c, sid, frame_type, off, blen);
+}
+
+HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const int *frame_types,
+                               const uint8_t *const *pics, const size_t *lens, int threads, int *ordinals)
+{
+    if (!c || n < 0 || !streams || !frame_types || !pics || !lens) return fail(HVQ_E_ARG, "bad arguments");
+    for (int i = 0; i < n; ++i) {
+        int rc = check_submit_args(c, streams[i], frame_types[i], pics[i], lens[i]);
+        if (rc) return rc;
+    }
+    if (n == 0) return HVQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    threads = std::max(1, std::min(threads, 256));
+    /* work units = streams (a parser is stateful); unit u gets its pictures in array order */
+    std::vector<std::vector<int>> per_stream(c->streams.size());
+    std::vector<int> units;
+    for (int i = 0; i < n; ++i) {
+        if (per_stream[(size_t)streams[i]].empty()) units.push_back(streams[i]);
+        per_stream[(size_t)streams[i]].push_back(i);
+    }
+    std::vector<std::vector<uint8_t>> blobs((size_t)n);
+    std::vector<int> rcs((size_t)n, 0);
+    std::atomic<size_t> next{ 0 };
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&]() {
+        std::vector<uint8_t> scratch;
+        for (;;) {
+            size_t u = next.fetch_add(1);
+            if (u >= units.size()) break;
+            Stream &s = c->streams[(size_t)units[u]];
+            size_t bound = hvq_parser_blob_bound(s.parser);
+            if (scratch.size() < bound + 16) scratch.resize(bound + 16);
+            uint8_t *buf = (uint8_t *)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15);
+            for (int i : per_stream[(size_t)units[u]]) {
+                size_t blen = 0;
+                rcs[(size_t)i] = hvq_parse_picture(s.parser, frame_types[i], pics[i], lens[i], buf, bound, &blen);
+                if (rcs[(size_t)i]) break;              /* later pictures of the stream would decode against a wrong state */
+                blobs[(size_t)i].assign(buf, buf + blen);
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    c->parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int i = 0; i < n; ++i)
+        if (rcs[(size_t)i] || blobs[(size_t)i].empty())
+            return fail(rcs[(size_t)i] ? rcs[(size_t)i] : HVQ_E_STATE, "parse failed for picture %d (stream %d)", i, streams[i]);
+    size_t need = 0;
+    for (auto &b : blobs) need += align_up(b.size(), 256);
+    int rc = arena_reserve(c, need);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        size_t off = c->arena_used;
+        memcpy(c->host_arena + off, blobs[(size_t)i].data(), blobs[(size_t)i].size());
+        c->arena_used = off + align_up(blobs[(size_t)i].size(), 256);
+        int ord = enqueue_picture(c, streams[i], frame_types[i], off, blobs[(size_t)i].size());
+        if (ordinals) ordinals[i] = ord;
+    }
+    return HVQ_OK;
 }
 
 HVQ_EXPORT int hvq_flush(HvqContext *c)

@@ -45,7 +45,7 @@ class Group:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = backend or os.environ.get("HVQM4_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)

@@ -59,6 +59,13 @@ int  hvq_stream_close(HvqContext *ctx, int stream);
  * `len` its length.  Returns the picture's ordinal in the stream (decode order). */
 int  hvq_stream_submit(HvqContext *ctx, int stream, int frame_type, const uint8_t *pic, size_t len);
 
+/* Same as hvq_stream_submit for `n` pictures, with the host entropy parse spread over `threads` worker
+ * threads (pictures of one stream are parsed in order by one worker -- the parser carries the nest of the
+ * last I picture; different streams run concurrently).  Pictures are queued in array order.  ordinals[i]
+ * (may be NULL) receives picture i's ordinal.  Returns HVQ_OK or the first error. */
+int  hvq_submit_many(HvqContext *ctx, int n, const int *streams, const int *frame_types,
+                     const uint8_t *const *pics, const size_t *lens, int threads, int *ordinals);
+
 /* Upload queued descriptors, group queued pictures into dependency levels, launch. Async. */
 int  hvq_flush(HvqContext *ctx);
 int  hvq_sync(HvqContext *ctx);

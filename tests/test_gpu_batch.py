@@ -111,3 +111,29 @@ def test_malformed_pictures_do_not_fault_the_gpu(gpu_ctx):
     want = bridge.oracle_decode(cl.data, cl.n_pictures)
     assert np.array_equal(decode_clip(gpu_ctx, cl.data), want)
     gpu_ctx.close_stream(sid)
+
+
+def test_threaded_submit_equals_sequential(gpu_ctx):
+    """hvq_submit_many: parse on a thread pool, queue in array order -> same pictures as one-by-one submission"""
+    from oracle import bridge
+    cases = [clips.SMALL[3], clips.SMALL[4], clips.SMALL[11], clips.SMALL[12], clips.SMALL[5]]
+    streams = []
+    for c in cases:
+        cl = clips.get(c)
+        sid, pics = _submit_all(gpu_ctx, cl)
+        streams.append((cl, sid, pics))
+    a_sid, a_ft, a_pic = [], [], []
+    k = 0
+    while any(k < len(p) for _c, _s, p in streams):
+        for cl, sid, pics in streams:
+            if k < len(pics):
+                a_sid.append(sid); a_ft.append(pics[k][0]); a_pic.append(pics[k][2])
+        k += 1
+    ords = gpu_ctx.submit_many(a_sid, a_ft, a_pic, threads=4)
+    assert len(ords) == len(a_pic)
+    gpu_ctx.flush()
+    for cl, sid, pics in streams:
+        want = bridge.oracle_decode(cl.data, cl.n_pictures)
+        for i in range(len(pics)):
+            assert np.array_equal(gpu_ctx.read_picture(sid, i), want[i]), (cl.width, i)
+        gpu_ctx.close_stream(sid)
