@@ -147,7 +147,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
             "kernel": "hvq_recon_kernel", "algorithmic_bytes_per_launch": int(st.algorithmic_bytes // launches),
             "avg_launch_us": round(avg_launch_s * 1e6, 2),
             "descriptor_bytes_per_launch": int(st.descriptor_bytes // launches),
@@ -166,6 +166,21 @@ def main():
         print(json.dumps(out), flush=True)
     ctx.close()
     grp.close()
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes of this same
+    default workload (tools/pmc_passes.sh -> tools/pmc_traffic.py -> profiles/*_pmc_traffic.json); None for
+    any other workload."""
+    default = (args.streams, args.width, args.height, args.gop, args.preset, args.distinct, args.mv_bits) == \
+              (128, 640, 480, "IPBBPBBPBBPBBPBB", "dense", 8, "0,1,2")
+    if not default:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    return int(json.load(open(files[-1]))["hbm_bytes_per_launch"])
 
 
 def cpu_baseline(clip, budget_s: float):

@@ -3,7 +3,9 @@
 // mode 0: every lane its own random address; mode 1: lane pairs (2k,2k+1) read addresses 4 bytes apart;
 // mode 2: 16 consecutive lanes read consecutive 8-byte words (coalesced 128 B); mode 3: as 0 but 4-byte loads;
 // mode 4: as 0 but 16-byte loads; mode 5: every lane its own random 128-byte line, 8 loads inside that line
-// (1 miss + 7 L1 hits); mode 6: as 5 but 4 loads per line (two lines per 8 loads).
+// (1 miss + 7 L1 hits); mode 6: as 5 but 4 loads per line (two lines per 8 loads);
+// mode 7: groups of 5 adjacent lanes share a random 128-byte line (8B at 16*j); mode 8: groups of 4; mode 9: groups of 8;
+// mode 10: lanes i and i+32 share a line (non-adjacent).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -16,7 +18,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k(const uint8_t* buf, uint32_t mask, uint32_t* out, int iters)
 {
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    uint32_t key = MODE == 1 ? (t >> 1) : MODE == 2 ? (t >> 4) : t;
+    uint32_t key = MODE == 1 ? (t >> 1) : MODE == 2 ? (t >> 4) : MODE == 7 ? (t / 5) : MODE == 8 ? (t >> 2) : MODE == 9 ? (t >> 3) : MODE == 10 ? (t & ~32u) : t;
     uint32_t x = key * 2654435761u + 12345u;
     uint64_t acc = 0;
     for (int i = 0; i < iters; ++i) {
@@ -28,6 +30,10 @@ __global__ __launch_bounds__(256) void k(const uint8_t* buf, uint32_t mask, uint
             if (MODE == 5 || MODE == 6) { if (j % (MODE == 5 ? 8 : 4) == 0) line = off & ~127u; off = line + ((j * 24 + (t & 7)) & 119); }
             if (MODE == 1) off += (t & 1) * 4;
             if (MODE == 2) off = (off & ~127u) + (t & 15) * 8;
+            if (MODE == 7) off = (off & ~127u) + (t % 5) * 16 + 3;
+            if (MODE == 8) off = (off & ~127u) + (t & 3) * 16 + 3;
+            if (MODE == 9) off = (off & ~127u) + (t & 7) * 16 + 3;
+            if (MODE == 10) off = (off & ~127u) + ((t >> 5) & 1) * 16 + 3;
             if (MODE == 3) acc += *(const u32u*)(buf + off);
             else if (MODE == 4) { q16 v = *(const q16*)(buf + (off & ~3u)); acc += v.a + v.b + v.c + v.d; }
             else acc += *(const u64u*)(buf + off);
@@ -66,6 +72,10 @@ int main()
         run<4>(buf, mask, out, "random 16B per lane");
         run<5>(buf, mask, out, "8 x 8B inside one private line");
         run<6>(buf, mask, out, "4 x 8B inside one private line");
+        run<7>(buf, mask, out, "5 adjacent lanes share a line");
+        run<8>(buf, mask, out, "4 adjacent lanes share a line");
+        run<9>(buf, mask, out, "8 adjacent lanes share a line");
+        run<10>(buf, mask, out, "lanes i, i+32 share a line");
         hipFree(buf); hipFree(out);
     }
     return 0;
