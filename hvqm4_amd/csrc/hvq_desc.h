@@ -130,8 +130,7 @@ typedef struct HvqJob {
     uint32_t mv_off, wave_base_off, pool_off, nest_off;
     uint32_t tile_first[4];
     uint32_t mcb_w;
-    uint32_t tiled_off;            /* byte offset from a slot's linear picture to its tiled copy (0: slots have none) */
-    uint32_t job_flags;            /* HVQ_JF_* */
+    uint32_t pad[2];
 } HvqJob;
 
 #if defined(__cplusplus)
@@ -139,21 +138,6 @@ static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
 #else
 _Static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
 #endif
-
-/* job flags (runtime -> kernel) */
-#define HVQ_JF_WRITE_TILED  0x1u   /* dst is an anchor (I/P): also write the tiled copy */
-#define HVQ_JF_REF0_TILED   0x2u   /* ref0 / ref1 carry a valid tiled copy */
-#define HVQ_JF_REF1_TILED   0x4u
-
-/* Tiled anchor copy: every plane as 16x8-sample tiles of 128 bytes (one cache line), tiles in raster order,
- * rows of a tile 16 bytes apart.  A 4x4 block's source rows then lie in one or two lines instead of five, and
- * lanes of one quad that fetch the rows of one block are merged into one access by the texture addresser
- * (profiles/r01_ubench_gather_rate.txt).  Needs plane widths % 16 == 0 and heights % 8 == 0. */
-#define HVQ_TILED_OK(w, h, ws, hs) ((((w) >> (ws)) % 16 == 0) && (((h) >> (hs)) % 8 == 0) && ((w) % 16 == 0))
-HVQ_HD static inline uint32_t hvq_tiled_addr(uint32_t x, uint32_t y, uint32_t pw)
-{
-    return ((y >> 3) * (pw >> 4) + (x >> 4)) * 128u + (y & 7u) * 16u + (x & 15u);
-}
 
 /* one workgroup = one tile */
 typedef struct HvqTileRef {

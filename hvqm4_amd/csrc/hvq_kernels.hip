@@ -300,40 +300,6 @@ __device__ __forceinline__ Blk predi_finish(const u32 r[16], Blk m, u32 p0, u32 
     return o4;
 }
 
-/* One 8-byte source row segment starting at plane sample (x, y).
- *   tiled : from the 16x8-tiled anchor copy (x, y inside the plane, `need` bytes must not leave the row);
- *           the segment may continue in the next tile of the tile row (second load only then)
- *   linear: from the row-major picture with the reference's linear address (h4m:1344), clamped to the slot */
-__device__ __forceinline__ uint64_t fetch_row(const uint8_t *lin, const uint8_t *til, bool tiled, i32 x, i32 y,
-                                              i32 pw, i32 plane_off, int need, i32 slot)
-{
-    if (!tiled) return *(const u64u *)(lin + clampi(plane_off + y * pw + x, 0, slot - 8));
-    const u32 xo = (u32)x & 15u;
-    const uint8_t *t = til + plane_off + ((u32)(y >> 3) * (u32)(pw >> 4) + ((u32)x >> 4)) * 128u + ((u32)y & 7u) * 16u;
-    const u32 back = xo > 8u ? xo - 8u : 0u;                         /* keep the 8-byte read inside the 16-byte tile row */
-    uint64_t q = *(const u64u *)(t + xo - back) >> (8u * back);
-    if (xo + (u32)need > 16u) q |= *(const u64u *)(t + 128) << (8u * (16u - xo));
-    return q;
-}
-
-/* one output row (4 samples) of a motion-compensated block from source rows q (this row) and qn (next row) */
-__device__ __forceinline__ u32 mc_filter_row(uint64_t q, uint64_t qn, int hx, int hy)
-{
-    const u32 p = (u32)q, n = (u32)(q >> 8);
-    if (!hy) return hx ? __builtin_amdgcn_lerp(p, n, 0x01010101u) : p;
-    const u32 p2 = (u32)qn, n2 = (u32)(qn >> 8);
-    if (!hx) return __builtin_amdgcn_lerp(p, p2, 0x01010101u);
-    const u32 M = 0x00FF00FFu;
-    const u32 e = (((p & M) + (n & M) + (p2 & M) + (n2 & M) + 0x00020002u) >> 2) & M;
-    const u32 d = ((((p >> 8) & M) + ((n >> 8) & M) + ((p2 >> 8) & M) + ((n2 >> 8) & M) + 0x00020002u) >> 2) & M;
-    return e | (d << 8);
-}
-
-/* value of `v` in the next lane of the quad (lane 3 keeps its own) */
-__device__ __forceinline__ u32 quad_next(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xF9 /* quad_perm:[1,2,3,3] */, 0xF, 0xF, false); }
-__device__ __forceinline__ u32 quad_xor1(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false); }
-__device__ __forceinline__ u32 quad_xor2(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false); }
-
 /* wave64 inclusive prefix sum on the DPP network: Kogge-Stone inside each row of 16 lanes
  * (row_shr 1,2,4,8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3. */
 __device__ __forceinline__ u32 wave_incl_scan(u32 v)
@@ -392,8 +358,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     __shared__ u32 s_item0[HVQ_WG];    /* owner lane | payload offset << 10 */
     __shared__ u32 s_item1[HVQ_WG];    /* map entry {value, type} */
     __shared__ u32 s_item2[HVQ_WG];    /* macroblock vector */
-    __shared__ u32 s_src0[HVQ_WG];     /* MC source of the lane's block: sx | sy << 16 (plane samples) */
-    __shared__ u32 s_src1[HVQ_WG];     /* bit0 needs MC, bit1 reference, bit2 hx, bit3 hy, bit4 tiled fetch */
     __shared__ u32 s_cnt[HVQ_NW][3];
 
     const int tid = threadIdx.x;
@@ -433,9 +397,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     uint8_t *plane = (uint8_t *)J->dst + plane_off;
     const i32 slot = (i32)J->slot_bytes;
     const i32 mcb_w = (i32)J->mcb_w;
-    const u32 jf = J->job_flags;
-    const u32 tiled_off = J->tiled_off;
-    const i32 ph = J->height >> hs;
     const i32 lw = J->width;
 #undef PSEL
 
@@ -470,29 +431,20 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
     if (lane == 63) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = pincl; }
 
-    /* motion-compensated blocks (plain MC and the MC part of MC-residual blocks) only record their source
-     * here; the rows are fetched after the barrier with lane = (block, row) so that the four row reads of a
-     * block share a quad -- and, in the tiled anchor copy, a cache line */
-    const bool needs_mc = valid && inter && (cls == 2 || (T & 0x10u) || kind == 0);
-    {
-        u32 src0 = 0, src1 = 0;
-        if (needs_mc) {
-            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-            const u32 k = (((T >> 5) & 3u) == 1u) ? 0u : 1u;
-            const i32 pdx = rx >> ws, pdy = ry >> hs;
-            const u32 hx = (u32)(is15 ? (pdx & 1) : (rx & 1)), hy = (u32)(is15 ? (pdy & 1) : (ry & 1));   /* h4m:1337-1343 */
-            const i32 sx = (pdx >> 1) + (bx & (1 - ws)) * 4, sy = (pdy >> 1) + (by & (1 - hs)) * 4;
-            const bool til = (jf & (HVQ_JF_REF0_TILED << k)) && sx >= 0 && sx + 5 <= pw && sy >= 0 && sy + 5 <= ph;
-            src0 = ((u32)sx & 0xFFFFu) | ((u32)sy << 16);
-            src1 = 1u | (k << 1) | (hx << 2) | (hy << 3) | ((u32)til << 4);
-        }
-        s_src0[tid] = src0;
-        s_src1[tid] = src1;
-    }
-    if (HVQ_ABL != 4 && HVQ_ABL != 5 && valid && cls == 0 && !needs_mc) {
+    if (HVQ_ABL != 4 && HVQ_ABL != 5 && valid && cls != 1) {
         Blk o;
         const u32 *__restrict__ pay = pool + off;
-        if (!inter && kind == 0) {
+        const bool needs_mc = inter && (cls == 2 || (T & 0x10u) || kind == 0);
+        if (needs_mc) {
+            /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
+            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+            const uint8_t *ref = (const uint8_t *)((((T >> 5) & 3u) == 1u) ? J->ref0 : J->ref1);
+            const i32 pdx = rx >> ws, pdy = ry >> hs;
+            const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
+            const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+            if (HVQ_ABL == 2) { o.r[0] = o.r[1] = o.r[2] = o.r[3] = (u32)(a + hx + hy); }
+            else o = mc_block(ref, a, pw, hx, hy, slot - 8);
+        } else if (!inter && kind == 0) {
             /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
              * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
             i32 Tt = (nt & 0x7700u) ? V : (i32)(nt & 0xFF);
@@ -512,27 +464,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     }
 
     __syncthreads();                                                           /* barrier 1: queue counts */
-    /* ---- phase A2: motion compensation, lane = (block, row) ---- */
-    if (is_pb && HVQ_ABL != 2 && HVQ_ABL != 4) {
-#pragma unroll 1
-        for (int f = 0; f < 4; ++f) {
-            const int j = f * 64 + (tid >> 2), row = tid & 3;
-            const u32 f1 = s_src1[j];
-            if (f1 & 1u) {                                     /* uniform over the quad */
-                const u32 f0 = s_src0[j];
-                const i32 sx = (i32)(int16_t)(f0 & 0xFFFF), sy = (i32)(int16_t)(f0 >> 16);
-                const int hx = (f1 >> 2) & 1, hy = (f1 >> 3) & 1;
-                const bool til = (f1 >> 4) & 1u;
-                const uint8_t *lin = (const uint8_t *)((f1 & 2u) ? J->ref1 : J->ref0);
-                const uint8_t *tl = lin + tiled_off;
-                const uint64_t q = fetch_row(lin, tl, til, sx, sy + row, pw, plane_off, 4 + hx, slot);
-                uint64_t qn = (uint64_t)quad_next((u32)q) | ((uint64_t)quad_next((u32)(q >> 32)) << 32);
-                if (row == 3 && hy) qn = fetch_row(lin, tl, til, sx, sy + 4, pw, plane_off, 4 + hx, slot);
-                s_out[row][j] = mc_filter_row(q, qn, hx, hy);
-            }
-        }
-    }
-
     u32 nI = 0, nP = 0, myI = 0, myP = 0, npairs = 0, pbefore = 0;
 #pragma unroll
     for (int w = 0; w < HVQ_NW; ++w) {
@@ -581,51 +512,22 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 
         u32 r[16];
         if (parallel) {
-            /* ---- phase B1: one lane per (item, basis, row): the four rows of a basis share a quad ---- */
-            for (u32 wi = (u32)tid; wi < 4u * npairs; wi += HVQ_WG) {
-                const u32 pr = s_pair[wi >> 2];
-                const int row = (int)(wi & 3u);
+            /* ---- phase B1: one lane per (item, basis) pair ---- */
+            for (u32 pi = (u32)tid; pi < npairs; pi += HVQ_WG) {
+                const u32 pr = s_pair[pi];
                 const u32 it = pr & 511u;
                 const u32 d = pool[pr >> 9];
-                const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
-                const u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
-                const u32 x2 = landscape ? sl : ss, y2 = landscape ? ss : sl;     /* sample / row step - 1 */
-                u32 e[4];
+                u32 e[16], lo, hi;
                 if (it < nI) {
-                    /* intra: nibble-packed LDS nest, linear index = the reference's byte index (h4m:702-711) */
-                    const i32 stride = landscape ? 70 : 38;
-                    const i32 n = (landscape ? stride * os + ol : stride * ol + os) + row * (stride << y2);
-                    const uint64_t q = *(const u64u *)(s_nest + (n >> 1)) >> (4 * (n & 1));
-                    const u32 sh = x2 ? 8u : 4u;
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) e[x] = ((u32)q >> (sh * x)) & 15u;
+                    gather_nest(d, landscape, s_nest, e, lo, hi);
                 } else {
-                    /* MC residual: window of the reference luma plane at the vector target (h4m:1865-1868); row of
-                     * the basis = plane sample (wx, wy) -- fetched tiled when it lies inside the plane */
                     const u32 t16 = s_item1[it], mv = s_item2[it];
                     const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
-                    const u32 k = ((t16 >> 13) & 3u) == 1u ? 0u : 1u;
-                    const uint8_t *lin = (const uint8_t *)(k ? J->ref1 : J->ref0);
-                    const i32 wx = landscape ? rx / 2 - 32 + ol : rx / 2 - 16 + os;
-                    const i32 wy = (landscape ? ry / 2 - 16 + os : ry / 2 - 32 + ol) + (row << y2);
-                    const int need = x2 ? 7 : 4;
-                    const bool til = (jf & (HVQ_JF_REF0_TILED << k)) && wx >= 0 && wx + need <= lw && wy >= 0 && wy < (i32)J->height;
-                    const uint64_t q = fetch_row(lin, lin + tiled_off, til, wx, wy, lw, 0, need, slot);
-                    u32 w = __builtin_amdgcn_perm((u32)(q >> 32), (u32)q, x2 ? 0x06040200u : 0x03020100u);
-                    w = (w >> 4) & 0x0F0F0F0Fu;                              /* upper nibble of each sample, h4m:756-761 */
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) e[x] = (w >> (8 * x)) & 0xFFu;
+                    const uint8_t *ref = (const uint8_t *)(((t16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
+                    const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
+                    gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
                 }
-                u32 lo = min(min(e[0], e[1]), min(e[2], e[3])), hi = max(max(e[0], e[1]), max(e[2], e[3]));
-                lo = min(lo, quad_xor1(lo)); hi = max(hi, quad_xor1(hi));
-                lo = min(lo, quad_xor2(lo)); hi = max(hi, quad_xor2(hi));
-                const i32 g = basis_gain(d, lo, hi, big);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const i32 t = big ? (i32)((u32)g * e[x]) : __mul24(g, (i32)e[x]);
-                    __hip_atomic_fetch_add(s_acc + (u32)(4 * row + x) * items_cap + it, t, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                basis_scatter(basis_gain(d, lo, hi, big), e, big, s_acc + it, items_cap);
             }
             __syncthreads();                                                   /* barrier 3: accumulators complete */
             if (has_item) {
@@ -678,8 +580,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         __syncthreads();                                                       /* barrier 4: tile complete in LDS */
     }
 
-    else if (is_pb) __syncthreads();               /* phase A2 wrote other lanes' blocks: make them visible */
-
     /* ---- phase C: tile -> HBM ---- */
     if (HVQ_ABL == 3 || HVQ_ABL == 4) return;
     if ((hb & 3) == 0) {
@@ -691,8 +591,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             block_coords(gb, hb, rhb, gx, gy);
             const uint4 v = *(const uint4 *)&s_out[rr][4 * g];
             *(uint4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
-            if (jf & HVQ_JF_WRITE_TILED)       /* anchors: 16x8-tiled copy for later motion compensation */
-                *(uint4 *)((uint8_t *)J->dst + tiled_off + plane_off + hvq_tiled_addr((u32)gx * 4u, (u32)(gy * 4 + rr), (u32)pw)) = v;
         }
     } else if (valid) {
         uint8_t *dst = plane + (size_t)(by * 4) * pw + bx * 4;

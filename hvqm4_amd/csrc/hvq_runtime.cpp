@@ -64,7 +64,6 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 /* ------------------------------------------------------------------ context */
 struct Slot {
-    bool tiled = false; /* the slot's tiled copy matches its linear picture */
     int w_level = -1;   /* level (in the pending batch) of the launch that writes the current content */
     int r_level = -1;   /* highest level that reads it */
     int pic = -1;       /* ordinal of the occupant */
@@ -74,9 +73,7 @@ struct Stream {
     bool open = false;
     HvqParser *parser = nullptr;
     int w = 0, h = 0;
-    uint32_t pic_bytes = 0, slot_bytes = 0;   /* slot = linear picture (+pad) followed by the tiled anchor copy */
-    uint32_t lin_bytes = 0;                   /* readable bytes of the linear part (pic_bytes + pad) */
-    bool tiled_ok = false;
+    uint32_t pic_bytes = 0, slot_bytes = 0;
     uint8_t *dev = nullptr;                  /* (nslots + 1) slots; the last one stays zero */
     std::vector<Slot> slots;
     int anchor_old = -1, anchor_new = -1;    /* "past" / "future" of the reference player */
@@ -87,7 +84,7 @@ struct Stream {
 };
 
 struct Pending {
-    uint32_t max_items, max_pairs, job_flags;
+    uint32_t max_items, max_pairs;
     int stream, ordinal, level;
     size_t blob_off, blob_len;
     int dst, ref0, ref1;
@@ -185,9 +182,7 @@ HVQ_EXPORT int hvq_stream_open(HvqContext *c, int width, int height, int h_samp,
     Stream s;
     s.open = true; s.parser = p; s.w = width; s.h = height;
     s.pic_bytes = hvq_parser_pic_bytes(p);
-    s.lin_bytes = (uint32_t)align_up((size_t)s.pic_bytes + 64, 256);
-    s.tiled_ok = HVQ_TILED_OK(width, height, h_samp == 2, v_samp == 2) && !getenv("HVQM4_AMD_NO_TILED");
-    s.slot_bytes = s.lin_bytes * (s.tiled_ok ? 2u : 1u);
+    s.slot_bytes = (uint32_t)align_up((size_t)s.pic_bytes + 64, 256);
     s.slots.resize((size_t)nslots);
     size_t bytes = (size_t)(nslots + 1) * s.slot_bytes;
     hipError_t e = hipMalloc((void **)&s.dev, bytes);
@@ -249,15 +244,6 @@ static int enqueue_picture(HvqContext *c, int sid, int frame_type, size_t off, s
     q.level = lvl;
     if (q.ref0 >= 0) s.slots[q.ref0].r_level = std::max(s.slots[q.ref0].r_level, lvl);
     if (q.ref1 >= 0 && q.ref1 != q.dst) s.slots[q.ref1].r_level = std::max(s.slots[q.ref1].r_level, lvl);
-    /* tiled copies: anchors written by the kernel carry one; the always-zero slot (missing reference) trivially does */
-    auto is_tiled = [&](int slot) { return s.tiled_ok && (slot < 0 || (slot != q.dst && s.slots[slot].tiled)); };
-    q.job_flags = 0;
-    if (frame_type != HVQ_FRAME_I) {
-        if (is_tiled(q.ref0)) q.job_flags |= HVQ_JF_REF0_TILED;
-        if (frame_type == HVQ_FRAME_B && is_tiled(q.ref1)) q.job_flags |= HVQ_JF_REF1_TILED;
-    }
-    if (s.tiled_ok && frame_type != HVQ_FRAME_B) q.job_flags |= HVQ_JF_WRITE_TILED;
-    s.slots[q.dst].tiled = (q.job_flags & HVQ_JF_WRITE_TILED) != 0;
     if (s.slots[q.dst].pic >= 0) s.pic_slot[(size_t)s.slots[q.dst].pic] = -1;
     s.slots[q.dst].w_level = lvl; s.slots[q.dst].r_level = -1; s.slots[q.dst].pic = q.ordinal;
     s.pic_slot.push_back(q.dst);
@@ -377,9 +363,7 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         j.dst = (uint64_t)(uintptr_t)s.slot_ptr(p.dst);
         j.ref0 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref0);
         j.ref1 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref1);
-        j.slot_bytes = s.lin_bytes;
-        j.tiled_off = s.tiled_ok ? s.lin_bytes : 0;
-        j.job_flags = p.job_flags;
+        j.slot_bytes = s.slot_bytes;
         const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + p.blob_off);
         j.flags = hd->flags; j.width = hd->width; j.height = hd->height;
         j.pic_kind = hd->pic_kind; j.unk_shift = hd->unk_shift; j.wshift = hd->wshift; j.hshift = hd->hshift;
@@ -585,7 +569,6 @@ void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, con
         return true;
     };
     s.anchor_old = -1; s.anchor_new = -1; s.ring = 2;
-    for (auto &sl : s.slots) sl.tiled = false;          /* uploaded pictures have no tiled copy */
     if (ftype == HVQ_FRAME_P) {
         if (!put(0, past)) return;
         s.anchor_old = -1; s.anchor_new = 0;            /* swapped to "past" by the submit's rotation */
