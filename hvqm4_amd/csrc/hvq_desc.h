@@ -35,7 +35,9 @@
 #include <stdint.h>
 
 #define HVQ_MAGIC        0x34515648u   /* "HVQ4" */
-#define HVQ_TILE_BLOCKS  256
+#ifndef HVQ_TILE_BLOCKS
+#define HVQ_TILE_BLOCKS  256           /* blocks per tile = threads per workgroup */
+#endif
 #define HVQ_NEST_BYTES   (70 * 38)
 
 #define HVQ_PIC_I 0

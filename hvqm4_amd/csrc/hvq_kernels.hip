@@ -34,7 +34,10 @@ typedef uint64_t __attribute__((aligned(1))) u64u;
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-#define HVQ_WG 256
+#define HVQ_WG HVQ_TILE_BLOCKS
+#ifndef HVQ_MIN_WAVES
+#define HVQ_MIN_WAVES 8               /* waves per SIMD the register allocation must allow (64 VGPRs) */
+#endif
 
 /* ablation builds only (tools/ablate.sh): 1 = no phase B, 2 = no MC loads, 3 = no stores, 4 = descriptors only,
  * 5 = no cheap-kind compute */
@@ -346,7 +349,7 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
  *   phase C   the finished tile leaves LDS as 16-byte row segments: one store instruction of a wave
  *             writes four complete 256-byte runs of the destination plane (full lines, written once).
  */
-__global__ __launch_bounds__(HVQ_WG)
+__global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
 void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles, u32 items_cap, u32 pair_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];   /* accumulators [16][items_cap] + pair list [pair_cap] */
