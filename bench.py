@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--gop", default="IPBBPBBPBBPBBPBB")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic clips per GPU (replicated over the streams)")
-    ap.add_argument("--preset", default="dense", choices=["dense", "realistic", "flat"])
+    ap.add_argument("--preset", default="dense", choices=["dense", "realistic", "flat", "natural"])
     ap.add_argument("--nslots", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-verify", action="store_true")

@@ -61,7 +61,7 @@ class SynthConfig:
     gop: str = "IPBBPBB"              # decode-order picture kinds of one GOP
     n_gops: int = 1
     seed: int = 0
-    preset: str = "dense"             # "dense"  | "realistic" | "flat"
+    preset: str = "dense"             # "dense"  | "realistic" | "flat" | "natural"
     dc_shifts: Sequence[int] = (0, 1, 2)
     unk_shifts: Sequence[int] = (6, 7, 8, 9)
     mv_res_bits: Sequence[int] = (0, 1, 2)
@@ -239,6 +239,7 @@ class _Gen:
         self.nest_w, self.nest_h = (70, 38) if self.landscape else (38, 70)
         self.picsize = w * h * 3 // 2
         self.is15 = cfg.version == "1.5"
+        self.smooth_mv = cfg.preset == "natural"
         p = cfg.preset
         if p == "dense":
             self.p_zero, self.run_mean = 0.35, 3.0
@@ -246,6 +247,13 @@ class _Gen:
             self.mcb_run_mean, self.proc_run_mean = 4.0, 3.0
             self.p_proc1 = 0.5
         elif p == "realistic":
+            self.p_zero, self.run_mean = 0.6, 12.0
+            self.p_dc_zero, self.dc_run_mean = 0.5, 8.0
+            self.mcb_run_mean, self.proc_run_mean = 24.0, 12.0
+            self.p_proc1 = 0.7
+        elif p == "natural":
+            # realistic sparsity + a coherent vector field: vectors follow a slow random walk from macroblock to
+            # macroblock (what delta-coded vectors, h4m:1846-1860, are designed for), not independent draws
             self.p_zero, self.run_mean = 0.6, 12.0
             self.p_dc_zero, self.dc_run_mean = 0.5, 8.0
             self.mcb_run_mean, self.proc_run_mean = 24.0, 12.0
@@ -492,6 +500,13 @@ class _Gen:
             for attempt in range(24):
                 if attempt == 23:
                     nh, nv = 0, 0
+                elif self.smooth_mv and attempt < 8:
+                    # random walk around the previous vector of this reference, occasional jump
+                    if rng.random() < 0.03:
+                        nh = int(rng.integers(-Rh, Rh)); nv = int(rng.integers(-Rv, Rv))
+                    else:
+                        nh = int(np.clip(mvh + rng.integers(-1, 2), -Rh, Rh - 1))
+                        nv = int(np.clip(mvv + rng.integers(-1, 2), -Rv, Rv - 1))
                 else:
                     nh = int(rng.integers(-Rh, Rh)); nv = int(rng.integers(-Rv, Rv))
                     if attempt > 8:

@@ -18,6 +18,7 @@ SMALL = [
     ("flat128x96", SynthConfig(width=128, height=96, gop="IPBBPBB", seed=13, preset="flat")),
     ("ragged24x40", SynthConfig(width=24, height=40, gop="IPBB", seed=14)),
     ("twogops64x48", SynthConfig(width=64, height=48, gop="IPBB", n_gops=3, seed=15)),
+    ("natural128x96", SynthConfig(width=128, height=96, gop="IPBBPBB", seed=17, preset="natural")),
     ("bigshift64x48", SynthConfig(width=64, height=48, gop="IPBB", seed=16, dc_shifts=(3, 4), unk_shifts=(4, 10, 12))),
 ]
 
