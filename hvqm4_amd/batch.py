@@ -54,6 +54,12 @@ class Context:
         check(lib().hvq_read_picture(self._h, sid, ordinal, out.ctypes.data, out.nbytes))
         return out
 
+    def read_picture_rgb(self, sid: int, ordinal: int, width: int, height: int) -> np.ndarray:
+        """RGB24 (h, w, 3) of a resident picture: the reference player's dumpRGB on the GPU"""
+        out = np.empty(width * height * 3, dtype=np.uint8)
+        check(lib().hvq_read_picture_rgb(self._h, sid, ordinal, out.ctypes.data, out.nbytes))
+        return out.reshape(height, width, 3)
+
     def stats(self) -> HvqStats:
         st = HvqStats()
         check(lib().hvq_get_stats(self._h, C.byref(st)))

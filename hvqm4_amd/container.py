@@ -90,3 +90,28 @@ def video_pictures(data: bytes) -> Iterator[Tuple[int, int, bytes]]:
         total_v += v
     if total_v != hdr.video_frames:
         raise ValueError("total frame count mismatch")
+
+
+def display_order(data: bytes):
+    """Decode-order indices of the video pictures sorted for display.  The reference names its output
+    `gop_start + disp_id` (h4m:2085, 2121-2122): gop_start = pictures before the GOP, disp_id from the record."""
+    hdr = parse_header(data)
+    keys = []
+    pos = 0x44
+    idx = 0
+    for _ in range(hdr.blocks):
+        _prev, bsize, vcount, acount, _m = struct.unpack(">5I", data[pos:pos + 20])
+        pos += 20
+        gop_start = idx
+        v = a = 0
+        while v < vcount or a < acount:
+            id1, _id2, size = struct.unpack(">HHI", data[pos:pos + 8])
+            pos += 8
+            if id1 == 1:
+                keys.append((gop_start + struct.unpack(">I", data[pos:pos + 4])[0], idx))
+                idx += 1
+                v += 1
+            else:
+                a += 1
+            pos += size
+    return [i for _k, i in sorted(keys)]

@@ -36,6 +36,8 @@
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
                                        uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
 
+extern "C" hipError_t hvq_launch_rgb(const uint8_t *yuv_dev, uint8_t *rgb_dev, int w, int h, hipStream_t stream);
+
 #define HVQ_EXPORT extern "C" __attribute__((visibility("default")))
 
 static thread_local std::string g_err;
@@ -113,6 +115,8 @@ struct HvqContext {
     std::vector<Launch> launches;
     HvqStats stats{};
     double parse_seconds = 0;
+    uint8_t *rgb_dev = nullptr;        /* scratch of the display epilogue */
+    size_t rgb_cap = 0;
 };
 
 static int arena_reserve(HvqContext *c, size_t need)
@@ -165,6 +169,7 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->dev_arena) (void)hipFree(c->dev_arena);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tiles_dev) (void)hipFree(c->tiles_dev);
+    if (c->rgb_dev) (void)hipFree(c->rgb_dev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -476,6 +481,30 @@ HVQ_EXPORT int hvq_read_picture(HvqContext *c, int sid, int ordinal, void *dst, 
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(dst, s.slot_ptr(slot), s.pic_bytes, hipMemcpyDeviceToHost));
+    return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_read_picture_rgb(HvqContext *c, int sid, int ordinal, void *dst, size_t cap)
+{
+    if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
+    Stream &s = c->streams[sid];
+    if (ordinal < 0 || ordinal >= s.npics) return fail(HVQ_E_ARG, "bad picture ordinal %d", ordinal);
+    const size_t need = (size_t)s.w * s.h * 3;
+    if (cap < need) return fail(HVQ_E_ARG, "destination too small");
+    if (s.pic_bytes != (uint32_t)(s.w * s.h * 3 / 2)) return fail(HVQ_E_GEOMETRY, "RGB epilogue needs 4:2:0");
+    for (auto &p : c->pending)
+        if (p.stream == sid && p.ordinal == ordinal) return fail(HVQ_E_STATE, "picture %d is queued but not flushed", ordinal);
+    int slot = s.pic_slot[(size_t)ordinal];
+    if (slot < 0) return fail(HVQ_E_STATE, "picture %d is no longer resident (slot reused)", ordinal);
+    HIPCHK(hipSetDevice(c->device));
+    if (need > c->rgb_cap) {
+        if (c->rgb_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->rgb_dev)); }
+        HIPCHK(hipMalloc((void **)&c->rgb_dev, need));
+        c->rgb_cap = need;
+    }
+    HIPCHK(hvq_launch_rgb(s.slot_ptr(slot), c->rgb_dev, s.w, s.h, c->stream));
+    HIPCHK(hipMemcpyAsync(dst, c->rgb_dev, need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return HVQ_OK;
 }
 

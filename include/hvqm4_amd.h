@@ -78,6 +78,10 @@ int  hvq_replay(HvqContext *ctx, int reps, float *gpu_ms);
 int  hvq_read_picture(HvqContext *ctx, int stream, int ordinal, void *dst, size_t cap);
 uint32_t hvq_stream_pic_bytes(HvqContext *ctx, int stream);
 
+/* Display epilogue of the reference player (dumpRGB, h4m:897-926) on the GPU: converts a resident 4:2:0
+ * picture to interleaved RGB24 (w*h*3 bytes, float math identical to the reference) and copies it to host. */
+int  hvq_read_picture_rgb(HvqContext *ctx, int stream, int ordinal, void *dst, size_t cap);
+
 int  hvq_get_stats(HvqContext *ctx, HvqStats *out);
 const char *hvq_last_error_string(void);
 

@@ -39,6 +39,8 @@ def ref():
         lib.ref_time_clip.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
         lib.ref_buffsize.restype = C.c_uint32
         lib.ref_buffsize.argtypes = [C.c_uint16, C.c_uint16, C.c_uint8, C.c_uint8]
+        lib.ref_rgb.restype = C.c_int
+        lib.ref_rgb.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_void_p, C.c_char_p]
         _ref = lib
     return _ref
 
@@ -86,6 +88,7 @@ def oracle():
         lib.hvqo_weight_block.argtypes = [C.c_void_p] + [C.c_uint8] * 5
         lib.hvqo_motion_comp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
         lib.hvqo_tables.argtypes = [C.c_void_p, C.c_void_p]
+        lib.hvqo_yuv420_to_rgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.hvqo_nest.restype = C.c_void_p
         lib.hvqo_nest.argtypes = [C.c_void_p]
         _orc = lib
@@ -114,3 +117,22 @@ def oracle_time(data: bytes, reps: int) -> Tuple[float, int]:
     px = C.c_uint64(0)
     t = oracle().hvqo_time_clip(data, len(data), reps, C.byref(px))
     return t, px.value
+
+
+def ref_rgb(yuv: np.ndarray, w: int, h: int) -> np.ndarray:
+    """RGB24 of a 4:2:0 picture through the reference's own dumpRGB"""
+    import tempfile
+    out = np.zeros(w * h * 3, dtype=np.uint8)
+    yuv = np.ascontiguousarray(yuv)
+    with tempfile.TemporaryDirectory() as d:
+        rc = ref().ref_rgb(yuv.ctypes.data, w, h, out.ctypes.data, os.path.join(d, "x.ppm").encode())
+    if rc:
+        raise RuntimeError(f"ref_rgb failed: {rc}")
+    return out
+
+
+def oracle_rgb(yuv: np.ndarray, w: int, h: int) -> np.ndarray:
+    out = np.zeros(w * h * 3, dtype=np.uint8)
+    yuv = np.ascontiguousarray(yuv)
+    oracle().hvqo_yuv420_to_rgb(yuv.ctypes.data, w, h, out.ctypes.data)
+    return out

@@ -745,3 +745,23 @@ API double hvqo_time_clip(const uint8_t *file, size_t n, int reps, uint64_t *pix
     if (pixels) *pixels = c.px;
     return c.sec;
 }
+
+/* ---------- display epilogue: YUV 4:2:0 -> RGB24 (h4m:897-926) ----------
+ * The reference converts in single-precision float, one operation at a time (no fused multiply-add in its
+ * default x86-64 build), clamps and truncates.  `volatile` pins every intermediate to a float so that no
+ * compiler contracts or widens the expression. */
+static uint8_t clampf255(float f) { return f < 0 ? 0 : f > 255 ? 255 : (uint8_t)f; }
+
+API void hvqo_yuv420_to_rgb(const uint8_t *yuv, int w, int h, uint8_t *rgb)
+{
+    const uint8_t *yp = yuv, *up = yp + (size_t)w * h, *vp = up + (size_t)w * h / 4;
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            volatile float y = yp[(size_t)i * w + j];
+            volatile float u = (float)up[(size_t)(i / 2) * w / 2 + j / 2] - 128.f;
+            volatile float v = (float)vp[(size_t)(i / 2) * w / 2 + j / 2] - 128.f;
+            volatile float rv = 1.402f * v, gu = 0.34414f * u, gv = 0.71414f * v, bu = 1.772f * u;
+            volatile float r = y + rv, g0 = y - gu, g = g0 - gv, b = y + bu;
+            *rgb++ = clampf255(r); *rgb++ = clampf255(g); *rgb++ = clampf255(b);
+        }
+}

@@ -39,6 +39,9 @@ int hvqo_decode_clip(const uint8_t *file, size_t n, uint8_t *out, size_t out_cap
 /* decode-only timing (CPU baseline "port"); returns seconds, *pixels = luma pixels decoded */
 double hvqo_time_clip(const uint8_t *file, size_t n, int reps, uint64_t *pixels);
 
+/* display epilogue of the reference player: YUV 4:2:0 -> RGB24, float, exactly dumpRGB (h4m:897-926) */
+void hvqo_yuv420_to_rgb(const uint8_t *yuv, int w, int h, uint8_t *rgb);
+
 /* white-box pieces for known-answer tests */
 void hvqo_weight_block(uint8_t dst16[16], uint8_t v, uint8_t t, uint8_t b, uint8_t l, uint8_t r);
 void hvqo_motion_comp(uint8_t dst16[16], const uint8_t *src, uint32_t stride, int hx, int hy);

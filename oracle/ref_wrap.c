@@ -246,3 +246,23 @@ REF_API uint32_t ref_buffsize(uint16_t w, uint16_t h, uint8_t hs, uint8_t vs)
     HVQM4InitSeqObj(&s, &vi);
     return HVQM4BuffSize(&s);
 }
+
+/* YUV 4:2:0 picture -> RGB24 through the reference's own dumpRGB (h4m:901-926): it writes a binary PPM,
+ * which is read back.  Returns 0 on success. */
+REF_API int ref_rgb(const uint8_t *yuv, uint16_t w, uint16_t h, uint8_t *rgb_out, const char *tmp_path)
+{
+    Player pl;
+    memset(&pl, 0, sizeof pl);
+    pl.seqobj.width = w; pl.seqobj.height = h; pl.seqobj.h_samp = 2; pl.seqobj.v_samp = 2;
+    pl.present = (void *)yuv;
+    dumpRGB(&pl, tmp_path);
+    FILE *f = fopen(tmp_path, "rb");
+    if (!f) return -1;
+    unsigned fw = 0, fh = 0, maxv = 0;
+    if (fscanf(f, "P6\n%u %u\n%u", &fw, &fh, &maxv) != 3 || fw != w || fh != h) { fclose(f); return -2; }
+    fgetc(f);
+    size_t n = fread(rgb_out, 1, (size_t)w * h * 3, f);
+    fclose(f);
+    remove(tmp_path);
+    return n == (size_t)w * h * 3 ? 0 : -3;
+}

@@ -30,3 +30,11 @@ def test_malformed_containers_are_rejected(mutate, msg):
     data = mutate(clips.get(clips.SMALL[3]).data)
     with pytest.raises(ValueError, match=msg):
         list(video_pictures(data))
+
+
+def test_display_order_sorts_by_gop_start_plus_disp_id():
+    from hvqm4_amd.container import display_order
+    clip = clips.get(clips.SMALL[14])        # three GOPs of I P B B: display I B B P
+    order = display_order(clip.data)
+    assert sorted(order) == list(range(clip.n_pictures))
+    assert order[:4] == [0, 2, 3, 1] and order[4:8] == [4, 6, 7, 5]

@@ -55,3 +55,23 @@ def test_ring_of_three_slots_matches_reference_rotation(gpu_ctx):
         got = gpu_ctx.read_picture(sid, i)
         assert np.array_equal(got, want[i]), f"picture {i}"
     gpu_ctx.close_stream(sid)
+
+
+@pytest.mark.parametrize("case", [clips.SMALL[3], clips.SMALL[5], clips.SMALL[13], clips.MEDIUM[1]], ids=lambda c: c[0])
+def test_rgb_epilogue_matches_oracle(case, gpu_ctx):
+    """display epilogue (dumpRGB, h4m:897-926) on the GPU: float math with one rounding per operation -> bit-exact"""
+    from hvqm4_amd.container import parse_header, video_pictures
+    from oracle import bridge
+    clip = clips.get(case)
+    hdr = parse_header(clip.data)
+    pics = list(video_pictures(clip.data))
+    want = bridge.oracle_decode(clip.data, clip.n_pictures)
+    sid = gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, len(pics) + 3)
+    for ft, _d, pic in pics:
+        gpu_ctx.submit(sid, ft, pic)
+    gpu_ctx.flush()
+    for i in range(len(pics)):
+        got = gpu_ctx.read_picture_rgb(sid, i, hdr.width, hdr.height)
+        exp = bridge.oracle_rgb(want[i], hdr.width, hdr.height).reshape(hdr.height, hdr.width, 3)
+        assert np.array_equal(got, exp), i          # tolerance 0: IEEE single precision on both sides
+    gpu_ctx.close_stream(sid)

@@ -96,3 +96,31 @@ def test_idempotent_and_stateless_across_clips():
     bridge.oracle_decode(b.data, b.n_pictures)
     again = bridge.oracle_decode(a.data, a.n_pictures)
     assert np.array_equal(first, again)
+
+
+def test_rgb_epilogue_matches_golden_and_live_reference():
+    """dumpRGB (h4m:897-926): float conversion, bit-exact because every operation rounds once (no FMA)"""
+    from oracle import bridge
+    n = 0
+    for name, e in MANIFEST["clips"].items():
+        if "rgb_sha256" not in e or "file" not in e:
+            continue
+        data = open(os.path.join(GOLD, e["file"]), "rb").read()
+        pics = bridge.oracle_decode(data, len(e["frame_types"]))
+        got = [hashlib.sha256(bridge.oracle_rgb(p, e["width"], e["height"]).tobytes()).hexdigest() for p in pics]
+        assert got == e["rgb_sha256"], name
+        if bridge.have_ref():
+            assert np.array_equal(bridge.oracle_rgb(pics[0], e["width"], e["height"]), bridge.ref_rgb(pics[0], e["width"], e["height"]))
+        n += 1
+    assert n >= 8
+
+
+def test_rgb_epilogue_extremes():
+    from oracle import bridge
+    w = h = 16
+    for yv, uv, vv in [(0, 0, 0), (255, 255, 255), (255, 0, 255), (0, 255, 0), (128, 128, 128)]:
+        yuv = np.concatenate([np.full(w * h, yv), np.full(w * h // 4, uv), np.full(w * h // 4, vv)]).astype(np.uint8)
+        rgb = bridge.oracle_rgb(yuv, w, h).reshape(h, w, 3)
+        assert (rgb == rgb[0, 0]).all()
+        r = yv + np.float32(1.402) * np.float32(vv - 128)
+        assert rgb[0, 0, 0] == int(min(max(r, 0), 255))
