@@ -160,6 +160,17 @@ def main():
         "flags_or": int(st.flags_or),
     }
 
+    # display epilogue: YUV420 -> RGB24 of the newest picture of every stream, one launch
+    try:
+        ctx.rgb_bench(2)
+        rms, rbytes, rpics = ctx.rgb_bench(50)
+        out["rgb_epilogue"] = {"kernel": "hvq_yuv420_rgb_kernel", "pictures_per_launch": rpics,
+                               "bytes_per_launch": rbytes, "avg_launch_us": round(rms * 1e3 / 50, 2),
+                               "achieved_GBs": round(rbytes * 50 / (rms * 1e-3) / 1e9, 1),
+                               "frac_of_8TBs": round(rbytes * 50 / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    except Exception as e:      # never let the optional epilogue measurement break the headline number
+        out["rgb_epilogue"] = {"error": str(e)}
+
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(clips[0], args.cpu_seconds)
     if rank == 0:

@@ -74,6 +74,7 @@ SYMBOLS = {
     "hvq_read_picture": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "hvq_stream_pic_bytes": (C.c_uint32, [C.c_void_p, C.c_int]),
     "hvq_read_picture_rgb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "hvq_rgb_bench": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "hvq_get_stats": (C.c_int, [C.c_void_p, C.POINTER(HvqStats)]),
     "hvq_last_error_string": (C.c_char_p, []),
     "hvq_parser_create": (C.c_void_p, [C.c_int] * 5),

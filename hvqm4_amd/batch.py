@@ -60,6 +60,12 @@ class Context:
         check(lib().hvq_read_picture_rgb(self._h, sid, ordinal, out.ctypes.data, out.nbytes))
         return out.reshape(height, width, 3)
 
+    def rgb_bench(self, reps: int):
+        """-> (gpu_ms, bytes_per_rep, pictures): batched display epilogue over the newest picture of every stream"""
+        ms, by, n = C.c_float(0), C.c_uint64(0), C.c_uint32(0)
+        check(lib().hvq_rgb_bench(self._h, reps, C.byref(ms), C.byref(by), C.byref(n)))
+        return float(ms.value), int(by.value), int(n.value)
+
     def stats(self) -> HvqStats:
         st = HvqStats()
         check(lib().hvq_get_stats(self._h, C.byref(st)))

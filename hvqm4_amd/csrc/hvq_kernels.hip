@@ -622,9 +622,15 @@ __device__ __forceinline__ u32 rgb_clamp(float f)
     return f < 0.f ? 0u : f > 255.f ? 255u : (u32)f;          /* h4m:897-900 */
 }
 
+struct HvqRgbJob { const uint8_t *yuv; uint8_t *rgb; int w, h; };
+
 __global__ __launch_bounds__(256)
-void hvq_yuv420_rgb_kernel(const uint8_t *__restrict__ yuv, uint8_t *__restrict__ rgb, int w, int h)
+void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
 {
+    const HvqRgbJob J = jobs[blockIdx.y];                    /* one picture per grid row */
+    const uint8_t *__restrict__ yuv = J.yuv;
+    uint8_t *__restrict__ rgb = J.rgb;
+    const int w = J.w, h = J.h;
     const int qw = w >> 2;                                   /* lanes per row */
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= qw * h) return;
@@ -654,9 +660,11 @@ void hvq_yuv420_rgb_kernel(const uint8_t *__restrict__ yuv, uint8_t *__restrict_
     dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2];
 }
 
-extern "C" hipError_t hvq_launch_rgb(const uint8_t *yuv_dev, uint8_t *rgb_dev, int w, int h, hipStream_t stream)
+/* jobs_dev: array of {yuv, rgb, w, h} in device memory; max_lanes = max over jobs of (w/4)*h */
+extern "C" hipError_t hvq_launch_rgb(const void *jobs_dev, int njobs, int max_lanes, hipStream_t stream)
 {
-    const int n = (w >> 2) * h;
-    hipLaunchKernelGGL(hvq_yuv420_rgb_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, yuv_dev, rgb_dev, w, h);
+    if (njobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(hvq_yuv420_rgb_kernel, dim3((max_lanes + 255) / 256, njobs), dim3(256), 0, stream,
+                       (const HvqRgbJob *)jobs_dev);
     return hipGetLastError();
 }

@@ -36,7 +36,8 @@
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
                                        uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
 
-extern "C" hipError_t hvq_launch_rgb(const uint8_t *yuv_dev, uint8_t *rgb_dev, int w, int h, hipStream_t stream);
+extern "C" hipError_t hvq_launch_rgb(const void *jobs_dev, int njobs, int max_lanes, hipStream_t stream);
+struct RgbJob { const uint8_t *yuv; uint8_t *rgb; int w, h; };
 
 #define HVQ_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -117,6 +118,8 @@ struct HvqContext {
     double parse_seconds = 0;
     uint8_t *rgb_dev = nullptr;        /* scratch of the display epilogue */
     size_t rgb_cap = 0;
+    RgbJob *rgb_jobs_dev = nullptr;
+    size_t rgb_jobs_cap = 0;
 };
 
 static int arena_reserve(HvqContext *c, size_t need)
@@ -170,6 +173,7 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tiles_dev) (void)hipFree(c->tiles_dev);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
+    if (c->rgb_jobs_dev) (void)hipFree(c->rgb_jobs_dev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -484,6 +488,36 @@ HVQ_EXPORT int hvq_read_picture(HvqContext *c, int sid, int ordinal, void *dst, 
     return HVQ_OK;
 }
 
+/* convert `n` resident pictures in one launch into consecutive regions of the RGB scratch; optional timing */
+static int rgb_run(HvqContext *c, RgbJob *jobs, int n, int reps, float *gpu_ms)
+{
+    size_t need = 0;
+    int max_lanes = 0;
+    for (int i = 0; i < n; ++i) { need += (size_t)jobs[i].w * jobs[i].h * 3; max_lanes = std::max(max_lanes, (jobs[i].w >> 2) * jobs[i].h); }
+    if (need > c->rgb_cap) {
+        if (c->rgb_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->rgb_dev)); }
+        HIPCHK(hipMalloc((void **)&c->rgb_dev, need));
+        c->rgb_cap = need;
+    }
+    if ((size_t)n > c->rgb_jobs_cap) {
+        if (c->rgb_jobs_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->rgb_jobs_dev)); }
+        HIPCHK(hipMalloc((void **)&c->rgb_jobs_dev, (size_t)n * sizeof(RgbJob)));
+        c->rgb_jobs_cap = (size_t)n;
+    }
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) { jobs[i].rgb = c->rgb_dev + off; off += (size_t)jobs[i].w * jobs[i].h * 3; }
+    HIPCHK(hipMemcpyAsync(c->rgb_jobs_dev, jobs, (size_t)n * sizeof(RgbJob), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (gpu_ms) HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; ++r) HIPCHK(hvq_launch_rgb(c->rgb_jobs_dev, n, max_lanes, c->stream));
+    if (gpu_ms) {
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        HIPCHK(hipEventSynchronize(c->ev1));
+        HIPCHK(hipEventElapsedTime(gpu_ms, c->ev0, c->ev1));
+    }
+    return HVQ_OK;
+}
+
 HVQ_EXPORT int hvq_read_picture_rgb(HvqContext *c, int sid, int ordinal, void *dst, size_t cap)
 {
     if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
@@ -497,14 +531,32 @@ HVQ_EXPORT int hvq_read_picture_rgb(HvqContext *c, int sid, int ordinal, void *d
     int slot = s.pic_slot[(size_t)ordinal];
     if (slot < 0) return fail(HVQ_E_STATE, "picture %d is no longer resident (slot reused)", ordinal);
     HIPCHK(hipSetDevice(c->device));
-    if (need > c->rgb_cap) {
-        if (c->rgb_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->rgb_dev)); }
-        HIPCHK(hipMalloc((void **)&c->rgb_dev, need));
-        c->rgb_cap = need;
-    }
-    HIPCHK(hvq_launch_rgb(s.slot_ptr(slot), c->rgb_dev, s.w, s.h, c->stream));
+    RgbJob job{ s.slot_ptr(slot), nullptr, s.w, s.h };
+    int rc = rgb_run(c, &job, 1, 1, nullptr);
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(dst, c->rgb_dev, need, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_rgb_bench(HvqContext *c, int reps, float *gpu_ms, uint64_t *bytes_per_rep, uint32_t *pictures)
+{
+    if (!c || reps < 1) return fail(HVQ_E_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<RgbJob> jobs;
+    uint64_t bytes = 0;
+    for (auto &s : c->streams) {
+        if (!s.open || s.npics == 0 || s.pic_bytes != (uint32_t)(s.w * s.h * 3 / 2)) continue;
+        int slot = s.pic_slot[(size_t)s.npics - 1];
+        if (slot < 0) continue;
+        jobs.push_back(RgbJob{ s.slot_ptr(slot), nullptr, s.w, s.h });
+        bytes += (uint64_t)s.w * s.h * 9 / 2;              /* 1.5 B/px read + 3 B/px written */
+    }
+    if (jobs.empty()) return fail(HVQ_E_STATE, "no resident 4:2:0 picture");
+    int rc = rgb_run(c, jobs.data(), (int)jobs.size(), reps, gpu_ms);
+    if (rc) return rc;
+    if (bytes_per_rep) *bytes_per_rep = bytes;
+    if (pictures) *pictures = (uint32_t)jobs.size();
     return HVQ_OK;
 }
 

@@ -81,6 +81,9 @@ uint32_t hvq_stream_pic_bytes(HvqContext *ctx, int stream);
 /* Display epilogue of the reference player (dumpRGB, h4m:897-926) on the GPU: converts a resident 4:2:0
  * picture to interleaved RGB24 (w*h*3 bytes, float math identical to the reference) and copies it to host. */
 int  hvq_read_picture_rgb(HvqContext *ctx, int stream, int ordinal, void *dst, size_t cap);
+/* Measurement helper: converts the newest resident picture of every open 4:2:0 stream in ONE launch, `reps`
+ * times, timed with HIP events on the launch stream.  bytes_per_rep = 1.5 B/px read + 3 B/px written. */
+int  hvq_rgb_bench(HvqContext *ctx, int reps, float *gpu_ms, uint64_t *bytes_per_rep, uint32_t *pictures);
 
 int  hvq_get_stats(HvqContext *ctx, HvqStats *out);
 const char *hvq_last_error_string(void);
