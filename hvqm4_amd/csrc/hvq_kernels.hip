@@ -624,6 +624,29 @@ __device__ __forceinline__ u32 rgb_clamp(float f)
 
 struct HvqRgbJob { const uint8_t *yuv; uint8_t *rgb; int w, h; };
 
+/* four samples: one dword of Y, two bytes each of U and V -> three dwords of RGB */
+__device__ __forceinline__ void rgb4(u32 y4, u32 u2, u32 v2, u32 out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float Y = (float)((y4 >> (8 * k)) & 0xFFu);
+        const float U = __fsub_rn((float)((u2 >> (8 * (k >> 1))) & 0xFFu), 128.f);
+        const float V = __fsub_rn((float)((v2 >> (8 * (k >> 1))) & 0xFFu), 128.f);
+        const u32 px[3] = { rgb_clamp(__fadd_rn(Y, __fmul_rn(1.402f, V))),
+                            rgb_clamp(__fsub_rn(__fsub_rn(Y, __fmul_rn(0.34414f, U)), __fmul_rn(0.71414f, V))),
+                            rgb_clamp(__fadd_rn(Y, __fmul_rn(1.772f, U))) };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int byte = 3 * k + c;
+            out[byte >> 2] |= px[c] << (8 * (byte & 3));
+        }
+    }
+}
+
+/* WIDE: one lane = 16 samples of a row (16-byte Y load, 8-byte U/V loads, three 16-byte stores; a wave writes
+ * 3 KB contiguous).  Needs width % 16 == 0; otherwise 4 samples per lane. */
+template <bool WIDE>
 __global__ __launch_bounds__(256)
 void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
 {
@@ -631,40 +654,43 @@ void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
     const uint8_t *__restrict__ yuv = J.yuv;
     uint8_t *__restrict__ rgb = J.rgb;
     const int w = J.w, h = J.h;
-    const int qw = w >> 2;                                   /* lanes per row */
+    constexpr int S = WIDE ? 16 : 4;
+    const int qw = w / S;                                    /* lanes per row */
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= qw * h) return;
     const int y = idx / qw, xq = idx - y * qw;
-    const uint8_t *yp = yuv + (size_t)y * w + 4 * xq;
-    const uint8_t *up = yuv + (size_t)w * h + (size_t)(y >> 1) * (w >> 1) + 2 * xq;
+    const uint8_t *yp = yuv + (size_t)y * w + S * xq;
+    const uint8_t *up = yuv + (size_t)w * h + (size_t)(y >> 1) * (w >> 1) + (S / 2) * xq;
     const uint8_t *vp = up + (size_t)(w >> 1) * (h >> 1);
-    const u32 y4 = *(const u32 *)yp;
-    const u32 u2 = *(const uint16_t *)up, v2 = *(const uint16_t *)vp;
-    u32 out[3] = { 0, 0, 0 };
+    u32 *dst = (u32 *)(rgb + ((size_t)y * w + S * xq) * 3);
+    if (WIDE) {
+        const uint4 y16 = *(const uint4 *)yp;
+        const uint2 u8 = *(const uint2 *)up, v8 = *(const uint2 *)vp;
+        const u32 ys[4] = { y16.x, y16.y, y16.z, y16.w };
+        const u32 us[4] = { u8.x & 0xFFFFu, u8.x >> 16, u8.y & 0xFFFFu, u8.y >> 16 };
+        const u32 vs[4] = { v8.x & 0xFFFFu, v8.x >> 16, v8.y & 0xFFFFu, v8.y >> 16 };
+        u32 o[12];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float Y = (float)((y4 >> (8 * k)) & 0xFFu);
-        const float U = __fsub_rn((float)((u2 >> (8 * (k >> 1))) & 0xFFu), 128.f);
-        const float V = __fsub_rn((float)((v2 >> (8 * (k >> 1))) & 0xFFu), 128.f);
-        const u32 r = rgb_clamp(__fadd_rn(Y, __fmul_rn(1.402f, V)));
-        const u32 g = rgb_clamp(__fsub_rn(__fsub_rn(Y, __fmul_rn(0.34414f, U)), __fmul_rn(0.71414f, V)));
-        const u32 b = rgb_clamp(__fadd_rn(Y, __fmul_rn(1.772f, U)));
-        const u32 px[3] = { r, g, b };
+        for (int q = 0; q < 4; ++q) rgb4(ys[q], us[q], vs[q], o + 3 * q);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int byte = 3 * k + c;
-            out[byte >> 2] |= px[c] << (8 * (byte & 3));
-        }
+        for (int q = 0; q < 3; ++q) ((uint4 *)dst)[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    } else {
+        u32 o[3];
+        rgb4(*(const u32 *)yp, *(const uint16_t *)up, *(const uint16_t *)vp, o);
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
     }
-    u32 *dst = (u32 *)(rgb + ((size_t)y * w + 4 * xq) * 3);
-    dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2];
 }
 
-/* jobs_dev: array of {yuv, rgb, w, h} in device memory; max_lanes = max over jobs of (w/4)*h */
-extern "C" hipError_t hvq_launch_rgb(const void *jobs_dev, int njobs, int max_lanes, hipStream_t stream)
+/* jobs_dev: array of {yuv, rgb, w, h} in device memory; max_lanes = max over jobs of (w/4)*h; wide = every
+ * width is a multiple of 16 */
+extern "C" hipError_t hvq_launch_rgb(const void *jobs_dev, int njobs, int max_lanes, int wide, hipStream_t stream)
 {
     if (njobs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(hvq_yuv420_rgb_kernel, dim3((max_lanes + 255) / 256, njobs), dim3(256), 0, stream,
-                       (const HvqRgbJob *)jobs_dev);
+    if (wide)
+        hipLaunchKernelGGL(hvq_yuv420_rgb_kernel<true>, dim3((max_lanes / 4 + 255) / 256, njobs), dim3(256), 0, stream,
+                           (const HvqRgbJob *)jobs_dev);
+    else
+        hipLaunchKernelGGL(hvq_yuv420_rgb_kernel<false>, dim3((max_lanes + 255) / 256, njobs), dim3(256), 0, stream,
+                           (const HvqRgbJob *)jobs_dev);
     return hipGetLastError();
 }

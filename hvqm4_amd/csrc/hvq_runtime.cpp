@@ -36,7 +36,7 @@
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
                                        uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
 
-extern "C" hipError_t hvq_launch_rgb(const void *jobs_dev, int njobs, int max_lanes, hipStream_t stream);
+extern "C" hipError_t hvq_launch_rgb(const void *jobs_dev, int njobs, int max_lanes, int wide, hipStream_t stream);
 struct RgbJob { const uint8_t *yuv; uint8_t *rgb; int w, h; };
 
 #define HVQ_EXPORT extern "C" __attribute__((visibility("default")))
@@ -492,7 +492,8 @@ HVQ_EXPORT int hvq_read_picture(HvqContext *c, int sid, int ordinal, void *dst, 
 static int rgb_run(HvqContext *c, RgbJob *jobs, int n, int reps, float *gpu_ms)
 {
     size_t need = 0;
-    int max_lanes = 0;
+    int max_lanes = 0, wide = 1;
+    for (int i = 0; i < n; ++i) if (jobs[i].w % 16) wide = 0;
     for (int i = 0; i < n; ++i) { need += (size_t)jobs[i].w * jobs[i].h * 3; max_lanes = std::max(max_lanes, (jobs[i].w >> 2) * jobs[i].h); }
     if (need > c->rgb_cap) {
         if (c->rgb_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->rgb_dev)); }
@@ -509,7 +510,7 @@ static int rgb_run(HvqContext *c, RgbJob *jobs, int n, int reps, float *gpu_ms)
     HIPCHK(hipMemcpyAsync(c->rgb_jobs_dev, jobs, (size_t)n * sizeof(RgbJob), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (gpu_ms) HIPCHK(hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; ++r) HIPCHK(hvq_launch_rgb(c->rgb_jobs_dev, n, max_lanes, c->stream));
+    for (int r = 0; r < reps; ++r) HIPCHK(hvq_launch_rgb(c->rgb_jobs_dev, n, max_lanes, wide, c->stream));
     if (gpu_ms) {
         HIPCHK(hipEventRecord(c->ev1, c->stream));
         HIPCHK(hipEventSynchronize(c->ev1));
