@@ -12,9 +12,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HVQM4_AMD_LIB") or os.path.join(HERE, "libhvqm4_amd.so")   # override: ablation builds only
 
-HVQ_OK, HVQ_E_ARG, HVQ_E_OVERFLOW, HVQ_E_GEOMETRY, HVQ_E_NOGPU, HVQ_E_HIP, HVQ_E_STATE = 0, -1, -2, -3, -4, -5, -6
+HVQ_OK, HVQ_E_ARG, HVQ_E_OVERFLOW, HVQ_E_GEOMETRY, HVQ_E_NOGPU, HVQ_E_HIP, HVQ_E_STATE, HVQ_E_CONTAINER = 0, -1, -2, -3, -4, -5, -6, -7
 ERROR_NAMES = {HVQ_E_ARG: "HVQ_E_ARG", HVQ_E_OVERFLOW: "HVQ_E_OVERFLOW", HVQ_E_GEOMETRY: "HVQ_E_GEOMETRY",
-               HVQ_E_NOGPU: "HVQ_E_NOGPU", HVQ_E_HIP: "HVQ_E_HIP", HVQ_E_STATE: "HVQ_E_STATE"}
+               HVQ_E_NOGPU: "HVQ_E_NOGPU", HVQ_E_HIP: "HVQ_E_HIP", HVQ_E_STATE: "HVQ_E_STATE",
+               HVQ_E_CONTAINER: "HVQ_E_CONTAINER"}
 
 HVQM4_VIDEOSTATE_SIZE = 28120
 HVQM4_VIDEOSTATE_PADDING = 28097
@@ -40,6 +41,18 @@ class SeqObj(C.Structure):                       # h4m_audio_decode.c:516-523
 class VideoInfo(C.Structure):                    # h4m_audio_decode.c:533-540
     _fields_ = [("hres", C.c_uint16), ("vres", C.c_uint16), ("h_samp", C.c_uint8), ("v_samp", C.c_uint8),
                 ("video_mode", C.c_uint8)]
+
+
+class HvqH4mInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("header_size", "body_size", "blocks", "video_frames", "audio_frames",
+                                          "usec_per_frame", "max_frame_size", "pic_bytes")] + \
+               [("width", C.c_uint16), ("height", C.c_uint16), ("h_samp", C.c_uint8), ("v_samp", C.c_uint8),
+                ("video_mode", C.c_uint8), ("is_1_5", C.c_uint8)]
+
+
+class HvqH4mIter(C.Structure):
+    _fields_ = [("pos", C.c_size_t), ("block_end", C.c_size_t)] + \
+               [(n, C.c_uint32) for n in ("block", "v_left", "a_left", "video_seen", "gop_start", "in_block")]
 
 
 class HvqStats(C.Structure):
@@ -77,6 +90,10 @@ SYMBOLS = {
     "hvq_rgb_bench": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "hvq_get_stats": (C.c_int, [C.c_void_p, C.POINTER(HvqStats)]),
     "hvq_last_error_string": (C.c_char_p, []),
+    "hvq_h4m_header": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(HvqH4mInfo)]),
+    "hvq_h4m_begin": (None, [C.POINTER(HvqH4mIter)]),
+    "hvq_h4m_next": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(HvqH4mIter), C.POINTER(C.c_int), C.POINTER(C.c_uint32),
+                               C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "hvq_parser_create": (C.c_void_p, [C.c_int] * 5),
     "hvq_parser_destroy": (None, [C.c_void_p]),
     "hvq_parser_blob_bound": (C.c_size_t, [C.c_void_p]),

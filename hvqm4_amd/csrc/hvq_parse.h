@@ -26,6 +26,7 @@ extern "C" {
 #define HVQ_E_NOGPU      -4
 #define HVQ_E_HIP        -5
 #define HVQ_E_STATE      -6
+#define HVQ_E_CONTAINER  -7
 
 typedef struct HvqParser HvqParser;
 

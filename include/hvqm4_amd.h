@@ -29,6 +29,7 @@ extern "C" {
 #define HVQ_E_NOGPU      -4
 #define HVQ_E_HIP        -5
 #define HVQ_E_STATE      -6
+#define HVQ_E_CONTAINER  -7   /* malformed .h4m file (every case the reference exits on) */
 
 #define HVQ_FRAME_I 0x10   /* container frame ids, h4m:2065-2070 */
 #define HVQ_FRAME_P 0x20
@@ -87,6 +88,30 @@ int  hvq_rgb_bench(HvqContext *ctx, int reps, float *gpu_ms, uint64_t *bytes_per
 
 int  hvq_get_stats(HvqContext *ctx, HvqStats *out);
 const char *hvq_last_error_string(void);
+
+/* .h4m container demux in memory (header checks of load_header h4m:2175-2247, block/record walk of h4m:2427-2537).
+ * Host only.  Typical use:
+ *     HvqH4mInfo info; hvq_h4m_header(file, n, &info);
+ *     int sid = hvq_stream_open(ctx, info.width, info.height, info.h_samp, info.v_samp, info.is_1_5, 6);
+ *     HvqH4mIter it; hvq_h4m_begin(&it);
+ *     while (hvq_h4m_next(file, n, &it, &type, &disp, &pic, &len) == 1) hvq_stream_submit(ctx, sid, type, pic, len);
+ *     hvq_flush(ctx);                                                                                         */
+typedef struct HvqH4mInfo {
+    uint32_t header_size, body_size, blocks, video_frames, audio_frames, usec_per_frame, max_frame_size;
+    uint32_t pic_bytes;            /* w*h*(hs*vs+2)/(hs*vs), h4m:2343-2345 */
+    uint16_t width, height;
+    uint8_t  h_samp, v_samp, video_mode, is_1_5;
+} HvqH4mInfo;
+typedef struct HvqH4mIter {
+    size_t   pos, block_end;
+    uint32_t block, v_left, a_left, video_seen, gop_start, in_block;
+} HvqH4mIter;
+int  hvq_h4m_header(const uint8_t *data, size_t n, HvqH4mInfo *out);
+void hvq_h4m_begin(HvqH4mIter *it);
+/* 1: produced a video picture (`pic` = data after the disp_id word, `disp_id` = gop_start + record disp_id);
+ * 0: clean end of file; < 0: HVQ_E_CONTAINER */
+int  hvq_h4m_next(const uint8_t *data, size_t n, HvqH4mIter *it, int *frame_type, uint32_t *disp_id,
+                  const uint8_t **pic, size_t *len);
 
 /* Host-only pieces, usable without a GPU (parse is pixel-independent). */
 typedef struct HvqParser HvqParser;
