@@ -106,12 +106,12 @@ _Static_assert(sizeof(HvqPicHeader) == 128, "HvqPicHeader must be 128 bytes");
 #endif
 HVQ_HD static inline uint32_t hvq_payload_dwords(uint32_t type, int is_pb, int is_I_luma)
 {
-    uint32_t kind = is_I_luma ? type : (type & 0xFu);
-    if (is_pb && (type & 0x60u)) {
-        if (type & 0x10u) return 0;
-        return kind == 0 ? 0u : kind == 6 ? 4u : kind + 1u;
-    }
-    return (kind == 0 || kind == 8) ? 0u : kind == 6 ? 4u : kind;
+    /* written with selects only: the kernel evaluates it per lane */
+    const uint32_t kind = is_I_luma ? type : (type & 0xFu);
+    const int inter = is_pb && (type & 0x60u);
+    const uint32_t n_intra = (kind == 0u || kind == 8u) ? 0u : kind;
+    const uint32_t n_inter = ((type & 0x10u) || kind == 0u) ? 0u : kind + 1u;
+    return kind == 6u ? ((inter && (type & 0x10u)) ? 0u : 4u) : (inter ? n_inter : n_intra);
 }
 
 /* one reconstruction job = one picture of one stream (device-visible).  The runtime copies the

@@ -97,18 +97,7 @@ __device__ __forceinline__ Blk mc_filter(const McRows &rows, int hx, int hy)
 {
     const uint64_t *q = rows.q;
     Blk o;
-    if (!hy) {
-        if (!hx) {
-#pragma unroll
-            for (int y = 0; y < 4; ++y) o.r[y] = (u32)q[y];
-        } else {
-#pragma unroll
-            for (int y = 0; y < 4; ++y) o.r[y] = __builtin_amdgcn_lerp((u32)q[y], (u32)(q[y] >> 8), 0x01010101u);
-        }
-    } else if (!hx) {
-#pragma unroll
-        for (int y = 0; y < 4; ++y) o.r[y] = __builtin_amdgcn_lerp((u32)q[y], (u32)q[y + 1], 0x01010101u);
-    } else {
+    if (hx & hy) {
         /* (a+b+c+d+2)>>2 exactly: two 16-bit lanes per dword, even and odd bytes */
         const u32 M = 0x00FF00FFu;
         u32 he[5], ho[5];
@@ -123,6 +112,15 @@ __device__ __forceinline__ Blk mc_filter(const McRows &rows, int hx, int hy)
             u32 e = ((he[y] + he[y + 1] + 0x00020002u) >> 2) & M;
             u32 d = ((ho[y] + ho[y + 1] + 0x00020002u) >> 2) & M;
             o.r[y] = e | (d << 8);
+        }
+    } else {
+        /* copy, horizontal or vertical 2-tap: v_lerp_u8 of the row with itself is the identity, so the three cases
+         * are one straight-line sequence with selected operands (no divergence) */
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const u32 p = (u32)q[y];
+            const u32 other = hx ? (u32)(q[y] >> 8) : hy ? (u32)q[y + 1] : p;
+            o.r[y] = __builtin_amdgcn_lerp(p, other, 0x01010101u);
         }
     }
     return o;
@@ -323,11 +321,11 @@ __device__ __forceinline__ u32 lanes_below(unsigned long long mask)
 
 __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, i32 &by)
 {
-    i32 q = (i32)((float)b * rhb);                 /* b < 2^22: estimate within +-1, fixed below */
+    i32 q = (i32)((float)b * rhb);                 /* b < 2^22: estimate within +-1, fixed below without branches */
     i32 r = (i32)b - q * hb;
-    if (r < 0) { q -= 1; r += hb; }
-    else if (r >= hb) { q += 1; r -= hb; }
-    by = q; bx = r;
+    const i32 lo = r < 0 ? 1 : 0, hi = r >= hb ? 1 : 0;
+    by = q - lo + hi;
+    bx = r + (lo - hi) * hb;
 }
 
 #define HVQ_NW (HVQ_WG / 64)
@@ -422,13 +420,12 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const bool inter = is_pb && (T & 0x60u);
     const u32 kind = I_luma ? T : (T & 0xFu);
     const u32 npay = valid ? hvq_payload_dwords(T, is_pb, I_luma) : 0u;
-    /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual; nb = bases */
-    int cls = 0;
-    u32 nb = 0;
-    if (valid) {
-        if (!inter) { if (kind != 0 && kind != 8 && kind != 6) { cls = 1; nb = kind; } }
-        else if (!(T & 0x10u) && kind != 0 && kind != 6) { cls = 2; nb = kind - 1; }
-    }
+    /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual; nb = bases (selects only) */
+    const bool aot_kind = kind != 0 && kind != 6;
+    const bool c1 = valid && !inter && aot_kind && kind != 8;
+    const bool c2 = valid && inter && !(T & 0x10u) && aot_kind;
+    const int cls = c1 ? 1 : c2 ? 2 : 0;
+    const u32 nb = c1 ? kind : c2 ? kind - 1u : 0u;
     const u32 off = wbase + wave_incl_scan(npay) - npay;
     const u32 pincl = wave_incl_scan(nb);
     const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
@@ -456,11 +453,11 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             bool lexp = is_pb ? !(nl & 0x7700u) : ((nl >> 8) == 0 || (nl >> 8) == 8);
             i32 Ll = lexp ? (i32)(nl & 0xFF) : V;
             o = weight_block(V, Tt, Bb, Ll, Rr);
-        } else if (!inter && kind == 8) {
-            u32 v = (u32)V * 0x01010101u;                                     /* h4m:281-286 */
-            o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
         } else {
-            o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3];   /* literal, h4m:543-549 */
+            /* flat DC (h4m:281-286) or literal (h4m:543-549) */
+            const u32 v = (u32)V * 0x01010101u;
+            o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
+            if (kind == 6) { o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3]; }
         }
 #pragma unroll
         for (int y = 0; y < 4; ++y) s_out[y][tid] = o.r[y];
