@@ -23,8 +23,9 @@
  *                 literal block (kind 6)      : 4 dwords = the 16 samples, row-major
  *                 AOT basis                   : 1 dword  = HVQ_BASIS(word, coef_sum)
  *                 MC-residual ("predi") block : 2 dwords {i32 dc_part, i32 gain_part} + bases
- *   nest        70*38 bytes (I pictures, and P/B pictures that contain intra AOT blocks; the
- *               nest of the most recent I picture, h4m:1823 -> 1367).
+ *   nest        the 70x38 nest of 4-bit values packed two per byte (value n of the reference's
+ *               nest_data[] = nibble n), HVQ_NESTP_BYTES; I pictures, and P/B pictures that contain
+ *               intra AOT blocks (the nest of the most recent I picture, h4m:1823 -> 1367).
  *
  * A tile is HVQ_TILE_BLOCKS consecutive 4x4 blocks of ONE plane in raster order; one
  * workgroup reconstructs one tile.
@@ -39,6 +40,7 @@
 #define HVQ_TILE_BLOCKS  256           /* blocks per tile = threads per workgroup */
 #endif
 #define HVQ_NEST_BYTES   (70 * 38)
+#define HVQ_NESTP_BYTES  (HVQ_NEST_BYTES / 2 + 14)   /* nest packed two 4-bit values per byte, padded to 16 */
 
 #define HVQ_PIC_I 0
 #define HVQ_PIC_P 1
@@ -117,28 +119,39 @@ HVQ_HD static inline uint32_t hvq_payload_dwords(uint32_t type, int is_pb, int i
 /* one reconstruction job = one picture of one stream (device-visible).  The runtime copies the
  * geometry out of the blob header so that a workgroup reaches its map with two dependent loads
  * (tile table -> job -> map) instead of three. */
+typedef struct HvqPlaneRec {       /* everything a tile of this plane needs, ready to use (32 bytes) */
+    uint64_t map;                  /* device address of the plane's map (entry [-1][-1], i.e. incl. border) */
+    uint64_t dst;                  /* device address of the plane inside the destination picture */
+    uint32_t plane_off;            /* byte offset of the plane inside a picture buffer (reference reads) */
+    uint32_t tile_first;           /* first tile index of the plane */
+    uint16_t hb, vb;               /* 4x4 blocks */
+    uint16_t pw;                   /* samples per row */
+    uint8_t  ws, hs;               /* subsampling shifts relative to luma */
+} HvqPlaneRec;
+
 typedef struct HvqJob {
-    uint64_t blob;                 /* device address of the descriptor blob */
-    uint64_t dst;                  /* device address of the picture being written */
     uint64_t ref0;                 /* "past"   (macroblock type 1) */
     uint64_t ref1;                 /* "future" (macroblock type 2) */
+    uint64_t pool;                 /* device addresses of the blob sections */
+    uint64_t mv;
+    uint64_t wave_base;
+    uint64_t nest;                 /* nibble-packed nest (HVQ_NESTP_BYTES), 0 when absent */
     uint32_t slot_bytes;           /* readable bytes at ref0/ref1 (>= pic_bytes + 8) */
     uint32_t flags;
     uint16_t width, height;
-    uint8_t  pic_kind, unk_shift, wshift, hshift;
-    uint16_t hb[3], vb[3];
-    uint32_t plane_off[3];
-    uint32_t map_off[3];
-    uint32_t mv_off, wave_base_off, pool_off, nest_off;
-    uint32_t tile_first[4];
+    uint8_t  pic_kind, unk_shift, pad0[2];
     uint32_t mcb_w;
-    uint32_t pad[2];
+    uint32_t pad1[3];
+    HvqPlaneRec plane[3];
+    uint32_t pad2[8];
 } HvqJob;
 
 #if defined(__cplusplus)
-static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
+static_assert(sizeof(HvqPlaneRec) == 32, "HvqPlaneRec must be 32 bytes");
+static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
 #else
-_Static_assert(sizeof(HvqJob) == 128, "HvqJob must be 128 bytes");
+_Static_assert(sizeof(HvqPlaneRec) == 32, "HvqPlaneRec must be 32 bytes");
+_Static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
 #endif
 
 /* one workgroup = one tile */

@@ -329,7 +329,6 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 }
 
 #define HVQ_NW (HVQ_WG / 64)
-#define HVQ_NESTP_BYTES (2660 / 2 + 16)   /* linear nibble index = the reference's byte index (stride 70 / 38) */
 #define HVQ_PAIR_CAP 1024            /* (block, basis) pairs handled basis-parallel per tile; beyond: serial fallback */
 
 /*
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
 void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles, u32 items_cap, u32 pair_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];   /* accumulators [16][items_cap] + pair list [pair_cap] */
-    __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES];   /* nest packed two 4-bit values per byte */
+    __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];   /* nest packed two 4-bit values per byte */
     __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];   /* [sample row][block] packed dwords */
     i32 *s_acc = (i32 *)s_dyn;             /* AOT accumulators, [sample][queued block]: lanes of one ds_add hit
                                               consecutive banks (a [block][16] layout is a 32-way conflict) */
@@ -367,22 +366,15 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const u32 tile = __builtin_amdgcn_readfirstlane(tiles[blockIdx.x].tile);
     if (job_id == 0xFFFFFFFFu) return;            /* padding entry of the XCD-dealt tile table (uniform exit) */
     const HvqJob *__restrict__ J = jobs + job_id;
-    const uint8_t *__restrict__ blob = (const uint8_t *)J->blob;
-
-    /* TOOLCHAIN HAZARD (ROCm 7.2 hipcc, gfx950): a wave-uniform but run-time index into these small
-     * arrays was lowered to s_load_dword with base (J + 2p) and soffset 2p; for p = 1 neither part is
-     * dword aligned and the scalar memory unit truncates them separately -> element 0 is read.  All
-     * per-plane fields are therefore fetched with constant indices and selected. */
-#define PSEL(a) (p == 0 ? (a)[0] : p == 1 ? (a)[1] : (a)[2])
-    const u32 tf1 = J->tile_first[1], tf2 = J->tile_first[2];
-    const int p = (tile >= tf1) + (tile >= tf2);
-    const u32 tf = p == 0 ? 0u : p == 1 ? tf1 : tf2;
-    const i32 hb = PSEL(J->hb), vb = PSEL(J->vb);
+    /* plane of the tile, then ONE 32-byte record with everything per-plane (absolute pointers, geometry) */
+    const int p = (tile >= J->plane[1].tile_first) + (tile >= J->plane[2].tile_first);
+    const HvqPlaneRec *__restrict__ R = &J->plane[p];
+    const i32 hb = R->hb, vb = R->vb;
     const float rhb = 1.0f / (float)hb;
     const u32 nblocks = (u32)hb * (u32)vb;
-    const u32 b0 = (tile - tf) * HVQ_TILE_BLOCKS;
-    const i32 ws = p ? J->wshift : 0, hs = p ? J->hshift : 0;
-    const i32 pw = J->width >> ws;
+    const u32 b0 = (tile - R->tile_first) * HVQ_TILE_BLOCKS;
+    const i32 ws = R->ws, hs = R->hs;
+    const i32 pw = R->pw;
     const u32 flags = J->flags;
     const bool is_pb = J->pic_kind != HVQ_PIC_I;
     const bool I_luma = !is_pb && p == 0;
@@ -391,15 +383,14 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
     const bool big = flags & HVQ_F_BIG_AOT;
-    const uint8_t *map = blob + PSEL(J->map_off);
-    const u32 *__restrict__ pool = (const u32 *)(blob + J->pool_off);
-    const u32 *__restrict__ mvs = (const u32 *)(blob + J->mv_off);
-    const i32 plane_off = (i32)PSEL(J->plane_off);
-    uint8_t *plane = (uint8_t *)J->dst + plane_off;
+    const uint8_t *map = (const uint8_t *)R->map;
+    const u32 *__restrict__ pool = (const u32 *)J->pool;
+    const u32 *__restrict__ mvs = (const u32 *)J->mv;
+    const i32 plane_off = (i32)R->plane_off;
+    uint8_t *plane = (uint8_t *)R->dst;
     const i32 slot = (i32)J->slot_bytes;
     const i32 mcb_w = (i32)J->mcb_w;
     const i32 lw = J->width;
-#undef PSEL
 
     /* ---- phase A: own block ---- */
     const u32 b = b0 + (u32)tid;
@@ -413,7 +404,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const u32 nl = *(const uint16_t *)(ent - 2), nr = *(const uint16_t *)(ent + 2);
     u32 mvw = 0;
     if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
-    const u32 wbase = ((const u32 *)(blob + J->wave_base_off))[tile * HVQ_NW + (u32)wave];
+    const u32 wbase = ((const u32 *)J->wave_base)[tile * HVQ_NW + (u32)wave];
 
     const i32 V = e16 & 0xFF;
     const u32 T = valid ? (e16 >> 8) : 0u;
@@ -426,8 +417,9 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const bool c2 = valid && inter && !(T & 0x10u) && aot_kind;
     const int cls = c1 ? 1 : c2 ? 2 : 0;
     const u32 nb = c1 ? kind : c2 ? kind - 1u : 0u;
-    const u32 off = wbase + wave_incl_scan(npay) - npay;
-    const u32 pincl = wave_incl_scan(nb);
+    /* payload offset / pair slot: prefix sums over the wave, skipped when the wave carries no payload at all */
+    u32 off = wbase, pincl = 0;
+    if (__ballot(npay != 0)) { off += wave_incl_scan(npay) - npay; pincl = wave_incl_scan(nb); }
     const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
     if (lane == 63) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = pincl; }
 
@@ -488,12 +480,8 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         }
     }
     if (nI) {
-        /* 4 nest bytes (values 0..15) -> 2 packed bytes */
-        const u32 *src = (const u32 *)(blob + J->nest_off);
-        for (int i = tid; i < HVQ_NEST_BYTES / 4; i += HVQ_WG) {
-            const u32 v = src[i];
-            ((uint16_t *)s_nest)[i] = (uint16_t)((v & 0xFu) | ((v >> 4) & 0xF0u) | ((v >> 8) & 0xF00u) | ((v >> 12) & 0xF000u));
-        }
+        const u32 *src = (const u32 *)J->nest;                /* already nibble-packed by the host */
+        for (int i = tid; i < (HVQ_NESTP_BYTES + 3) / 4; i += HVQ_WG) ((u32 *)s_nest)[i] = src[i];
     }
     if (total) __syncthreads();                                                /* barrier 2: queue + nest staged */
 

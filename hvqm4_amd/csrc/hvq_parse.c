@@ -194,7 +194,7 @@ HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int 
     p->wave_base_off = off;
     off = ALIGN16(off + 4u * p->total_tiles * (HVQ_TILE_BLOCKS / 64));
     p->fixed_bytes = off;
-    p->bound = (size_t)off + 64u * blocks + ALIGN16(HVQ_NEST_BYTES) + 64;
+    p->bound = (size_t)off + 64u * blocks + ALIGN16(HVQ_NESTP_BYTES) + 64;
     return p;
 }
 
@@ -359,6 +359,13 @@ static void fill_header(const HvqParser *p, uint8_t *blob, int kind, uint32_t po
     h->max_items = (uint16_t)p->max_items; h->max_pairs = p->max_pairs;
 }
 
+/* nest values are 4 bits (h4m:1211): two per byte, value n in nibble n -- what the kernel stages in LDS */
+static void pack_nest(uint8_t *dst, const uint8_t *nest)
+{
+    memset(dst, 0, ALIGN16(HVQ_NESTP_BYTES));
+    for (int i = 0; i < HVQ_NEST_BYTES; i += 2) dst[i >> 1] = (uint8_t)((nest[i] & 0xF) | ((nest[i + 1] & 0xF) << 4));
+}
+
 /* ------------------------------------------------------------------ I pictures */
 static void ipic_kinds(HvqParser *p, uint8_t *blob)                              /* h4m:1073-1130 */
 {
@@ -452,7 +459,7 @@ static int parse_ipic(HvqParser *p, const uint8_t *pic, uint8_t *blob, size_t ca
     make_nest(p, blob, nx, ny);
     uint32_t pool_dwords = layout_pool(p, blob, 0);
     size_t total = (size_t)p->fixed_bytes + 4u * (size_t)pool_dwords;
-    if (p->flags & HVQ_F_HAS_NEST) total = ALIGN16(total) + ALIGN16(HVQ_NEST_BYTES);
+    if (p->flags & HVQ_F_HAS_NEST) total = ALIGN16(total) + ALIGN16(HVQ_NESTP_BYTES);
     total = ALIGN16(total);
     if (total > cap || pool_dwords >= (1u << 22)) return HVQ_E_OVERFLOW;   /* kernel packs offsets in 22 bits */
     fill_header(p, blob, HVQ_PIC_I, pool_dwords, (uint32_t)total);
@@ -474,7 +481,7 @@ static int parse_ipic(HvqParser *p, const uint8_t *pic, uint8_t *blob, size_t ca
         }
     }
     if (p->flags & HVQ_F_HAS_NEST)
-        memcpy(blob + ((HvqPicHeader *)blob)->nest_off, p->nest, HVQ_NEST_BYTES);
+        pack_nest(blob + ((HvqPicHeader *)blob)->nest_off, p->nest);
     *blob_len = total;
     return HVQ_OK;
 }
@@ -592,7 +599,7 @@ static int parse_pbpic(HvqParser *p, int is_P, const uint8_t *pic, uint8_t *blob
     pb_pass1(p, blob, is_P);
     uint32_t pool_dwords = layout_pool(p, blob, 1);
     size_t total = (size_t)p->fixed_bytes + 4u * (size_t)pool_dwords;
-    if (p->flags & HVQ_F_HAS_NEST) total = ALIGN16(total) + ALIGN16(HVQ_NEST_BYTES);
+    if (p->flags & HVQ_F_HAS_NEST) total = ALIGN16(total) + ALIGN16(HVQ_NESTP_BYTES);
     total = ALIGN16(total);
     if (total > cap || pool_dwords >= (1u << 22)) return HVQ_E_OVERFLOW;
     fill_header(p, blob, is_P ? HVQ_PIC_P : HVQ_PIC_B, pool_dwords, (uint32_t)total);
@@ -653,7 +660,7 @@ static int parse_pbpic(HvqParser *p, int is_P, const uint8_t *pic, uint8_t *blob
             }
         }
     if (p->flags & HVQ_F_HAS_NEST)
-        memcpy(blob + ((HvqPicHeader *)blob)->nest_off, p->nest, HVQ_NEST_BYTES);
+        pack_nest(blob + ((HvqPicHeader *)blob)->nest_off, p->nest);
     *blob_len = total;
     return HVQ_OK;
 }

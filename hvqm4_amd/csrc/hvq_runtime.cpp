@@ -368,21 +368,29 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         const Stream &s = c->streams[(size_t)p.stream];
         HvqJob &j = jobs[i];
         memset(&j, 0, sizeof j);
-        j.blob = (uint64_t)(uintptr_t)(c->dev_arena + p.blob_off);
-        j.dst = (uint64_t)(uintptr_t)s.slot_ptr(p.dst);
+        const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + p.blob_off);
+        const uint64_t blob = (uint64_t)(uintptr_t)(c->dev_arena + p.blob_off);
+        const uint64_t dst = (uint64_t)(uintptr_t)s.slot_ptr(p.dst);
         j.ref0 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref0);
         j.ref1 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref1);
+        j.pool = blob + hd->pool_off;
+        j.mv = blob + hd->mv_off;
+        j.wave_base = blob + hd->wave_base_off;
+        j.nest = hd->nest_off ? blob + hd->nest_off : 0;
         j.slot_bytes = s.slot_bytes;
-        const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + p.blob_off);
         j.flags = hd->flags; j.width = hd->width; j.height = hd->height;
-        j.pic_kind = hd->pic_kind; j.unk_shift = hd->unk_shift; j.wshift = hd->wshift; j.hshift = hd->hshift;
-        for (int k = 0; k < 3; ++k) {
-            j.hb[k] = hd->hb[k]; j.vb[k] = hd->vb[k];
-            j.plane_off[k] = hd->plane_off[k]; j.map_off[k] = hd->map_off[k];
-        }
-        j.mv_off = hd->mv_off; j.wave_base_off = hd->wave_base_off; j.pool_off = hd->pool_off; j.nest_off = hd->nest_off;
-        for (int k = 0; k < 4; ++k) j.tile_first[k] = hd->tile_first[k];
+        j.pic_kind = hd->pic_kind; j.unk_shift = hd->unk_shift;
         j.mcb_w = hd->mcb_w;
+        for (int k = 0; k < 3; ++k) {
+            HvqPlaneRec &r = j.plane[k];
+            r.map = blob + hd->map_off[k];
+            r.dst = dst + hd->plane_off[k];
+            r.plane_off = hd->plane_off[k];
+            r.tile_first = hd->tile_first[k];
+            r.hb = hd->hb[k]; r.vb = hd->vb[k];
+            r.ws = k ? hd->wshift : 0; r.hs = k ? hd->hshift : 0;
+            r.pw = (uint16_t)(hd->width >> r.ws);
+        }
         st.pictures++;
         st.luma_pixels += (uint64_t)p.w * p.h;
         st.algorithmic_bytes += (uint64_t)s.pic_bytes * (p.kind == HVQ_PIC_I ? 1u : 2u);

@@ -89,7 +89,10 @@ API int hvqd_recon(const uint8_t *blob, uint8_t *dst, const uint8_t *ref0, const
     static const int a4[4] = { 2, 0, -1, -1 };
     const HvqPicHeader *h = (const HvqPicHeader *)blob;
     if (h->magic != HVQ_MAGIC) return -1;
-    Ctx c = { blob, h, h->nest_off ? blob + h->nest_off : NULL, (h->flags & HVQ_F_LANDSCAPE) ? 70 : 38, slot_bytes, { 0 } };
+    uint8_t nest_bytes[HVQ_NEST_BYTES];                      /* the blob carries the nest nibble-packed */
+    if (h->nest_off)
+        for (int i = 0; i < HVQ_NEST_BYTES; ++i) nest_bytes[i] = (blob[h->nest_off + (i >> 1)] >> (4 * (i & 1))) & 0xF;
+    Ctx c = { blob, h, h->nest_off ? nest_bytes : NULL, (h->flags & HVQ_F_LANDSCAPE) ? 70 : 38, slot_bytes, { 0 } };
     for (int i = 1; i < 16; ++i) c.divt[i] = 0x1000 / (i * 16) * 16;
     const uint32_t *pool = (const uint32_t *)(blob + h->pool_off);
     const uint32_t *wave_base = (const uint32_t *)(blob + h->wave_base_off);
