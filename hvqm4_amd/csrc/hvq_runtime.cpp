@@ -218,6 +218,7 @@ HVQ_EXPORT int hvq_stream_close(HvqContext *c, int sid)
     Stream &s = c->streams[sid];
     hvq_parser_destroy(s.parser); s.parser = nullptr;
     HIPCHK(hipFree(s.dev)); s.dev = nullptr;
+    c->launches.clear();               /* the resident batch may reference the freed slots: no replay after a close */
     s.open = false;
     return HVQ_OK;
 }

@@ -70,6 +70,7 @@ class SynthConfig:
     max_predi_bases: int = 6
     literal_weight: float = 1.0
     usec_per_frame: int = 33366
+    sampling: str = "420"             # "420" (h_samp = v_samp = 2) | "444" (1, 1: four chroma blocks per macroblock)
 
 
 class _Ops:
@@ -234,10 +235,13 @@ class _Gen:
         assert w % 8 == 0 and h % 8 == 0 and w >= 8 and h >= 8
         self.w, self.h = w, h
         self.hb, self.vb = w // 4, h // 4
-        self.chb, self.cvb = w // 8, h // 8
+        self.s444 = cfg.sampling == "444"
+        self.cshift = 0 if self.s444 else 1                    # chroma plane shift
+        self.cblk = 4 if self.s444 else 1                      # chroma blocks per macroblock (h4m:852-854)
+        self.chb, self.cvb = (w // 4, h // 4) if self.s444 else (w // 8, h // 8)
         self.landscape = w >= h
         self.nest_w, self.nest_h = (70, 38) if self.landscape else (38, 70)
-        self.picsize = w * h * 3 // 2
+        self.picsize = w * h * 3 if self.s444 else w * h * 3 // 2
         self.is15 = cfg.version == "1.5"
         self.smooth_mv = cfg.preset == "natural"
         p = cfg.preset
@@ -393,10 +397,11 @@ class _Gen:
     def _mc_extent(self, rx: int, ry: int):
         """largest in-plane coordinates touched by the MC reads of one macroblock:
         (luma col, luma row, chroma col, chroma row); half-pel rule per version (h4m:1329-1343)"""
-        pdx, pdy = rx >> 1, ry >> 1
+        pdx, pdy = rx >> self.cshift, ry >> self.cshift
         hx, hy = (pdx & 1, pdy & 1) if self.is15 else (rx & 1, ry & 1)
+        cext = 7 if self.s444 else 3                           # chroma macroblock is 8x8 in 4:4:4
         return ((rx >> 1) + 7 + (rx & 1), (ry >> 1) + 7 + (ry & 1),
-                (pdx >> 1) + 3 + hx, (pdy >> 1) + 3 + hy)
+                (pdx >> 1) + cext + hx, (pdy >> 1) + cext + hy)
 
     def _mv_legal(self, rx: int, ry: int, predi: bool) -> bool:
         """every MC read stays inside its own plane's storage (rows may run off the right
@@ -405,7 +410,7 @@ class _Gen:
         if rx < 0 or ry < 0:
             return False
         lc, lr, cc, cr = self._mc_extent(rx, ry)
-        cw, ch = w // 2, h // 2
+        cw, ch = w >> self.cshift, h >> self.cshift
         if lr * w + lc > w * h - 1 or cr * cw + cc > cw * ch - 1:
             return False
         if predi:
@@ -424,7 +429,7 @@ class _Gen:
         if rx < 0 or ry < 0:
             return False
         lc, lr, cc, cr = self._mc_extent(rx, ry)
-        return lc <= self.w - 1 and lr <= self.h - 1 and cc <= self.w // 2 - 1 and cr <= self.h // 2 - 1
+        return lc <= self.w - 1 and lr <= self.h - 1 and cc <= (self.w >> self.cshift) - 1 and cr <= (self.h >> self.cshift) - 1
 
     def gen_PB(self, kind: int) -> _Picture:
         rng = self.rng
@@ -528,12 +533,13 @@ class _Gen:
             mvh, mvv = nh, nv
         # 4. pass 1 (spread_PB_descMap): DC + kinds ; pass 2 payload ops are queued per MCB
         rleY = rleC = 0
-        kinds = np.zeros((nm, 6), dtype=np.int32)       # Y TL,BL,BR,TR, U, V
+        nc = self.cblk
+        kinds = np.zeros((nm, 4 + 2 * nc), dtype=np.int32)   # Y TL,BL,BR,TR, then U blocks, then V blocks
         for m in range(nm):
             t = int(types[m])
             intra = t == 0
             if intra:
-                for p, cnt in ((0, 4), (1, 1), (2, 1)):
+                for p, cnt in ((0, 4), (1, nc), (2, nc)):
                     for _ in range(cnt):
                         d = self._delta() if rng.random() > self.p_dc_zero else 0
                         for lf in _sovf_leaves(d):
@@ -554,33 +560,34 @@ class _Gen:
                     k &= 0xF
                     pic.ops[BN0].leaf(k)
                     kinds[m, j] = k
-            if rleC:
-                rleC -= 1
-            elif rng.random() < self.p_zero:
-                pic.ops[BN1].leaf(0)
-                rleC = self._run(self.run_mean)
-                pic.ops[BNR1].leaf(rleC)
-            else:
-                while True:
-                    u = (self._intra_kind(False) if intra else self._inter_kind(pok)) if rng.random() > 0.3 else 0
-                    v = (self._intra_kind(False) if intra else self._inter_kind(pok)) if rng.random() > 0.3 else 0
-                    if (u & 0xF) | (v & 0xF):
-                        break
-                pic.ops[BN1].leaf((u & 0xF) | ((v & 0xF) << 4))
-                kinds[m, 4], kinds[m, 5] = u & 0xF, v & 0xF
+            for jc in range(nc):
+                if rleC:
+                    rleC -= 1
+                elif rng.random() < self.p_zero:
+                    pic.ops[BN1].leaf(0)
+                    rleC = self._run(self.run_mean)
+                    pic.ops[BNR1].leaf(rleC)
+                else:
+                    while True:
+                        u = (self._intra_kind(False) if intra else self._inter_kind(pok)) if rng.random() > 0.3 else 0
+                        v = (self._intra_kind(False) if intra else self._inter_kind(pok)) if rng.random() > 0.3 else 0
+                        if (u & 0xF) | (v & 0xF):
+                            break
+                    pic.ops[BN1].leaf((u & 0xF) | ((v & 0xF) << 4))
+                    kinds[m, 4 + jc], kinds[m, 4 + nc + jc] = u & 0xF, v & 0xF
         # 5. pass 2 payloads (BpicPlaneDec second loop): per MCB, per plane, per block
         for m in range(nm):
             t = int(types[m])
             if t == 0:
-                for j in range(6):
-                    p = 0 if j < 4 else j - 3
+                for j in range(4 + 2 * nc):
+                    p = 0 if j < 4 else 1 if j < 4 + nc else 2
                     k = int(kinds[m, j])
                     if k == 0 or k == 8:
                         continue
                     self._emit_payload_intra(pic, p, k)
             elif procs[m] == 0:
-                for j in range(6):
-                    p = 0 if j < 4 else j - 3
+                for j in range(4 + 2 * nc):
+                    p = 0 if j < 4 else 1 if j < 4 + nc else 2
                     k = int(kinds[m, j])
                     if k == 6:
                         pic.ops[FX0 + p].bytes += rng.integers(0, 256, 16, dtype=np.uint8).tobytes()
@@ -628,10 +635,12 @@ class SynthClip:
     kinds: List[int]                       # frame type per picture, decode order
     cursors: List[List[int]]               # expected reader cursor per picture per stream
     pictures: List[bytes] = field(default_factory=list)   # picture data (after disp_id), decode order
+    samp: int = 2
 
     @property
     def picsize(self) -> int:
-        return self.width * self.height * 3 // 2
+        ss = self.samp * self.samp
+        return self.width * self.height * (ss + 2) // ss
 
     @property
     def n_pictures(self) -> int:
@@ -666,6 +675,7 @@ def make_clip(cfg: SynthConfig) -> SynthClip:
     magic = (b"HVQM4 1.5" if cfg.version == "1.5" else b"HVQM4 1.3").ljust(16, b"\0")
     hdr = magic + struct.pack(">IIIIIIIII", 0x44, len(body), cfg.n_gops, len(kinds), 0,
                               cfg.usec_per_frame, max_frame, 0, 0)
-    hdr += struct.pack(">HHBBBBBBBBI", cfg.width, cfg.height, 2, 2, 0, 0, 0, 0, 0, 0, 0)
+    samp = 1 if cfg.sampling == "444" else 2
+    hdr += struct.pack(">HHBBBBBBBBI", cfg.width, cfg.height, samp, samp, 0, 0, 0, 0, 0, 0, 0)
     assert len(hdr) == 0x44, len(hdr)
-    return SynthClip(bytes(hdr + body), cfg.width, cfg.height, cfg.version, kinds, cursors, pictures)
+    return SynthClip(bytes(hdr + body), cfg.width, cfg.height, cfg.version, kinds, cursors, pictures, samp)

@@ -20,6 +20,10 @@ SMALL = [
     ("twogops64x48", SynthConfig(width=64, height=48, gop="IPBB", n_gops=3, seed=15)),
     ("natural128x96", SynthConfig(width=128, height=96, gop="IPBBPBB", seed=17, preset="natural")),
     ("bigshift64x48", SynthConfig(width=64, height=48, gop="IPBB", seed=16, dc_shifts=(3, 4), unk_shifts=(4, 10, 12))),
+    # 4:4:4 (h_samp = v_samp = 1): four chroma blocks per macroblock, chroma planes as large as luma
+    ("yuv444_64x48", SynthConfig(width=64, height=48, gop="IPBBPBB", seed=18, sampling="444")),
+    ("yuv444_13_portrait48x64", SynthConfig(width=48, height=64, gop="IPBB", seed=19, sampling="444", version="1.3", runoff_prob=0.3)),
+    ("yuv444_296x160", SynthConfig(width=296, height=160, gop="IPB", seed=20, sampling="444", weird_kinds=True)),
 ]
 
 MEDIUM = [

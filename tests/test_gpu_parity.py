@@ -26,7 +26,7 @@ def test_batched_path_matches_oracle(case, gpu_ctx):
     assert np.array_equal(got, want), _first_diff(got, want)      # integer pixel work: bit-exact
 
 
-@pytest.mark.parametrize("case", clips.SMALL[:8] + clips.MEDIUM[1:2], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", clips.SMALL[:8] + clips.SMALL[17:18] + clips.MEDIUM[1:2], ids=lambda c: c[0])
 def test_sdk_entry_points_match_oracle(case):
     """The seven SDK symbols with the reference player's buffer rotation (h4m:2078-2138)."""
     from hvqm4_amd import sdk

@@ -21,7 +21,7 @@ def decode_via_descriptors(clip, truncate=None):
     o.hvqd_recon.argtypes = [C.c_void_p] * 4 + [C.c_uint32]
     ps = clip.picsize
     slot = ps + 64
-    prs = l.hvq_parser_create(clip.width, clip.height, 2, 2, 1 if clip.version == "1.5" else 0)
+    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp, clip.samp, 1 if clip.version == "1.5" else 0)
     assert prs
     bound = l.hvq_parser_blob_bound(prs)
     blob = np.zeros(bound, dtype=np.uint8)
