@@ -174,7 +174,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(clips[0], args.cpu_seconds)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        grp.emit(json.dumps(out))
     ctx.close()
     grp.close()
 

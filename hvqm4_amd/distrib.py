@@ -40,12 +40,19 @@ class Group:
         self.dist = None
         self.torch = None
         self.device = None
-        if self.world > 1:
+        self._out_fd = None
+        if self.world > 1 or os.environ.get("HVQM4_DIST_FORCE"):      # FORCE: rehearse the RCCL path with one rank
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
             backend = backend or os.environ.get("HVQM4_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            # RCCL prints a version banner on stdout when the first communicator is created: keep stdout for the
+            # one JSON result line (emit) and send everything else to stderr
+            import sys
+            sys.stdout.flush()
+            self._out_fd = os.dup(1)
+            os.dup2(2, 1)
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)
@@ -85,6 +92,13 @@ class Group:
         for o in out:
             r = (r + (int(o[0].item()) | (int(o[1].item()) << 63))) & 0xFFFFFFFFFFFFFFFF
         return r
+
+    def emit(self, text: str):
+        """write the result line to the process's real stdout"""
+        if self._out_fd is None:
+            print(text, flush=True)
+        else:
+            os.write(self._out_fd, (text + "\n").encode())
 
     def close(self):
         if self.dist is not None:

@@ -30,7 +30,7 @@ wall = g.max(time.perf_counter() - t0)
 total_px = g.sum(px)
 digest = g.sum64(checksum_of_checksums(crcs))
 if g.rank == 0:
-    print(json.dumps({"world": g.world, "mine": mine, "total_px": total_px, "digest": digest, "wall": wall}))
+    g.emit(json.dumps({"world": g.world, "mine": mine, "total_px": total_px, "digest": digest, "wall": wall}))
 g.close()
 '''
 
