@@ -3,23 +3,28 @@
  *
  * One launch reconstructs a BATCH of pictures (one job per picture, any mix of streams,
  * sizes and picture kinds).  One 256-thread workgroup = one tile = 256 consecutive 4x4
- * blocks of one plane; one lane = one 4x4 block, held as four packed dwords (4 samples per
- * dword).  Because intra prediction reads neighbour DC values from the descriptor map, not
+ * blocks of one plane (raster order); a block is four packed dwords (4 samples per dword).  Because intra prediction reads neighbour DC values from the descriptor map, not
  * neighbour pixels, every block of a picture is independent:
  * no intra-picture wavefront dependency exists and the whole batch is data-parallel.
  *
- * Integer/byte work, HBM-bound by design: no MFMA.  What matters here:
- *   - stores: lane i writes dword i of a 256-byte row segment -> every store instruction of a
- *     wave covers whole contiguous segments of the destination plane;
- *   - payload lookup: a block's payload length is a function of its type byte, so one
- *     workgroup prefix scan replaces per-block offsets (no offset traffic);
- *   - the 70x38 intra nest (2660 B) is staged once per workgroup in LDS and gathered from
- *     there (16 byte-gathers per basis);
- *   - sample arithmetic is SIMD-within-register: v_lerp_u8 for the 2-tap half-sample
- *     filters, 16-bit packed math for the weighted-DC predictor, v_sad_u8 for block sums;
- *   - reference pictures are addressed LINEARLY inside the Y|U|V buffer exactly like the
- *     reference's pointer arithmetic; every address is clamped to the
- *     picture slot so malformed vectors cannot fault the GPU.
+ * Integer/byte work, no dense contraction: no MFMA.  What matters here (measurements in DESIGN.md section 5):
+ *   - the tile is assembled in LDS and leaves as 16-byte row segments: every store instruction of a wave
+ *     writes four complete 256-byte runs, every output line reaches HBM once and whole;
+ *   - payload lookup: a block's payload length is a function of its type byte, so one 64-lane prefix scan
+ *     (DPP) replaces per-block offsets (no offset traffic);
+ *   - cheap block kinds are reconstructed by the lane that owns the block; AOT work is re-dealt so that one
+ *     lane handles one (block, basis) pair -- the cumulative coefficient sum is resolved by the host, which
+ *     makes bases independent -- and meets in LDS accumulators (ds_add);
+ *   - the 70x38 intra nest is staged per workgroup in LDS, nibble-packed: one unaligned ds_read_b64 per
+ *     basis row; MC-residual window rows are one unaligned 8-byte global load each;
+ *   - sample arithmetic is SIMD-within-register: v_lerp_u8 for the 2-tap half-sample filters, 16-bit packed
+ *     math for the weighted-DC predictor, v_sad_u8 for block sums, 24-bit multiplies for the AOT products;
+ *     the reference's divTable / mcdivTable lookups are a v_rcp_f32 estimate with an exact integer fix-up;
+ *   - reference pictures are addressed LINEARLY inside the Y|U|V buffer exactly like the reference's pointer
+ *     arithmetic; every address is clamped to the picture slot so malformed vectors cannot
+ *     fault the GPU.
+ * The limiter on vector-heavy streams is the number of distinct cache lines a CU's texture addresser can
+ * process (~0.43 per clock, tools/ubench/gather_rate.hip), not HBM bandwidth and not the ALUs.
  *
  * Reference behaviour restated per device function (h4m: = h4m_audio_decode.c).
  */
@@ -44,9 +49,6 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 #ifndef HVQ_ABL
 #define HVQ_ABL 0
 #endif
-
-/* divTable of h4m:265-273: 0x1000 / (i*16) * 16 */
-__device__ __constant__ uint16_t k_div16[16] = { 0, 4096, 2048, 1360, 1024, 816, 672, 576, 512, 448, 400, 368, 336, 304, 288, 272 };
 
 struct Blk { u32 r[4]; };
 
@@ -329,7 +331,6 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 }
 
 #define HVQ_NW (HVQ_WG / 64)
-#define HVQ_PAIR_CAP 1024            /* (block, basis) pairs handled basis-parallel per tile; beyond: serial fallback */
 
 /*
  * Workgroup = tile of 256 consecutive blocks of one plane.
@@ -523,7 +524,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
                 for (int i = 0; i < 16; ++i) r[i] = (u32)s_acc[i * items_cap + tid];
             }
         } else if (has_item) {
-            /* serial fallback for tiles with more than HVQ_PAIR_CAP bases (pathological streams) */
+            /* serial fallback for tiles whose queue exceeds the launch's LDS sizing (pathological streams) */
             i32 acc[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0;
