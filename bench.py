@@ -76,7 +76,8 @@ def main():
     # decode-order interleave: picture k of every stream, then k+1 ... (the order a player would submit).
     # This first pass is also the END-TO-END measurement: host entropy parse (thread pool) + descriptor upload
     # + all launches, from bitstreams in host memory to pictures in HBM.
-    threads = max(1, min(args.parse_threads or (os.cpu_count() or 1), 64))
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(args.parse_threads or allowed, 64))
     a_sid, a_ft, a_pic = [], [], []
     for k in range(n_pic):
         for s, sid in enumerate(sids):

@@ -314,46 +314,73 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
         if (per_stream[(size_t)streams[i]].empty()) units.push_back(streams[i]);
         per_stream[(size_t)streams[i]].push_back(i);
     }
-    std::vector<std::vector<uint8_t>> blobs((size_t)n);
+    /* workers parse into private growing buffers (no per-picture allocation), then copy their blobs into the
+     * pinned arena in parallel once the layout is known */
+    struct Piece { int worker; size_t off, len; };
+    std::vector<Piece> pieces((size_t)n, Piece{ -1, 0, 0 });
     std::vector<int> rcs((size_t)n, 0);
+    struct RawBuf {                       /* growing byte buffer without value-initialisation */
+        uint8_t *p = nullptr; size_t size = 0, cap = 0;
+        ~RawBuf() { free(p); }
+        bool ensure(size_t n) { if (n <= cap) return true; size_t nc = std::max(cap * 2, n); uint8_t *q = (uint8_t *)realloc(p, nc); if (!q) return false; p = q; cap = nc; return true; }
+    };
+    std::vector<RawBuf> wbuf((size_t)threads);
     std::atomic<size_t> next{ 0 };
     auto t0 = std::chrono::steady_clock::now();
-    auto worker = [&]() {
-        std::vector<uint8_t> scratch;
+    auto worker = [&](int wid) {
+        RawBuf &buf = wbuf[(size_t)wid];
         for (;;) {
             size_t u = next.fetch_add(1);
             if (u >= units.size()) break;
             Stream &s = c->streams[(size_t)units[u]];
-            size_t bound = hvq_parser_blob_bound(s.parser);
-            if (scratch.size() < bound + 16) scratch.resize(bound + 16);
-            uint8_t *buf = (uint8_t *)(((uintptr_t)scratch.data() + 15) & ~(uintptr_t)15);
+            const size_t bound = hvq_parser_blob_bound(s.parser);
             for (int i : per_stream[(size_t)units[u]]) {
+                if (!buf.ensure(buf.size + bound + 32)) { rcs[(size_t)i] = HVQ_E_OVERFLOW; break; }
+                const size_t at = (size_t)((((uintptr_t)buf.p + buf.size + 15) & ~(uintptr_t)15) - (uintptr_t)buf.p);
                 size_t blen = 0;
-                rcs[(size_t)i] = hvq_parse_picture(s.parser, frame_types[i], pics[i], lens[i], buf, bound, &blen);
-                if (rcs[(size_t)i]) break;              /* later pictures of the stream would decode against a wrong state */
-                blobs[(size_t)i].assign(buf, buf + blen);
+                rcs[(size_t)i] = hvq_parse_picture(s.parser, frame_types[i], pics[i], lens[i], buf.p + at, bound, &blen);
+                if (rcs[(size_t)i]) break;                 /* later pictures of the stream would see a wrong parser state */
+                pieces[(size_t)i] = Piece{ wid, at, blen };
+                buf.size = at + blen;
             }
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
-    worker();
-    for (auto &t : pool) t.join();
-    c->parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+        worker(0);
+        for (auto &t : pool) t.join();
+    }
     for (int i = 0; i < n; ++i)
-        if (rcs[(size_t)i] || blobs[(size_t)i].empty())
+        if (rcs[(size_t)i] || pieces[(size_t)i].worker < 0)
             return fail(rcs[(size_t)i] ? rcs[(size_t)i] : HVQ_E_STATE, "parse failed for picture %d (stream %d)", i, streams[i]);
     size_t need = 0;
-    for (auto &b : blobs) need += align_up(b.size(), 256);
+    std::vector<size_t> offs((size_t)n);
+    for (int i = 0; i < n; ++i) { offs[(size_t)i] = need; need += align_up(pieces[(size_t)i].len, 256); }
     int rc = arena_reserve(c, need);
     if (rc) return rc;
+    const size_t base = c->arena_used;
+    {
+        std::atomic<int> nexti{ 0 };
+        auto copier = [&]() {
+            for (;;) {
+                int i = nexti.fetch_add(1);
+                if (i >= n) break;
+                const Piece &pc = pieces[(size_t)i];
+                memcpy(c->host_arena + base + offs[(size_t)i], wbuf[(size_t)pc.worker].p + pc.off, pc.len);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(copier);
+        copier();
+        for (auto &t : pool) t.join();
+    }
+    c->parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (int i = 0; i < n; ++i) {
-        size_t off = c->arena_used;
-        memcpy(c->host_arena + off, blobs[(size_t)i].data(), blobs[(size_t)i].size());
-        c->arena_used = off + align_up(blobs[(size_t)i].size(), 256);
-        int ord = enqueue_picture(c, streams[i], frame_types[i], off, blobs[(size_t)i].size());
+        int ord = enqueue_picture(c, streams[i], frame_types[i], base + offs[(size_t)i], pieces[(size_t)i].len);
         if (ordinals) ordinals[i] = ord;
     }
+    c->arena_used = base + need;
     return HVQ_OK;
 }
 
