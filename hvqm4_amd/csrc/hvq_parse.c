@@ -31,18 +31,27 @@ typedef struct {
 static inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 static inline uint32_t be16(const uint8_t *p) { return ((uint32_t)p[0] << 8) | p[1]; }
 
+/* Top up the reservoir to >= 56 valid bits.  Fast path: one unaligned big-endian 64-bit load OR-ed below the valid
+ * bits; only whole bytes are accounted, the few extra bits that come along are the stream's own next bits and are
+ * OR-ed again (idempotent) by the next refill.  Within 8 bytes of the end: byte-wise with zero fill. */
 static inline void br_refill(BitRd *b)
 {
-    if (b->cnt <= 32) {
-        uint32_t w;
-        if (b->p + 4 <= b->end) w = be32(b->p);
-        else {
-            w = 0;
-            for (int i = 0; i < 4; ++i) w = (w << 8) | (b->p + i < b->end ? b->p[i] : 0u);
+    if (b->cnt > 32) return;
+    if (__builtin_expect(b->p + 8 <= b->end, 1)) {
+        uint64_t w;
+        memcpy(&w, b->p, 8);
+        w = __builtin_bswap64(w);
+        b->acc |= w >> b->cnt;
+        const int adv = (63 - b->cnt) >> 3;
+        b->p += adv;
+        b->cnt += adv * 8;
+    } else {
+        while (b->cnt <= 56) {
+            const uint64_t byte = b->p < b->end ? *b->p : 0u;
+            b->acc |= byte << (56 - b->cnt);
+            b->p++;
+            b->cnt += 8;
         }
-        b->acc |= (uint64_t)w << (32 - b->cnt);
-        b->p += 4;
-        b->cnt += 32;
     }
 }
 
@@ -136,6 +145,7 @@ typedef struct {
     int hb, vb, stride;          /* blocks; map row length incl. border */
     int bx_per, by_per, nblk;    /* blocks of this plane per macroblock */
     int moff[4];                 /* block offsets inside a macroblock, order TL, BL, BR, TR (h4m:447-455, 862-865) */
+    int dx[4], dy[4];            /* the same as block coordinates */
     uint32_t nblocks, ntiles;
 } PPlane;
 
@@ -159,10 +169,14 @@ struct HvqParser {
 
 #define ALIGN16(x) (((x) + 15u) & ~15u)
 
+static int g_type_info_ready;
+static void build_type_info(void);
+
 HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int is15)
 {
     if (width < 8 || height < 8 || (width & 7) || (height & 7) || width > 8192 || height > 8192) return NULL;
     if (!((h_samp == 2 && v_samp == 2) || (h_samp == 1 && v_samp == 1))) return NULL;
+    if (!g_type_info_ready) build_type_info();        /* idempotent; identical content from any thread */
     HvqParser *p = calloc(1, sizeof *p);
     if (!p) return NULL;
     p->w = width; p->h = height; p->is15 = is15 != 0;
@@ -178,6 +192,7 @@ HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int 
         q->stride = q->hb + 2;
         q->bx_per = 2 >> ws; q->by_per = 2 >> hs; q->nblk = q->bx_per * q->by_per;
         q->moff[0] = 0; q->moff[1] = q->stride; q->moff[2] = q->stride + 1; q->moff[3] = 1;
+        q->dx[0] = 0; q->dy[0] = 0; q->dx[1] = 0; q->dy[1] = 1; q->dx[2] = 1; q->dy[2] = 1; q->dx[3] = 1; q->dy[3] = 0;
         q->nblocks = (uint32_t)q->hb * q->vb;
         q->ntiles = (q->nblocks + HVQ_TILE_BLOCKS - 1) / HVQ_TILE_BLOCKS;
         p->total_tiles += q->ntiles;
@@ -289,42 +304,66 @@ static void init_maps(const HvqParser *p, uint8_t *blob)                        
     }
 }
 
+/* per type byte: payload dwords (hvq_payload_dwords), whether the kernel queues the block, its basis count and the
+ * header flags it raises -- one table per context: [0] I luma, [1] I chroma, [2] P/B */
+typedef struct { uint8_t n, item, pairs, flags; } TypeInfo;
+static TypeInfo g_type_info[3][256];
+
+static void build_type_info(void)
+{
+    for (int ctx = 0; ctx < 3; ++ctx)
+        for (uint32_t t = 0; t < 256; ++t) {
+            const int is_pb = ctx == 2, il = ctx == 0;
+            const uint32_t n = hvq_payload_dwords(t, is_pb, il);
+            const int inter = is_pb && (t & 0x60u);
+            const uint32_t kind = il ? t : (t & 0xFu);
+            TypeInfo ti = { (uint8_t)n, 0, 0, 0 };
+            if (n && kind != 6) {                         /* queued by the kernel: intra AOT or MC residual */
+                ti.item = 1;
+                ti.pairs = (uint8_t)(inter ? kind - 1 : kind);
+                if (!inter) ti.flags = (uint8_t)(HVQ_F_HAS_NEST | (kind > 15 ? HVQ_F_BIG_AOT : 0));
+            }
+            g_type_info[ctx][t] = ti;
+        }
+    g_type_info_ready = 1;
+}
+
 /* raster scan of the type maps: per-block pool offsets, per-64-block bases, flags; returns pool dwords */
 static uint32_t layout_pool(HvqParser *p, uint8_t *blob, int is_pb)
 {
     uint32_t *wave_base = (uint32_t *)(blob + p->wave_base_off);
-    uint32_t off = 0, wv = 0;
+    uint32_t off = 0, wv = 0, flags = 0;
     p->max_items = 0; p->max_pairs = 0;
     for (int i = 0; i < 3; ++i) {
         const PPlane *q = &p->pl[i];
+        const TypeInfo *info = g_type_info[is_pb ? 2 : (i == 0 ? 0 : 1)];
+        uint32_t *blk_off = p->blk_off[i];
         uint32_t b = 0, items = 0, pairs = 0;
         for (int by = 0; by < q->vb; ++by) {
             const uint8_t *row = map_ent(p, blob, i, by, 0);
             for (int bx = 0; bx < q->hb; ++bx, ++b) {
-                if ((b & 63u) == 0) wave_base[wv++] = off;
-                if ((b % HVQ_TILE_BLOCKS) == 0) items = pairs = 0;
-                uint32_t t = row[2 * bx + 1];
-                p->blk_off[i][b] = off;
-                uint32_t n = hvq_payload_dwords(t, is_pb, !is_pb && i == 0);
-                if (n) {
-                    int inter = is_pb && (t & 0x60u);
-                    uint32_t kind = (!is_pb && i == 0) ? t : (t & 0xFu);
-                    if (!inter && kind != 6) {
-                        p->flags |= HVQ_F_HAS_NEST;
-                        if (kind > 15) p->flags |= HVQ_F_BIG_AOT;
-                    }
-                    if (kind != 6) {                      /* queued by the kernel: intra AOT or MC residual */
-                        items += 1; pairs += inter ? kind - 1 : kind;
+                if ((b & 63u) == 0) {
+                    wave_base[wv++] = off;
+                    if ((b % HVQ_TILE_BLOCKS) == 0) {
                         if (items > p->max_items) p->max_items = items;
                         if (pairs > p->max_pairs) p->max_pairs = pairs;
+                        items = pairs = 0;
                     }
                 }
-                off += n;
+                const TypeInfo ti = info[row[2 * bx + 1]];
+                blk_off[b] = off;
+                off += ti.n;
+                items += ti.item;
+                pairs += ti.pairs;
+                flags |= ti.flags;
             }
         }
+        if (items > p->max_items) p->max_items = items;
+        if (pairs > p->max_pairs) p->max_pairs = pairs;
         /* the last tile of a plane may be ragged: its unused runs point at the plane's end */
         while (wv % (HVQ_TILE_BLOCKS / 64)) wave_base[wv++] = off;
     }
+    p->flags |= flags;
     return off;
 }
 
@@ -626,7 +665,7 @@ static int parse_pbpic(HvqParser *p, int is_P, const uint8_t *pic, uint8_t *blob
                     for (int j = 0; j < q->nblk; ++j) {
                         uint32_t k = e[2 * q->moff[j] + 1] & 0xFu;
                         if (k == 0 || k == 8) continue;
-                        uint32_t b = (uint32_t)(by0 + (q->moff[j] >= q->stride)) * q->hb + (uint32_t)(bx0 + (q->moff[j] % q->stride));
+                        uint32_t b = (uint32_t)(by0 + q->dy[j]) * q->hb + (uint32_t)(bx0 + q->dx[j]);
                         uint32_t *dst = pool + p->blk_off[i][b];
                         if (k == 6) fx_literal(p, i, dst);
                         else emit_bases(p, i, k, dst);
@@ -648,7 +687,7 @@ static int parse_pbpic(HvqParser *p, int is_P, const uint8_t *pic, uint8_t *blob
                 for (int j = 0; j < q->nblk; ++j) {
                     uint32_t k = e[2 * q->moff[j] + 1] & 0xFu;
                     if (k == 0) continue;
-                    uint32_t b = (uint32_t)(by0 + (q->moff[j] >= q->stride)) * q->hb + (uint32_t)(bx0 + (q->moff[j] % q->stride));
+                    uint32_t b = (uint32_t)(by0 + q->dy[j]) * q->hb + (uint32_t)(bx0 + q->dx[j]);
                     uint32_t *dst = pool + p->blk_off[i][b];
                     if (k == 6) { fx_literal(p, i, dst); continue; }
                     emit_bases(p, i, k - 1, dst + 2);
