@@ -1,0 +1,113 @@
+"""CPU: the GPU parse core (hvqm4_amd/csrc/hvq_gparse_core.h), run phase by phase on the CPU by
+tests/native/gparse_emul.c, must produce the host parser's descriptor blobs byte for byte: same maps, motion
+vectors, run bases, pool, header; the nest it writes aside must be the one the host parser embeds."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import clips
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "native", "gparse_emul.c")
+OUT = os.path.join(HERE, "native", "_build", "libgparse_emul.so")
+NESTP = (70 * 38 // 2 + 14 + 15) & ~15
+
+HDR = struct.Struct("<II HH BBBBB3x I 3H3H 3I I 3I I I I I I 4I II H2x I 3I")
+# magic total | w h | kind unk dc ws hs | flags | hb vb | plane_off | pic_bytes | map_off | mv | wave | pool | pool_dw | nest | tile_first | mcb | max_items | max_pairs
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("flags", C.c_uint32), ("max_items", C.c_uint32), ("max_pairs", C.c_uint32),
+                ("pool_dwords", C.c_uint32), ("total_bytes", C.c_uint32), ("pad", C.c_uint32 * 2)]
+
+
+@pytest.fixture(scope="module")
+def emul():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    deps = [SRC] + [os.path.join(HERE, "..", "hvqm4_amd", "csrc", f) for f in ("hvq_gparse_core.h", "hvq_desc.h")]
+    if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
+        subprocess.run(["gcc", "-O2", "-Wall", "-shared", "-fPIC", SRC, "-o", OUT], check=True)
+    lib = C.CDLL(OUT)
+    lib.gparse_emul.restype = C.c_int
+    lib.gparse_emul.argtypes = [C.c_char_p, C.c_uint32] + [C.c_int] * 6 + [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Result)]
+    return lib
+
+
+def header(blob):
+    f = HDR.unpack_from(blob, 0)
+    names = ["magic", "total", "w", "h", "kind", "unk", "dc", "ws", "hs", "flags"]
+    d = dict(zip(names, f[:10]))
+    d["hb"], d["vb"], d["plane_off"] = f[10:13], f[13:16], f[16:19]
+    d["pic_bytes"] = f[19]
+    d["map_off"] = f[20:23]
+    d["mv_off"], d["wave_off"], d["pool_off"], d["pool_dwords"], d["nest_off"] = f[23:28]
+    d["tile_first"] = f[28:32]
+    d["mcb_w"], d["mcb_h"], d["max_items"], d["max_pairs"] = f[32:36]
+    return d
+
+
+def compare_clip(emul, clip):
+    from hvqm4_amd._lib import lib
+    l = lib()
+    is15 = 1 if clip.version == "1.5" else 0
+    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp, clip.samp, is15)
+    assert prs
+    bound = l.hvq_parser_blob_bound(prs)
+    a = np.zeros(bound, dtype=np.uint8)
+    b = np.zeros(bound, dtype=np.uint8)
+    nest = np.zeros(NESTP, dtype=np.uint8)
+    last_nest = np.zeros(NESTP, dtype=np.uint8)
+    for idx, (ft, pic) in enumerate(zip(clip.kinds, clip.pictures)):
+        n = C.c_size_t(0)
+        assert l.hvq_parse_picture(prs, ft, pic + b"\0" * 8, len(pic), a.ctypes.data, bound, C.byref(n)) == 0
+        b[:] = 0xEE
+        res = Result()
+        assert emul.gparse_emul(pic, len(pic), ft, clip.width, clip.height, clip.samp, clip.samp, is15,
+                                b.ctypes.data, bound, nest.ctypes.data, C.byref(res)) == 0
+        assert res.status == 0, (idx, res.status)
+        ha, hb = header(a.tobytes()), header(b.tobytes())
+        where = f"picture {idx} type {ft:#x}"
+        for k in ha:
+            if k in ("total", "nest_off"):
+                continue
+            assert ha[k] == hb[k], (where, k, ha[k], hb[k])
+        assert res.flags == ha["flags"] and res.max_items == ha["max_items"] and res.max_pairs == ha["max_pairs"], where
+        assert res.pool_dwords == ha["pool_dwords"], where
+        for i in range(3):
+            nmap = 2 * (ha["hb"][i] + 2) * (ha["vb"][i] + 2)
+            o = ha["map_off"][i]
+            assert np.array_equal(a[o:o + nmap], b[o:o + nmap]), (where, "map", i)
+        if ft != 0x10:
+            o, nmv = ha["mv_off"], 4 * ha["mcb_w"] * ha["mcb_h"]
+            assert np.array_equal(a[o:o + nmv], b[o:o + nmv]), (where, "mv")
+        o, nw = ha["wave_off"], 4 * ha["tile_first"][3] * 4
+        assert np.array_equal(a[o:o + nw], b[o:o + nw]), (where, "wave_base")
+        o, npool = ha["pool_off"], 4 * ha["pool_dwords"]
+        assert np.array_equal(a[o:o + npool], b[o:o + npool]), (where, "pool")
+        if ft == 0x10:
+            last_nest = nest.copy()
+        if ha["nest_off"]:
+            o = ha["nest_off"]
+            assert np.array_equal(a[o:o + NESTP], last_nest), (where, "nest")
+    l.hvq_parser_destroy(prs)
+
+
+@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM, ids=lambda c: c[0])
+def test_gpu_parse_core_matches_host_parser(emul, case):
+    compare_clip(emul, clips.get(case))
+
+
+def test_gpu_parse_core_random_geometries(emul):
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    rng = np.random.default_rng(99)
+    for _ in range(40):
+        cfg = SynthConfig(width=int(rng.integers(1, 30)) * 8, height=int(rng.integers(1, 24)) * 8,
+                          version=str(rng.choice(["1.3", "1.5"])), gop=str(rng.choice(["IPB", "IPBBPBB", "IPPP"])),
+                          seed=int(rng.integers(0, 1 << 30)), preset=str(rng.choice(["dense", "realistic", "flat", "natural"])),
+                          sampling=str(rng.choice(["420", "444"])), weird_kinds=bool(rng.random() < 0.3),
+                          runoff_prob=float(rng.choice([0.0, 0.3])))
+        compare_clip(emul, make_clip(cfg))

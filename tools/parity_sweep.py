@@ -1,0 +1,71 @@
+"""GPU box: randomized parity sweep -- many synthetic clips (geometry, version, sampling, preset, GOP, shifts, ring
+size drawn from a seed) through the batched C-ABI path vs the CPU oracle, bit-exact.  Test infrastructure
+(uses oracle/); usage: python tools/parity_sweep.py [n_clips] [seed]."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+from hvqm4_amd import batch  # noqa: E402
+from hvqm4_amd.synth import SynthConfig, make_clip  # noqa: E402
+from oracle import bridge  # noqa: E402
+
+GOPS = ["I", "IP", "IPB", "IPBB", "IPBBPBB", "IPPPP", "IPBBPBBPBB"]
+
+
+def draw(rng) -> SynthConfig:
+    return SynthConfig(
+        width=int(rng.integers(1, 42)) * 8, height=int(rng.integers(1, 32)) * 8,
+        version=str(rng.choice(["1.3", "1.5"])), gop=str(rng.choice(GOPS)), n_gops=int(rng.integers(1, 3)),
+        seed=int(rng.integers(0, 1 << 30)), preset=str(rng.choice(["dense", "realistic", "flat", "natural"])),
+        sampling=str(rng.choice(["420", "420", "444"])), runoff_prob=float(rng.choice([0.0, 0.05, 0.4])),
+        weird_kinds=bool(rng.random() < 0.3),
+        dc_shifts=tuple(int(x) for x in rng.choice([0, 1, 2], 2)),
+        unk_shifts=tuple(int(x) for x in rng.choice([6, 7, 8, 9], 2)),
+        mv_res_bits=tuple(int(x) for x in rng.choice([0, 1, 2], 2)))
+
+
+def decode_last(ctx, data, nslots):
+    from hvqm4_amd.container import parse_header, video_pictures
+    hdr = parse_header(data)
+    sid = ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, nslots)
+    last = -1
+    for ft, _disp, pic in video_pictures(data):
+        last = ctx.submit(sid, ft, pic)
+    ctx.flush()
+    out = ctx.read_picture(sid, last)
+    ctx.close_stream(sid)
+    return out
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    ctx = batch.Context(0)
+    bad = pics = 0
+    t0 = time.time()
+    for i in range(n):
+        cfg = draw(rng)
+        clip = make_clip(cfg)
+        want = bridge.oracle_decode(clip.data, clip.n_pictures)
+        nslots = [None, 3, 4, 6][int(rng.integers(0, 4))]      # None: every picture stays resident
+        if nslots is None:
+            got = batch.decode_clip(ctx, clip.data)
+            ok = np.array_equal(got, want)
+        else:                                                  # small ring: only the last picture is guaranteed resident
+            got = decode_last(ctx, clip.data, nslots)
+            ok = np.array_equal(got, want[-1])
+        pics += clip.n_pictures
+        if not ok:
+            bad += 1
+            print("MISMATCH", nslots, cfg, flush=True)
+        if (i + 1) % 50 == 0:
+            print(f"{i + 1} clips, {pics} pictures, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    ctx.close()
+    print(f"sweep done: {n} clips, {pics} pictures, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
