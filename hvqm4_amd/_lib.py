@@ -58,7 +58,8 @@ class HvqH4mIter(C.Structure):
 class HvqStats(C.Structure):
     _fields_ = [("pictures", C.c_uint64), ("luma_pixels", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("descriptor_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32),
-                ("parse_seconds", C.c_double), ("flags_or", C.c_uint32)]
+                ("parse_seconds", C.c_double), ("flags_or", C.c_uint32), ("gpu_parsed", C.c_uint32),
+                ("gpu_parse_ms", C.c_double)]
 
 
 # every symbol include/hvqm4.h and include/hvqm4_amd.h declare: (restype, argtypes)
@@ -81,6 +82,8 @@ SYMBOLS = {
     "hvq_stream_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "hvq_submit_many": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p),
                                   C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)]),
+    "hvq_submit_many_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p),
+                                         C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "hvq_flush": (C.c_int, [C.c_void_p]),
     "hvq_sync": (C.c_int, [C.c_void_p]),
     "hvq_replay": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),

@@ -35,6 +35,17 @@ class Context:
         check(lib().hvq_submit_many(self._h, n, a_s, a_t, a_p, a_l, threads, a_o))
         return list(a_o)
 
+    def submit_many_device(self, sids, frame_types, pictures):
+        """queue raw bitstreams; flush() parses them on the GPU (no host entropy parse at all)"""
+        n = len(pictures)
+        a_s = (C.c_int * n)(*sids)
+        a_t = (C.c_int * n)(*frame_types)
+        a_p = (C.c_char_p * n)(*pictures)
+        a_l = (C.c_size_t * n)(*[len(p) for p in pictures])
+        a_o = (C.c_int * n)()
+        check(lib().hvq_submit_many_device(self._h, n, a_s, a_t, a_p, a_l, a_o))
+        return list(a_o)
+
     def flush(self) -> None:
         check(lib().hvq_flush(self._h))
 
@@ -83,16 +94,24 @@ class Context:
             pass
 
 
-def decode_clip(ctx: Context, data: bytes, nslots: Optional[int] = None) -> np.ndarray:
-    """Decode a whole .h4m through the batched path; returns uint8[n_pictures, pic_bytes] (decode order)."""
+def decode_clip(ctx: Context, data: bytes, nslots: Optional[int] = None, gpu_parse: bool = False,
+                flush_every: Optional[int] = None) -> np.ndarray:
+    """Decode a whole .h4m through the batched path; returns uint8[n_pictures, pic_bytes] (decode order).
+    gpu_parse: entropy-parse on the GPU (hvq_submit_many_device); flush_every: flush after that many pictures."""
     from .container import parse_header, video_pictures
     hdr = parse_header(data)
     pics = list(video_pictures(data))
     sid = ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15,
                           nslots if nslots is not None else len(pics) + 3)
-    for ft, _disp, pic in pics:
-        ctx.submit(sid, ft, pic)
-    ctx.flush()
+    step = flush_every or len(pics)
+    for at in range(0, len(pics), step):
+        part = pics[at:at + step]
+        if gpu_parse:
+            ctx.submit_many_device([sid] * len(part), [ft for ft, _d, _p in part], [bytes(p) for _f, _d, p in part])
+        else:
+            for ft, _disp, pic in part:
+                ctx.submit(sid, ft, pic)
+        ctx.flush()
     out = np.stack([ctx.read_picture(sid, i) for i in range(len(pics))])
     ctx.close_stream(sid)
     return out

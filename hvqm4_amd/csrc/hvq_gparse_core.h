@@ -29,7 +29,7 @@
 #include "hvq_desc.h"
 
 #if defined(__HIPCC__)
-#define GP_FN __device__ static inline
+#define GP_FN __host__ __device__ static inline
 #else
 #define GP_FN static inline
 #endif
@@ -131,8 +131,10 @@ GP_FN void gc_read(GCode *c, GBits *carrier, int is_signed, int scale, uint32_t 
             c->leaf[byte] = (int16_t)((uint32_t)v << scale);          /* int16 truncation: h4m:613-617 */
             val = byte;
         } else {
-            const int id = next < 511 ? next++ : 511;
-            if (sp >= 256) { *status |= GP_ST_BADTREE; c->root = 0; return; }
+            /* a tree over 256 leaf bytes has at most 255 inner nodes (ids 256..510) and so nests at most 255 deep;
+             * anything more is malformed, and would let node 511 become its own child (an endless walk in gsym) */
+            if (next >= 511 || sp >= 256) { *status |= GP_ST_BADTREE; c->root = 0; return; }
+            const int id = next++;
             stk[sp++] = (uint16_t)id;
             continue;
         }

@@ -82,7 +82,10 @@ static int code_node(Code *c, BitRd *b, int is_signed, int scale, int depth)
         c->leaf[byte] = (int16_t)((uint32_t)v << scale);          /* int16 truncation: h4m:613-617 */
         return byte;
     }
-    int id = c->next < 511 ? c->next++ : 511;
+    /* more than 255 inner nodes cannot come from 256 leaf bytes: malformed; stop before node 511 can become its
+     * own child (an endless walk in sym) */
+    if (c->next >= 511) return 0;
+    int id = c->next++;
     c->kid[0][id] = (int16_t)code_node(c, b, is_signed, scale, depth + 1);
     c->kid[1][id] = (int16_t)code_node(c, b, is_signed, scale, depth + 1);
     return id;
@@ -396,6 +399,13 @@ static void fill_header(const HvqParser *p, uint8_t *blob, int kind, uint32_t po
     h->nest_off = (p->flags & HVQ_F_HAS_NEST) ? ALIGN16(p->fixed_bytes + 4u * pool_dwords) : 0;
     h->mcb_w = (uint32_t)p->w / 8; h->mcb_h = (uint32_t)p->h / 8;
     h->max_items = (uint16_t)p->max_items; h->max_pairs = p->max_pairs;
+}
+
+void hvq_parser_layout(const HvqParser *p, HvqPicHeader *out)
+{
+    HvqParser q = *p;
+    q.flags = 0; q.unk_shift = 0; q.dc_shift = 0; q.max_items = 0; q.max_pairs = 0;
+    fill_header(&q, (uint8_t *)out, HVQ_PIC_P, 0, 0);
 }
 
 /* nest values are 4 bits (h4m:1211): two per byte, value n in nibble n -- what the kernel stages in LDS */

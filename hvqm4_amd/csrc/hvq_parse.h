@@ -38,6 +38,9 @@ void hvq_parser_destroy(HvqParser *p);
 size_t hvq_parser_blob_bound(const HvqParser *p);
 uint32_t hvq_parser_pic_bytes(const HvqParser *p);
 
+/* geometry part of the blob header (everything but the per-picture fields): the layout any blob of this parser has */
+void hvq_parser_layout(const HvqParser *p, HvqPicHeader *out);
+
 /*
  * Parse one picture.  `frame_type` is the container id 0x10 I / 0x20 P / 0x30 B
  * (h4m:2065-2070); `pic` points at the picture data (after the 4-byte disp_id); `len` is the

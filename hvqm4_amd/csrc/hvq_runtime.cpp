@@ -32,6 +32,12 @@
 #include "../../include/hvqm4_amd.h"
 #include "hvq_desc.h"
 #include "hvq_parse.h"
+#include "hvq_gparse_core.h"
+
+extern "C" hipError_t hvq_launch_parse(const HvqParseJob *jobs_dev, HvqParseResult *results_dev, uint32_t n,
+                                       uint32_t rowbuf_stride, hipStream_t stream);
+extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t n, hipStream_t stream);
+extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
 
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
                                        uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
@@ -83,6 +89,15 @@ struct Stream {
     int ring = 0;
     int npics = 0;
     std::vector<int> pic_slot;
+    /* GPU entropy parse (hvq_submit_many_device): the stream's pictures never meet the host parser */
+    int parse_mode = 0;                      /* 0 undecided, 1 host parser, 2 device parser */
+    HvqPicHeader layout{};                   /* geometry part of every blob of this stream */
+    uint32_t blob_cap = 0, scratch_bytes = 0;
+    uint8_t *nest_keep = nullptr;            /* two slots: [nest_cur] = packed nest of the last I picture of earlier
+                                                batches (zero before any); a flush commits into the other slot */
+    int nest_cur = 0;
+    uint8_t *nest_keep_ptr(int which) const { return nest_keep + (size_t)which * GP_ALIGN16(HVQ_NESTP_BYTES); }
+    int nest_src = -1;                       /* pending index of the last I picture queued in this batch, -1: nest_keep */
     uint8_t *slot_ptr(int s) const { return dev + (size_t)(s < 0 ? (int)slots.size() : s) * slot_bytes; }
 };
 
@@ -93,6 +108,11 @@ struct Pending {
     int dst, ref0, ref1;
     uint32_t ntiles, kind;
     uint32_t w, h;
+    /* device-parsed pictures: raw bitstream in the arena instead of a blob */
+    bool dev = false;
+    int nest_ref = -1;                 /* pending index of the governing I picture, -1: the stream's nest_keep */
+    uint64_t dev_blob = 0, dev_nest = 0;
+    uint32_t flags = 0, unk_shift = 0;
 };
 
 struct Launch {
@@ -121,6 +141,14 @@ struct HvqContext {
     size_t rgb_cap = 0;
     RgbJob *rgb_jobs_dev = nullptr;
     size_t rgb_jobs_cap = 0;
+    /* GPU entropy parse: blobs + scratch + nests of the batch, job and result tables */
+    uint8_t *gp_dev = nullptr;
+    size_t gp_cap = 0;
+    HvqParseJob *pj_dev = nullptr;
+    HvqParseResult *pr_dev = nullptr;
+    uint64_t *np_dev = nullptr;
+    size_t pj_cap = 0;
+    double gpu_parse_ms = 0;           /* device time of the parse kernel of the last flush */
 };
 
 static int arena_reserve(HvqContext *c, size_t need)
@@ -171,7 +199,12 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     for (auto &s : c->streams) {
         if (s.parser) hvq_parser_destroy(s.parser);
         if (s.dev) (void)hipFree(s.dev);
+        if (s.nest_keep) (void)hipFree(s.nest_keep);
     }
+    if (c->gp_dev) (void)hipFree(c->gp_dev);
+    if (c->pj_dev) (void)hipFree(c->pj_dev);
+    if (c->pr_dev) (void)hipFree(c->pr_dev);
+    if (c->np_dev) (void)hipFree(c->np_dev);
     if (c->host_arena) (void)hipHostFree(c->host_arena);
     if (c->dev_arena) (void)hipFree(c->dev_arena);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
@@ -218,6 +251,7 @@ HVQ_EXPORT int hvq_stream_close(HvqContext *c, int sid)
     Stream &s = c->streams[sid];
     hvq_parser_destroy(s.parser); s.parser = nullptr;
     HIPCHK(hipFree(s.dev)); s.dev = nullptr;
+    if (s.nest_keep) { HIPCHK(hipFree(s.nest_keep)); s.nest_keep = nullptr; }
     c->launches.clear();               /* the resident batch may reference the freed slots: no replay after a close */
     s.open = false;
     return HVQ_OK;
@@ -239,16 +273,11 @@ static int alloc_slot(Stream &s)
     return -1;
 }
 
-/* queue one parsed picture (blob already in the host arena at `off`): slot assignment == picture rotation of
- * h4m:2087-2093 / 2131-2137, then the dependency level */
-static int enqueue_picture(HvqContext *c, int sid, int frame_type, size_t off, size_t blen)
+/* queue one picture: slot assignment == picture rotation of h4m:2087-2093 / 2131-2137, then the dependency level */
+static int enqueue_common(HvqContext *c, int sid, int frame_type, Pending q)
 {
     Stream &s = c->streams[(size_t)sid];
-    Pending q{};
-    q.stream = sid; q.ordinal = s.npics; q.blob_off = off; q.blob_len = blen;
-    const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + off);
-    q.ntiles = hd->tile_first[3]; q.kind = hd->pic_kind; q.w = hd->width; q.h = hd->height;
-    q.max_items = hd->max_items; q.max_pairs = hd->max_pairs;
+    q.stream = sid; q.ordinal = s.npics;
     if (frame_type != HVQ_FRAME_B) std::swap(s.anchor_old, s.anchor_new);   /* past <-> future */
     q.dst = alloc_slot(s);
     if (frame_type == HVQ_FRAME_I) { q.ref0 = -1; q.ref1 = -1; }
@@ -269,6 +298,17 @@ static int enqueue_picture(HvqContext *c, int sid, int frame_type, size_t off, s
     return s.npics++;
 }
 
+/* host-parsed picture: blob already in the host arena at `off` */
+static int enqueue_picture(HvqContext *c, int sid, int frame_type, size_t off, size_t blen)
+{
+    Pending q{};
+    q.blob_off = off; q.blob_len = blen;
+    const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + off);
+    q.ntiles = hd->tile_first[3]; q.kind = hd->pic_kind; q.w = hd->width; q.h = hd->height;
+    q.max_items = hd->max_items; q.max_pairs = hd->max_pairs;
+    return enqueue_common(c, sid, frame_type, q);
+}
+
 static int check_submit_args(HvqContext *c, int sid, int frame_type, const uint8_t *pic, size_t len)
 {
     if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
@@ -284,6 +324,8 @@ HVQ_EXPORT int hvq_stream_submit(HvqContext *c, int sid, int frame_type, const u
     if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
     Stream &s = c->streams[sid];
+    if (s.parse_mode == 2) return fail(HVQ_E_STATE, "stream %d is parsed on the GPU; use hvq_submit_many_device", sid);
+    s.parse_mode = 1;
     size_t bound = align_up(hvq_parser_blob_bound(s.parser), 256);
     rc = arena_reserve(c, bound);
     if (rc) return rc;
@@ -305,6 +347,11 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
         if (rc) return rc;
     }
     if (n == 0) return HVQ_OK;
+    for (int i = 0; i < n; ++i) {
+        Stream &s = c->streams[(size_t)streams[i]];
+        if (s.parse_mode == 2) return fail(HVQ_E_STATE, "stream %d is parsed on the GPU; use hvq_submit_many_device", streams[i]);
+        s.parse_mode = 1;
+    }
     HIPCHK(hipSetDevice(c->device));
     threads = std::max(1, std::min(threads, 256));
     /* work units = streams (a parser is stateful); unit u gets its pictures in array order */
@@ -384,6 +431,129 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
     return HVQ_OK;
 }
 
+/* GPU entropy parse: queue the raw bitstreams; hvq_flush parses them on the device (hvq_gparse.hip) */
+HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, const int *frame_types,
+                                      const uint8_t *const *pics, const size_t *lens, int *ordinals)
+{
+    if (!c || n < 0 || !streams || !frame_types || !pics || !lens) return fail(HVQ_E_ARG, "bad arguments");
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) {
+        int rc = check_submit_args(c, streams[i], frame_types[i], pics[i], lens[i]);
+        if (rc) return rc;
+        if (lens[i] > 0x7FFFFFF0u) return fail(HVQ_E_ARG, "picture %d: the GPU parser needs the real picture length", i);
+        if (c->streams[(size_t)streams[i]].parse_mode == 1)
+            return fail(HVQ_E_STATE, "stream %d is parsed on the host; a stream keeps one parser for its lifetime", streams[i]);
+        need += align_up(lens[i] + 16, 256);
+    }
+    if (n == 0) return HVQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = arena_reserve(c, need);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        Stream &s = c->streams[(size_t)streams[i]];
+        if (s.parse_mode == 0) {
+            s.parse_mode = 2;
+            hvq_parser_layout(s.parser, &s.layout);
+            s.blob_cap = (uint32_t)align_up(hvq_parser_blob_bound(s.parser), 256);
+            uint32_t blocks = 0;
+            for (int k = 0; k < 3; ++k) blocks += (uint32_t)s.layout.hb[k] * s.layout.vb[k];
+            s.scratch_bytes = (uint32_t)align_up(hvq_gparse_scratch_bytes(blocks, s.layout.tile_first[3] * (HVQ_TILE_BLOCKS / 64),
+                                                                          s.layout.mcb_w * s.layout.mcb_h), 256);
+            HIPCHK(hipMalloc((void **)&s.nest_keep, 2 * GP_ALIGN16(HVQ_NESTP_BYTES)));
+            HIPCHK(hipMemsetAsync(s.nest_keep, 0, 2 * GP_ALIGN16(HVQ_NESTP_BYTES), c->stream));
+        }
+        const size_t off = c->arena_used, span = align_up(lens[i] + 16, 256);
+        memcpy(c->host_arena + off, pics[i], lens[i]);
+        memset(c->host_arena + off + lens[i], 0, span - lens[i]);       /* the device reader sees zeros past the end */
+        c->arena_used = off + span;
+        Pending q{};
+        q.dev = true;
+        q.blob_off = off; q.blob_len = lens[i];
+        q.ntiles = s.layout.tile_first[3];
+        q.kind = frame_types[i] == HVQ_FRAME_I ? HVQ_PIC_I : (frame_types[i] == HVQ_FRAME_P ? HVQ_PIC_P : HVQ_PIC_B);
+        q.w = s.layout.width; q.h = s.layout.height;
+        q.unk_shift = pics[i][1];
+        q.nest_ref = s.nest_src;
+        const int ord = enqueue_common(c, streams[i], frame_types[i], q);
+        if (frame_types[i] == HVQ_FRAME_I) {
+            s.nest_src = (int)c->pending.size() - 1;
+            c->pending.back().nest_ref = s.nest_src;
+        }
+        if (ordinals) ordinals[i] = ord;
+    }
+    return HVQ_OK;
+}
+
+/* parse every device-parsed picture of the pending batch in one launch; fills dev_blob, dev_nest, the LDS sizes and the flags */
+static int device_parse(HvqContext *c)
+{
+    std::vector<size_t> idx;
+    size_t need = 0;
+    uint32_t rowbuf = 0;
+    for (size_t i = 0; i < c->pending.size(); ++i) {
+        Pending &p = c->pending[i];
+        if (!p.dev) continue;
+        const Stream &s = c->streams[(size_t)p.stream];
+        idx.push_back(i);
+        need += (size_t)s.blob_cap + s.scratch_bytes + align_up(GP_ALIGN16(HVQ_NESTP_BYTES), 256);
+        rowbuf = std::max(rowbuf, (uint32_t)s.layout.hb[0] + 2u);
+    }
+    if (idx.empty()) return HVQ_OK;
+    if (need > c->gp_cap) {
+        if (c->gp_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->gp_dev)); c->gp_dev = nullptr; c->gp_cap = 0; }
+        HIPCHK(hipMalloc((void **)&c->gp_dev, need));
+        c->gp_cap = need;
+    }
+    if (idx.size() > c->pj_cap) {
+        if (c->pj_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pj_dev)); HIPCHK(hipFree(c->pr_dev)); HIPCHK(hipFree(c->np_dev)); }
+        c->pj_cap = idx.size() * 2;
+        HIPCHK(hipMalloc((void **)&c->pj_dev, c->pj_cap * sizeof(HvqParseJob)));
+        HIPCHK(hipMalloc((void **)&c->pr_dev, c->pj_cap * sizeof(HvqParseResult)));
+        HIPCHK(hipMalloc((void **)&c->np_dev, c->pj_cap * 2 * sizeof(uint64_t)));
+    }
+    std::vector<HvqParseJob> jobs(idx.size());
+    size_t off = 0;
+    for (size_t k = 0; k < idx.size(); ++k) {
+        Pending &p = c->pending[idx[k]];
+        const Stream &s = c->streams[(size_t)p.stream];
+        HvqParseJob &j = jobs[k];
+        memset(&j, 0, sizeof j);
+        p.dev_blob = (uint64_t)(uintptr_t)(c->gp_dev + off);             off += s.blob_cap;
+        j.scratch = (uint64_t)(uintptr_t)(c->gp_dev + off);              off += s.scratch_bytes;
+        p.dev_nest = (uint64_t)(uintptr_t)(c->gp_dev + off);             off += align_up(GP_ALIGN16(HVQ_NESTP_BYTES), 256);
+        j.pic = (uint64_t)(uintptr_t)(c->dev_arena + p.blob_off);
+        j.blob = p.dev_blob;
+        j.nest_out = p.dev_nest;
+        j.len = (uint32_t)p.blob_len;
+        j.pic_dwords = (uint32_t)((p.blob_len + 16) / 4);
+        j.cap = s.blob_cap;
+        j.width = (uint16_t)p.w; j.height = (uint16_t)p.h;
+        j.frame_type = (uint8_t)(p.kind == HVQ_PIC_I ? HVQ_FRAME_I : (p.kind == HVQ_PIC_P ? HVQ_FRAME_P : HVQ_FRAME_B));
+        j.h_samp = s.layout.wshift ? 2 : 1; j.v_samp = s.layout.hshift ? 2 : 1;
+        j.is15 = (s.layout.flags & HVQ_F_IS15) ? 1 : 0;
+    }
+    HIPCHK(hipMemcpyAsync(c->pj_dev, jobs.data(), jobs.size() * sizeof(HvqParseJob), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, c->stream));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    std::vector<HvqParseResult> res(idx.size());
+    HIPCHK(hipMemcpyAsync(res.data(), c->pr_dev, res.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->gpu_parse_ms = ms;
+    for (size_t k = 0; k < idx.size(); ++k) {
+        Pending &p = c->pending[idx[k]];
+        if (res[k].status)
+            return fail(res[k].status & GP_ST_OVERFLOW ? HVQ_E_OVERFLOW : HVQ_E_ARG,
+                        "GPU parse failed (status %u) for stream %d picture %d", res[k].status, p.stream, p.ordinal);
+        p.max_items = res[k].max_items; p.max_pairs = res[k].max_pairs;
+        p.flags = res[k].flags;
+        p.blob_len = res[k].total_bytes;
+    }
+    return HVQ_OK;
+}
+
 /* enqueue all launches of the resident batch once: the second queue forks from / joins into the main stream */
 static int run_launches(HvqContext *c)
 {
@@ -410,6 +580,8 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
     HIPCHK(hipSetDevice(c->device));
     /* 1. descriptors -> HBM (one copy) */
     HIPCHK(hipMemcpyAsync(c->dev_arena, c->host_arena, c->arena_used, hipMemcpyHostToDevice, c->stream));
+    /* 1b. streams parsed on the GPU: bitstreams -> blobs, one launch */
+    { int rc = device_parse(c); if (rc) { c->pending.clear(); c->arena_used = 0; for (auto &s : c->streams) s.nest_src = -1; return rc; } }
     /* 2. job + tile tables, level by level, tiles dealt so that a picture stays on one XCD */
     int max_level = 0;
     for (auto &p : c->pending) max_level = std::max(max_level, p.level);
@@ -422,8 +594,15 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         const Stream &s = c->streams[(size_t)p.stream];
         HvqJob &j = jobs[i];
         memset(&j, 0, sizeof j);
-        const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + p.blob_off);
-        const uint64_t blob = (uint64_t)(uintptr_t)(c->dev_arena + p.blob_off);
+        HvqPicHeader hdev;
+        if (p.dev) {                                   /* geometry from the stream, per-picture fields from the parse result */
+            hdev = s.layout;
+            hdev.pic_kind = (uint8_t)p.kind; hdev.unk_shift = (uint8_t)p.unk_shift; hdev.flags = p.flags;
+            if (p.kind == HVQ_PIC_I) hdev.mv_off = 0;
+            hdev.nest_off = 1;
+        }
+        const HvqPicHeader *hd = p.dev ? &hdev : (const HvqPicHeader *)(c->host_arena + p.blob_off);
+        const uint64_t blob = p.dev ? p.dev_blob : (uint64_t)(uintptr_t)(c->dev_arena + p.blob_off);
         const uint64_t dst = (uint64_t)(uintptr_t)s.slot_ptr(p.dst);
         j.ref0 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref0);
         j.ref1 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref1);
@@ -431,6 +610,7 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         j.mv = blob + hd->mv_off;
         j.wave_base = blob + hd->wave_base_off;
         j.nest = hd->nest_off ? blob + hd->nest_off : 0;
+        if (p.dev) j.nest = p.nest_ref >= 0 ? c->pending[(size_t)p.nest_ref].dev_nest : (uint64_t)(uintptr_t)s.nest_keep_ptr(s.nest_cur);
         j.slot_bytes = s.slot_bytes;
         j.flags = hd->flags; j.width = hd->width; j.height = hd->height;
         j.pic_kind = hd->pic_kind; j.unk_shift = hd->unk_shift;
@@ -449,7 +629,8 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         st.luma_pixels += (uint64_t)p.w * p.h;
         st.algorithmic_bytes += (uint64_t)s.pic_bytes * (p.kind == HVQ_PIC_I ? 1u : 2u);
         st.descriptor_bytes += p.blob_len;
-        st.flags_or |= ((const HvqPicHeader *)(c->host_arena + p.blob_off))->flags;
+        st.flags_or |= hd->flags;
+        st.gpu_parsed += p.dev ? 1u : 0u;
     }
     /* Two queues: clips are independent, so the dependency levels of the even and of the odd streams form two
      * chains that run on two HIP streams -- while one chain drains a level the other keeps the CUs busy. */
@@ -490,6 +671,7 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
       }
     st.launches = (uint32_t)c->launches.size();
     st.parse_seconds = c->parse_seconds;
+    st.gpu_parse_ms = st.gpu_parsed ? c->gpu_parse_ms : 0.0;
     if (jobs.size() > c->jobs_cap) {
         if (c->jobs_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->jobs_dev)); }
         c->jobs_cap = jobs.size() * 2;
@@ -506,6 +688,20 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
     HIPCHK(hipStreamSynchronize(c->stream));
     /* 3. one launch per level */
     { int rc = run_launches(c); if (rc) return rc; }
+    {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
+        std::vector<uint64_t> pairs;
+        for (auto &s : c->streams)
+            if (s.open && s.nest_src >= 0) {
+                pairs.push_back(c->pending[(size_t)s.nest_src].dev_nest);
+                pairs.push_back((uint64_t)(uintptr_t)s.nest_keep_ptr(s.nest_cur ^ 1));   /* replays of this batch keep reading [nest_cur] */
+                s.nest_cur ^= 1;
+                s.nest_src = -1;
+            }
+        if (!pairs.empty()) {
+            HIPCHK(hipMemcpyAsync(c->np_dev, pairs.data(), pairs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hvq_launch_nest_commit(c->np_dev, (uint32_t)(pairs.size() / 2), c->stream));
+        }
+    }
     c->stats = st;
     /* the batch is in flight: levels restart from zero for whatever is queued next */
     for (auto &s : c->streams)

@@ -46,6 +46,8 @@ typedef struct HvqStats {
     uint32_t workgroups;        /* total workgroups per pass */
     double   parse_seconds;     /* host entropy-parse time accumulated by hvq_stream_submit */
     uint32_t flags_or;          /* OR of all blob header flags (HVQ_F_*) */
+    uint32_t gpu_parsed;        /* pictures of the batch whose bitstream was parsed on the GPU */
+    double   gpu_parse_ms;      /* device time of that parse launch (HIP events) */
 } HvqStats;
 
 int  hvq_context_create(int device, HvqContext **out);
@@ -66,6 +68,14 @@ int  hvq_stream_submit(HvqContext *ctx, int stream, int frame_type, const uint8_
  * (may be NULL) receives picture i's ordinal.  Returns HVQ_OK or the first error. */
 int  hvq_submit_many(HvqContext *ctx, int n, const int *streams, const int *frame_types,
                      const uint8_t *const *pics, const size_t *lens, int threads, int *ordinals);
+
+/* GPU entropy parse: queue RAW picture bitstreams; hvq_flush uploads them and parses them on
+ * the device (one workgroup per picture, hvq_gparse.hip), so no host core touches a bit of the stream.  Same
+ * queueing semantics as hvq_submit_many.  A stream uses either the host parser or the GPU parser for its whole
+ * lifetime (the host parser keeps the nest of the last I picture); lens[] must be the real picture lengths.
+ * Errors of the device parse (HVQ_E_OVERFLOW, HVQ_E_ARG) are reported by hvq_flush. */
+int  hvq_submit_many_device(HvqContext *ctx, int n, const int *streams, const int *frame_types,
+                            const uint8_t *const *pics, const size_t *lens, int *ordinals);
 
 /* Upload queued descriptors, group queued pictures into dependency levels, launch. Async. */
 int  hvq_flush(HvqContext *ctx);

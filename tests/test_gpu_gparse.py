@@ -1,0 +1,118 @@
+"""GPU: entropy parse ON the device (hvq_submit_many_device -> hvq_gparse.hip) followed by the reconstruction
+kernels must give the oracle's pictures bit for bit -- no host core parses a bit of these streams."""
+import numpy as np
+import pytest
+
+from tests import clips
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_ctx():
+    from hvqm4_amd import batch
+    ctx = batch.Context(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM, ids=lambda c: c[0])
+def test_gpu_parsed_clip_matches_oracle(gpu_ctx, case):
+    from hvqm4_amd import batch
+    from oracle import bridge
+    clip = clips.get(case)
+    want = bridge.oracle_decode(clip.data, clip.n_pictures)
+    got = batch.decode_clip(gpu_ctx, clip.data, gpu_parse=True)
+    assert np.array_equal(got, want)
+    st = gpu_ctx.stats()
+    assert st.gpu_parsed == clip.n_pictures
+
+
+@pytest.mark.parametrize("every", [1, 2, 5])
+def test_nest_of_the_last_I_picture_survives_flushes(gpu_ctx, every):
+    """P/B pictures with intra AOT blocks use the nest of the most recent I picture (h4m:1823 -> 1367); with one
+    flush per few pictures that I picture sits in an earlier batch"""
+    from hvqm4_amd import batch
+    from oracle import bridge
+    clip = clips.get(clips.SMALL[3])
+    want = bridge.oracle_decode(clip.data, clip.n_pictures)
+    got = batch.decode_clip(gpu_ctx, clip.data, gpu_parse=True, flush_every=every)
+    assert np.array_equal(got, want)
+
+
+def test_many_streams_one_parse_launch(gpu_ctx):
+    from hvqm4_amd.container import parse_header, video_pictures
+    from oracle import bridge
+    cases = [clips.get(c) for c in clips.SMALL[:8]]
+    sids, per = [], []
+    for cl in cases:
+        hdr = parse_header(cl.data)
+        sids.append(gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, cl.n_pictures + 3))
+        per.append(list(video_pictures(cl.data)))
+    a_s, a_t, a_p = [], [], []
+    for k in range(max(len(p) for p in per)):
+        for sid, p in zip(sids, per):
+            if k < len(p):
+                a_s.append(sid); a_t.append(p[k][0]); a_p.append(bytes(p[k][2]))
+    gpu_ctx.submit_many_device(a_s, a_t, a_p)
+    gpu_ctx.flush()
+    assert gpu_ctx.stats().gpu_parsed == len(a_p)
+    for sid, cl in zip(sids, cases):
+        want = bridge.oracle_decode(cl.data, cl.n_pictures)
+        for k in range(cl.n_pictures):
+            assert np.array_equal(gpu_ctx.read_picture(sid, k), want[k]), (cl, k)
+        gpu_ctx.close_stream(sid)
+
+
+def test_host_and_gpu_parsed_streams_share_a_batch(gpu_ctx):
+    from hvqm4_amd.container import parse_header, video_pictures
+    from oracle import bridge
+    cl = clips.get(clips.SMALL[4])
+    hdr = parse_header(cl.data)
+    pics = list(video_pictures(cl.data))
+    s_host = gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, len(pics) + 3)
+    s_dev = gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, len(pics) + 3)
+    for ft, _d, pic in pics:
+        gpu_ctx.submit(s_host, ft, pic)
+    gpu_ctx.submit_many_device([s_dev] * len(pics), [p[0] for p in pics], [bytes(p[2]) for p in pics])
+    gpu_ctx.flush()
+    want = bridge.oracle_decode(cl.data, cl.n_pictures)
+    for k in range(cl.n_pictures):
+        assert np.array_equal(gpu_ctx.read_picture(s_host, k), want[k])
+        assert np.array_equal(gpu_ctx.read_picture(s_dev, k), want[k])
+    # a stream keeps its parser
+    with pytest.raises(Exception):
+        gpu_ctx.submit(s_dev, pics[0][0], pics[0][2])
+    with pytest.raises(Exception):
+        gpu_ctx.submit_many_device([s_host], [pics[0][0]], [bytes(pics[0][2])])
+    gpu_ctx.close_stream(s_host)
+    gpu_ctx.close_stream(s_dev)
+
+
+def test_corrupted_streams_do_not_fault_the_gpu_parser(gpu_ctx):
+    """bit flips, truncation and garbage: the device parser must stay in bounds and terminate; pictures are either
+    rejected by flush or decoded to something"""
+    from hvqm4_amd.container import parse_header, video_pictures
+    cl = clips.get(clips.SMALL[3])
+    hdr = parse_header(cl.data)
+    pics = [(ft, bytes(p)) for ft, _d, p in video_pictures(cl.data)]
+    rng = np.random.default_rng(11)
+    variants = []
+    for ft, p in pics[:4]:
+        a = bytearray(p)
+        for _ in range(20):
+            a[int(rng.integers(8, len(a)))] ^= 1 << int(rng.integers(0, 8))
+        variants.append((ft, bytes(a)))
+        variants.append((ft, p[:max(0x60, len(p) // 3)]))
+        variants.append((ft, p[:0x50] + bytes(rng.integers(0, 256, len(p) - 0x50, dtype=np.uint8))))
+    for ft, data in variants:
+        sid = gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, 4)
+        try:
+            gpu_ctx.submit_many_device([sid], [ft], [data])
+            gpu_ctx.flush()
+            gpu_ctx.sync()
+        except Exception:
+            pass
+        gpu_ctx.close_stream(sid)
+    # the context is still healthy
+    test_nest_of_the_last_I_picture_survives_flushes(gpu_ctx, 2)
