@@ -34,7 +34,26 @@
 #define GP_FN static inline
 #endif
 
-#define GP_LUT_BITS 9
+/* Everything in HBM is addressed through global-address-space pointers: a generic (flat) access counts on the LDS
+ * counter as well, so every table lookup in LDS would also wait for the chain's outstanding bitstream loads and
+ * blob stores -- which defeats the readers' lookahead. */
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define GP_G __attribute__((address_space(1)))
+#else
+#define GP_G
+#endif
+
+/* Chains and the serial steps run WAVE-UNIFORM on the device: every lane of the wave executes the same chain with the
+ * same values, so the compiler keeps cursors, reservoirs and counters in scalar registers and runs the bit-level
+ * logic on the scalar unit (one branch instead of an exec-mask dance per `if`), several times faster for a
+ * dependent chain than one active vector lane.  Only the stores to HBM are restricted to one lane (GP_ST). */
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define GP_ST(lvalue, value) do { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) (lvalue) = (value); } while (0)
+#else
+#define GP_ST(lvalue, value) do { (lvalue) = (value); } while (0)
+#endif
+
+#define GP_LUT_BITS 8
 #define GP_MAX_OVF_ITER 65536
 #define GP_ALIGN16(x) (((x) + 15u) & ~15u)
 
@@ -68,33 +87,65 @@ typedef struct HvqParseResult {   /* what the host needs back to size and order 
 } HvqParseResult;
 
 /* ------------------------------------------------------------------ bit reader over aligned dwords */
+/* A chain is one dependent sequence, so a load that is needed at once costs its full latency.  The wave therefore
+ * fetches its section GP_BLK dwords at a time -- one coalesced load by GP_BLK lanes -- into an LDS staging slot that
+ * belongs to the cursor, and a refill reads the next dword from LDS: one HBM round trip per 128 bytes of bitstream
+ * instead of one per 4.  (Keeping look-ahead dwords in registers does not work: the compiler's register copies of a
+ * freshly requested dword make it wait for the load on the spot.) */
+#define GP_BLK 32
+#define GP_SLOTS 17
+
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+__shared__ uint32_t gp_stage[GP_SLOTS * GP_BLK];
+#define GP_LANE() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#else
+static uint32_t gp_stage[GP_SLOTS * GP_BLK];
+#endif
+
 typedef struct {
-    const uint32_t *d;
+    const GP_G uint32_t *d;
     uint32_t nd;               /* readable dwords; everything past them reads as zero */
-    uint32_t idx;              /* next dword */
+    uint32_t idx;              /* next dword to consume */
+    uint32_t base;             /* first dword held by the staging slot, ~0 = none */
+    uint32_t slot;             /* staging slot of this cursor */
     uint64_t acc;              /* left aligned */
     int cnt;
     int live;
 } GBits;
 
-GP_FN uint32_t gb_dword(const GBits *b, uint32_t i) { return i < b->nd ? __builtin_bswap32(b->d[i]) : 0u; }
+GP_FN uint32_t gb_raw(const GBits *b, uint32_t i) { return i < b->nd ? b->d[i] : 0u; }
 
-GP_FN void gb_init(GBits *b, const uint32_t *d, uint32_t nd, uint64_t byte_off, int live)
+GP_FN void gb_init(GBits *b, const GP_G uint32_t *d, uint32_t nd, uint64_t byte_off, int live, uint32_t slot)
 {
-    b->d = d; b->nd = nd; b->live = live;
+    b->d = d; b->nd = nd; b->live = live; b->slot = slot; b->base = ~0u;
     if (byte_off >= (uint64_t)nd * 4u) { b->idx = nd; b->acc = 0; b->cnt = 32; return; }
     const uint32_t i = (uint32_t)(byte_off >> 2), sh = (uint32_t)(byte_off & 3u) * 8u;
-    b->acc = ((uint64_t)gb_dword(b, i) << 32) << sh;
+    b->acc = ((uint64_t)__builtin_bswap32(gb_raw(b, i)) << 32) << sh;
     b->cnt = 32 - (int)sh;
     b->idx = i + 1;
+}
+
+/* all lanes of the (uniformly executing) wave: stage dwords [blk, blk + GP_BLK) of the section */
+GP_FN void gb_fetch(GBits *b, uint32_t blk)
+{
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    const int lane = GP_LANE();
+    if (lane < GP_BLK) gp_stage[b->slot * GP_BLK + (uint32_t)lane] = gb_raw(b, blk + (uint32_t)lane);
+#else
+    for (uint32_t l = 0; l < GP_BLK; ++l) gp_stage[b->slot * GP_BLK + l] = gb_raw(b, blk + l);
+#endif
+    b->base = blk;
 }
 
 GP_FN void gb_refill(GBits *b)
 {
     if (b->cnt <= 32) {
-        b->acc |= (uint64_t)gb_dword(b, b->idx) << (32 - b->cnt);
-        b->idx++;
+        const uint32_t blk = b->idx & ~(uint32_t)(GP_BLK - 1);
+        if (blk != b->base) gb_fetch(b, blk);
+        const uint32_t w = gp_stage[b->slot * GP_BLK + (b->idx & (GP_BLK - 1))];
+        b->acc |= (uint64_t)__builtin_bswap32(w) << (32 - b->cnt);
         b->cnt += 32;
+        b->idx++;
     }
 }
 
@@ -108,10 +159,27 @@ GP_FN uint32_t gb_take(GBits *b, int n)        /* n <= 32 */
     return v;
 }
 
+/* sequential reader of a byte array in HBM (macroblock types / tags), four bytes per load, one load ahead; the array
+ * must be readable up to 8 bytes past its last element */
+typedef struct {
+    const GP_G uint32_t *p;
+    uint32_t cur, nxt, i;
+} GBytes;
+
+GP_FN void gby_init(GBytes *b, const GP_G uint8_t *a) { b->p = (const GP_G uint32_t *)a; b->cur = b->p[0]; b->nxt = b->p[1]; b->i = 0; }
+
+GP_FN uint32_t gby_next(GBytes *b)
+{
+    const uint32_t v = (b->cur >> (8u * (b->i & 3u))) & 0xFFu;
+    if ((++b->i & 3u) == 0) { b->cur = b->nxt; b->nxt = b->p[(b->i >> 2) + 1]; }
+    return v;
+}
+
 /* ------------------------------------------------------------------ prefix trees (h4m:385-394, 604-651) */
 typedef struct {
     int root;
-    uint16_t lut[1 << GP_LUT_BITS];     /* [15:10] bits consumed, [9:0] leaf byte (< 256) or node id; the tree reader's stack */
+    uint32_t lut[1 << GP_LUT_BITS];     /* [5:0] bits consumed, [7] leaf reached, [31:16] leaf VALUE (int16) or node id;
+                                           one LDS read decodes a short code.  Doubles as the tree reader's stack. */
     uint16_t kid[2][256];               /* children of node ids 256..511 */
     int16_t leaf[256];
 } GCode;
@@ -121,7 +189,7 @@ GP_FN void gc_read(GCode *c, GBits *carrier, int is_signed, int scale, uint32_t 
 {
     c->root = 0;
     if (!carrier->live) { c->leaf[0] = 0; (void)flags; return; }
-    uint16_t *stk = c->lut;
+    uint16_t *stk = (uint16_t *)c->lut;
     int sp = 0, next = 0x100;
     for (;;) {
         int val;
@@ -157,7 +225,7 @@ GP_FN void gc_fill_lut(GCode *c, int tid, int nthr)
     for (int e = tid; e < (1 << GP_LUT_BITS); e += nthr) {
         int node = root, d = 0;
         while (node >= 256 && d < GP_LUT_BITS) { node = c->kid[(e >> (GP_LUT_BITS - 1 - d)) & 1][node - 256]; ++d; }
-        c->lut[e] = (uint16_t)((d << 10) | node);
+        c->lut[e] = node < 256 ? ((uint32_t)d | 0x80u | ((uint32_t)(uint16_t)c->leaf[node] << 16)) : ((uint32_t)d | ((uint32_t)node << 16));
     }
 }
 
@@ -165,10 +233,11 @@ GP_FN int32_t gsym(const GCode *c, GBits *b)                                   /
 {
     gb_refill(b);
     const uint32_t e = c->lut[b->acc >> (64 - GP_LUT_BITS)];
-    const int len = (int)(e >> 10);
-    int id = (int)(e & 1023u);
+    const int len = (int)(e & 63u);
     b->acc <<= len;
     b->cnt -= len;
+    if (e & 0x80u) return (int16_t)(e >> 16);
+    int id = (int)(e >> 16);
     while (id >= 256) {
         if (b->cnt == 0) gb_refill(b);
         id = c->kid[b->acc >> 63][id - 256];
@@ -202,30 +271,30 @@ typedef struct {
     uint32_t nblocks, ntiles;
     uint32_t map_off, plane_off;
     uint32_t run_first;          /* index of the plane's first 64-block run in wave_base[] */
-    uint32_t blk_first;          /* index of the plane's first block in blk_off[] */
+    uint32_t blk_first;          /* index of the plane's first entry in pinfo[] */
 } GPlane;
 
 enum { GC_BN = 0, GC_RUN, GC_DC, GC_BT, GC_MV, GC_MCB, GC_COUNT };
 
 typedef struct {
     /* job */
-    const uint32_t *d;
+    const GP_G uint32_t *d;
     uint32_t nd, len, cap;
-    uint8_t *blob;
-    uint8_t *nest_out;
+    GP_G uint8_t *blob;
+    GP_G uint8_t *nest_out;
     int frame_type, is_pb, is_P;
     /* geometry (hvq_parser_create) */
     int w, h, is15, landscape, nest_w, nest_h, wshift, hshift, mw, mh;
     GPlane pl[3];
     uint32_t mv_off, wave_base_off, fixed_bytes, pic_bytes, total_tiles, total_runs, total_blocks;
     /* scratch */
-    uint32_t *blk_off;           /* [total_blocks] pool offset of every block */
-    uint16_t *run_items;         /* [total_runs] */
-    uint16_t *run_pairs;         /* [total_runs] */
-    uint8_t *mbtype;             /* [mw*mh] macroblock type 0..3 */
-    uint8_t *procseq;            /* [mw*mh] proc value of the n-th inter macroblock */
-    uint8_t *mbtag;              /* [mw*mh] (type << 5) | (proc << 4) */
-    uint32_t *part;              /* [GP_PART] partial counts of the parallel phases */
+    GP_G uint32_t *pinfo;        /* [total_blocks] payload entry of every block, in CONSUMPTION order (GP_ENT) */
+    GP_G uint16_t *run_items;    /* [total_runs] */
+    GP_G uint16_t *run_pairs;    /* [total_runs] */
+    GP_G uint8_t *mbtype;        /* [mw*mh] macroblock type 0..3 */
+    GP_G uint8_t *procseq;       /* [mw*mh] proc value of the n-th inter macroblock */
+    GP_G uint8_t *mbtag;         /* [mw*mh] (type << 5) | (proc << 4) */
+    GP_G uint32_t *part;         /* [GP_PART] partial counts of the parallel phases */
     /* picture */
     int dc_shift, unk_shift, nx, ny;
     int32_t dc_lo, dc_hi;
@@ -256,16 +325,16 @@ GP_FN uint32_t gp_byte(const GPic *g, uint32_t off) { return (gp_be32(g, off & ~
 /* bytes of scratch one picture of this geometry needs */
 GP_FN uint32_t gp_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb)
 {
-    return GP_ALIGN16(4u * total_blocks) + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb) * 3u + 4u * GP_PART;
+    return GP_ALIGN16(4u * total_blocks) + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb + 16u) * 3u + 4u * GP_PART;
 }
 
 /* serial (thread 0): geometry exactly as hvq_parser_create lays the blob out */
 GP_FN void gp_setup(GPic *g, const HvqParseJob *job)
 {
-    g->d = (const uint32_t *)(uintptr_t)job->pic;
+    g->d = (const GP_G uint32_t *)(uintptr_t)job->pic;
     g->nd = job->pic_dwords; g->len = job->len; g->cap = job->cap;
-    g->blob = (uint8_t *)(uintptr_t)job->blob;
-    g->nest_out = (uint8_t *)(uintptr_t)job->nest_out;
+    g->blob = (GP_G uint8_t *)(uintptr_t)job->blob;
+    g->nest_out = (GP_G uint8_t *)(uintptr_t)job->nest_out;
     g->frame_type = job->frame_type;
     g->is_pb = job->frame_type != 0x10;
     g->is_P = job->frame_type == 0x20;
@@ -301,14 +370,14 @@ GP_FN void gp_setup(GPic *g, const HvqParseJob *job)
     off = GP_ALIGN16(off + 4u * g->total_tiles * (HVQ_TILE_BLOCKS / 64));
     g->fixed_bytes = off;
     const uint32_t nmb = (uint32_t)g->mw * (uint32_t)g->mh;
-    uint8_t *s = (uint8_t *)(uintptr_t)job->scratch;
-    g->blk_off = (uint32_t *)s;          s += GP_ALIGN16(4u * blocks);
-    g->run_items = (uint16_t *)s;        s += GP_ALIGN16(2u * runs);
-    g->run_pairs = (uint16_t *)s;        s += GP_ALIGN16(2u * runs);
-    g->mbtype = s;                       s += GP_ALIGN16(nmb);
-    g->procseq = s;                      s += GP_ALIGN16(nmb);
-    g->mbtag = s;                        s += GP_ALIGN16(nmb);
-    g->part = (uint32_t *)s;
+    GP_G uint8_t *s = (GP_G uint8_t *)(uintptr_t)job->scratch;
+    g->pinfo = (GP_G uint32_t *)s;       s += GP_ALIGN16(4u * blocks);
+    g->run_items = (GP_G uint16_t *)s;   s += GP_ALIGN16(2u * runs);
+    g->run_pairs = (GP_G uint16_t *)s;   s += GP_ALIGN16(2u * runs);
+    g->mbtype = s;                       s += GP_ALIGN16(nmb + 16u);
+    g->procseq = s;                      s += GP_ALIGN16(nmb + 16u);
+    g->mbtag = s;                        s += GP_ALIGN16(nmb + 16u);
+    g->part = (GP_G uint32_t *)s;
     g->flags = 0; g->status = 0; g->max_items = 0; g->max_pairs = 0; g->pool_dwords = 0; g->total = 0; g->nest_off = 0;
     if (g->cap < g->fixed_bytes || g->len < 8 + 0x44 + 4) g->status |= GP_ST_BADARG;
 }
@@ -322,11 +391,11 @@ GP_FN uint64_t gp_section(const GPic *g, uint32_t data_off, uint32_t tab_off, in
     return s + 4;
 }
 
-GP_FN void gp_section_bits(const GPic *g, GBits *b, uint32_t data_off, uint32_t tab_off, int i)
+GP_FN void gp_section_bits(const GPic *g, GBits *b, uint32_t data_off, uint32_t tab_off, int i, uint32_t slot)
 {
     int live;
     const uint64_t s = gp_section(g, data_off, tab_off, i, &live);
-    gb_init(b, g->d, g->nd, s, live);
+    gb_init(b, g->d, g->nd, s, live, slot);
 }
 
 /* serial (thread 0): picture header fields and all section cursors */
@@ -344,22 +413,23 @@ GP_FN void gp_sections(GPic *g)
     } else {
         g->nx = (int)(gp_be32(g, 4) >> 16); g->ny = (int)(gp_be32(g, 4) & 0xFFFFu);
     }
+    /* staging slots: bn 0-1, bnr 2-3, dc 4-6, bt 7-9, fx 10-12, then rle 13-15 (I) or mvh, mvv, mtype, mproc 13-16 (P/B) */
     for (int i = 0; i < 2; ++i) {
-        gp_section_bits(g, &g->bn[i], data, tab, 2 * i);
-        gp_section_bits(g, &g->bnr[i], data, tab, 2 * i + 1);
+        gp_section_bits(g, &g->bn[i], data, tab, 2 * i, (uint32_t)i);
+        gp_section_bits(g, &g->bnr[i], data, tab, 2 * i + 1, 2u + (uint32_t)i);
     }
     for (int k = 0; k < 3; ++k) {
-        gp_section_bits(g, &g->dc[k], data, tab, 4 + 3 * k);
-        gp_section_bits(g, &g->bt[k], data, tab, 5 + 3 * k);
-        gp_section_bits(g, &g->fx[k], data, tab, 6 + 3 * k);
+        gp_section_bits(g, &g->dc[k], data, tab, 4 + 3 * k, 4u + (uint32_t)k);
+        gp_section_bits(g, &g->bt[k], data, tab, 5 + 3 * k, 7u + (uint32_t)k);
+        gp_section_bits(g, &g->fx[k], data, tab, 6 + 3 * k, 10u + (uint32_t)k);
     }
     if (g->is_pb) {
-        gp_section_bits(g, &g->mvh, data, tab, 13);
-        gp_section_bits(g, &g->mvv, data, tab, 14);
-        gp_section_bits(g, &g->mtype, data, tab, 15);
-        gp_section_bits(g, &g->mproc, data, tab, 16);
+        gp_section_bits(g, &g->mvh, data, tab, 13, 13u);
+        gp_section_bits(g, &g->mvv, data, tab, 14, 14u);
+        gp_section_bits(g, &g->mtype, data, tab, 15, 15u);
+        gp_section_bits(g, &g->mproc, data, tab, 16, 16u);
     } else {
-        for (int k = 0; k < 3; ++k) gp_section_bits(g, &g->rle[k], data, tab, 13 + k);
+        for (int k = 0; k < 3; ++k) gp_section_bits(g, &g->rle[k], data, tab, 13 + k, 13u + (uint32_t)k);
     }
     g->dc_hi = (int32_t)((uint32_t)0x7F << (g->dc_shift & 31));
     g->dc_lo = (int32_t)((uint32_t)-0x80 << (g->dc_shift & 31));
@@ -379,7 +449,7 @@ GP_FN void gp_read_tree(GPic *g, GCode *codes, int t)
     default:     gc_read(&codes[GC_MCB], &g->mtype, 0, 0, &st, &fl); break;
     }
     /* one word per tree: no two lanes update the same location */
-    g->part[GP_MISC + t] = st; g->part[GP_MISC + GC_COUNT + t] = fl;
+    GP_ST(g->part[GP_MISC + t], st); GP_ST(g->part[GP_MISC + GC_COUNT + t], fl);
 }
 
 GP_FN void gp_collect_tree_status(GPic *g, int ntrees)      /* serial (thread 0), after the tree reads */
@@ -389,7 +459,7 @@ GP_FN void gp_collect_tree_status(GPic *g, int ntrees)      /* serial (thread 0)
 }
 
 /* ------------------------------------------------------------------ blob helpers */
-GP_FN uint8_t *gp_map_ent(const GPic *g, int plane, int by, int bx)
+GP_FN GP_G uint8_t *gp_map_ent(const GPic *g, int plane, int by, int bx)
 {
     return g->blob + g->pl[plane].map_off + 2u * ((uint32_t)(by + 1) * (uint32_t)g->pl[plane].stride + (uint32_t)(bx + 1));
 }
@@ -400,7 +470,7 @@ GP_FN void gp_init_maps(const GPic *g, int tid, int nthr)
     if (g->status) return;
     for (int i = 0; i < 3; ++i) {
         const GPlane *q = &g->pl[i];
-        uint16_t *m = (uint16_t *)(g->blob + q->map_off);
+        GP_G uint16_t *m = (GP_G uint16_t *)(g->blob + q->map_off);
         const uint32_t n = (uint32_t)q->stride * (uint32_t)(q->vb + 2);
         for (uint32_t e = (uint32_t)tid; e < n; e += (uint32_t)nthr) {
             const uint32_t r = e / (uint32_t)q->stride, c = e - r * (uint32_t)q->stride;
@@ -409,7 +479,7 @@ GP_FN void gp_init_maps(const GPic *g, int tid, int nthr)
         }
     }
     if (g->is_pb) {
-        uint32_t *mv = (uint32_t *)(g->blob + g->mv_off);
+        GP_G uint32_t *mv = (GP_G uint32_t *)(g->blob + g->mv_off);
         const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
         for (uint32_t e = (uint32_t)tid; e < n; e += (uint32_t)nthr) mv[e] = 0;
     }
@@ -426,23 +496,23 @@ GP_FN void gp_ikinds(GPic *g, const GCode *codes, int which)
     if (which == 0) {
         const GPlane *Y = &g->pl[0];
         for (int by = 0; by < Y->vb; ++by) {
-            uint8_t *row = gp_map_ent(g, 0, by, 0);
+            GP_G uint8_t *row = gp_map_ent(g, 0, by, 0);
             for (int bx = 0; bx < Y->hb; ++bx) {
                 if (run) { --run; continue; }
                 const int32_t k = gsym(c_bn, &bn) & 0xFFFF;
                 if ((int16_t)k == 0) run = (uint32_t)gsym(c_run, &bnr);
-                else row[2 * bx + 1] = (uint8_t)k;
+                else GP_ST(row[2 * bx + 1], (uint8_t)k);
             }
         }
     } else {
         const GPlane *C = &g->pl[1];
         for (int by = 0; by < C->vb; ++by) {
-            uint8_t *ru = gp_map_ent(g, 1, by, 0), *rv = gp_map_ent(g, 2, by, 0);
+            GP_G uint8_t *ru = gp_map_ent(g, 1, by, 0), *rv = gp_map_ent(g, 2, by, 0);
             for (int bx = 0; bx < C->hb; ++bx) {
                 if (run) { --run; continue; }
                 const int32_t k = gsym(c_bn, &bn) & 0xFFFF;
                 if ((int16_t)k == 0) run = (uint32_t)gsym(c_run, &bnr);
-                else { ru[2 * bx + 1] = (uint8_t)(k & 0xF); rv[2 * bx + 1] = (uint8_t)((k >> 4) & 0xF); }
+                else { GP_ST(ru[2 * bx + 1], (uint8_t)(k & 0xF)); GP_ST(rv[2 * bx + 1], (uint8_t)((k >> 4) & 0xF)); }
             }
         }
     }
@@ -460,7 +530,7 @@ GP_FN void gp_idc(GPic *g, const GCode *codes, int i, uint8_t *rowbuf)
     for (int bx = 0; bx <= q->hb; ++bx) rowbuf[bx] = 0x7F;
     uint32_t run = 0;
     for (int by = 0; by < q->vb; ++by) {
-        uint8_t *row = gp_map_ent(g, i, by, 0);
+        GP_G uint8_t *row = gp_map_ent(g, i, by, 0);
         uint8_t pred = by ? rowbuf[0] : 0x7F;
         for (int bx = 0; bx < q->hb; ++bx) {
             uint32_t delta = 0;
@@ -470,7 +540,7 @@ GP_FN void gp_idc(GPic *g, const GCode *codes, int i, uint8_t *rowbuf)
                 if (delta == 0) run = (uint32_t)gsym(c_run, &rle);
             }
             const uint8_t v = (uint8_t)(pred + delta);                  /* uint8 wrap: h4m:1145-1149 */
-            row[2 * bx] = v;
+            GP_ST(row[2 * bx], v);
             pred = (uint8_t)((v + rowbuf[bx + 1] + 1) / 2);
             rowbuf[bx] = v;
         }
@@ -530,7 +600,7 @@ GP_FN int gp_run_plane(const GPic *g, uint32_t r) { return r >= g->pl[2].run_fir
 GP_FN void gp_layout_sum(GPic *g, int tid, int nthr)
 {
     if (g->status) return;
-    uint32_t *wave_base = (uint32_t *)(g->blob + g->wave_base_off);
+    GP_G uint32_t *wave_base = (GP_G uint32_t *)(g->blob + g->wave_base_off);
     uint32_t fl = 0;
     for (uint32_t r = (uint32_t)tid; r < g->total_runs; r += (uint32_t)nthr) {
         const int i = gp_run_plane(g, r);
@@ -556,13 +626,13 @@ GP_FN void gp_layout_sum(GPic *g, int tid, int nthr)
 GP_FN void gp_layout_scan(GPic *g, int nthr)
 {
     if (g->status) return;
-    uint32_t *wave_base = (uint32_t *)(g->blob + g->wave_base_off);
+    GP_G uint32_t *wave_base = (GP_G uint32_t *)(g->blob + g->wave_base_off);
     uint32_t off = 0, fl = 0, mi = 0, mp = 0, ti = 0, tp = 0;
     for (int t = 0; t < nthr; ++t) fl |= g->part[t];
     for (uint32_t r = 0; r < g->total_runs; ++r) {
         if (r % (HVQ_TILE_BLOCKS / 64) == 0) { ti = 0; tp = 0; }
         const uint32_t s = wave_base[r];
-        wave_base[r] = off;
+        GP_ST(wave_base[r], off);
         off += s;
         ti += g->run_items[r]; tp += g->run_pairs[r];
         if (ti > mi) mi = ti;
@@ -577,8 +647,11 @@ GP_FN void gp_layout_scan(GPic *g, int nthr)
     if (total > g->cap || off >= (1u << 22)) { g->status |= GP_ST_OVERFLOW; return; }
     g->total = (uint32_t)total;
     /* header (hvq_parse.c fill_header); nest_off stays 0: the nest travels separately */
-    HvqPicHeader *h = (HvqPicHeader *)g->blob;
-    uint32_t *hw = (uint32_t *)g->blob;
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) != 0) return;      /* one lane writes the header */
+#endif
+    GP_G HvqPicHeader *h = (GP_G HvqPicHeader *)g->blob;
+    GP_G uint32_t *hw = (GP_G uint32_t *)g->blob;
     for (int k = 0; k < (int)(sizeof(HvqPicHeader) / 4); ++k) hw[k] = 0;
     h->magic = HVQ_MAGIC;
     h->total_bytes = g->total;
@@ -607,11 +680,20 @@ GP_FN void gp_layout_scan(GPic *g, int nthr)
     h->max_items = (uint16_t)mi; h->max_pairs = mp;
 }
 
-/* parallel L3: pool offset of every block */
+/* payload entry of one block: [21:0] pool offset (dwords), [29:22] number of bases, [31:30] mode */
+#define GP_ENT(off, nb, mode) ((uint32_t)(off) | ((uint32_t)(nb) << 22) | ((uint32_t)(mode) << 30))
+#define GP_MODE_NONE    0u
+#define GP_MODE_LITERAL 1u
+#define GP_MODE_BASES   2u     /* intra AOT: `nb` bases */
+#define GP_MODE_PREDI   3u     /* MC residual: 2 parameters + `nb` bases */
+
+/* parallel L3: one payload entry per block, stored in the order the payload chain consumes them -- raster order for an
+ * I picture (h4m:2011-2015), macroblock order with blocks TL, BL, BR, TR for P/B (h4m:1919-1967) -- so that the chain
+ * reads one sequential array instead of chasing map entries and offsets through HBM */
 GP_FN void gp_layout_blocks(GPic *g, int tid, int nthr)
 {
     if (g->status) return;
-    const uint32_t *wave_base = (const uint32_t *)(g->blob + g->wave_base_off);
+    const GP_G uint32_t *wave_base = (const GP_G uint32_t *)(g->blob + g->wave_base_off);
     for (uint32_t r = (uint32_t)tid; r < g->total_runs; r += (uint32_t)nthr) {
         const int i = gp_run_plane(g, r);
         const GPlane *q = &g->pl[i];
@@ -620,9 +702,22 @@ GP_FN void gp_layout_blocks(GPic *g, int tid, int nthr)
         uint32_t off = wave_base[r];
         uint32_t by = b0 / (uint32_t)q->hb, bx = b0 - by * (uint32_t)q->hb;
         for (uint32_t b = b0; b < b0 + 64u && b < q->nblocks; ++b) {
+            const uint32_t t = gp_map_ent(g, i, (int)by, (int)bx)[1];
             uint32_t n, it, pr, f;
-            gp_type_info(ctx, gp_map_ent(g, i, (int)by, (int)bx)[1], &n, &it, &pr, &f);
-            g->blk_off[q->blk_first + b] = off;
+            gp_type_info(ctx, t, &n, &it, &pr, &f);
+            const uint32_t kind = ctx == 0 ? t : (t & 0xFu);
+            const int inter = ctx == 2 && (t & 0x60u);
+            uint32_t ent = GP_ENT(off, 0, GP_MODE_NONE);
+            if (n) ent = kind == 6 ? GP_ENT(off, 0, GP_MODE_LITERAL)
+                       : (inter ? GP_ENT(off, kind - 1, GP_MODE_PREDI) : GP_ENT(off, kind, GP_MODE_BASES));
+            uint32_t at = b;
+            if (g->is_pb) {
+                const uint32_t dy = by % (uint32_t)q->by_per, dx = bx % (uint32_t)q->bx_per;
+                const uint32_t mb = (by / (uint32_t)q->by_per) * (uint32_t)g->mw + bx / (uint32_t)q->bx_per;
+                at = mb * (uint32_t)q->nblk + (dx ? (dy ? 2u : 3u) : (dy ? 1u : 0u));
+                if (q->nblk == 1) at = mb;
+            }
+            g->pinfo[q->blk_first + at] = ent;
             off += n;
             if (++bx == (uint32_t)q->hb) { bx = 0; ++by; }
         }
@@ -631,38 +726,50 @@ GP_FN void gp_layout_blocks(GPic *g, int tid, int nthr)
 
 /* ------------------------------------------------------------------ payloads */
 /* `n` bases of one block: word from fixvl, coefficient from bufTree0 (h4m:691-692, 726-731 / 738-739, 767-772) */
-GP_FN void gp_emit_bases(const GCode *c_bt, GBits *fx, GBits *bt, uint32_t n, uint32_t *dst)
+GP_FN void gp_emit_bases(const GCode *c_bt, GBits *fx, GBits *bt, uint32_t n, GP_G uint32_t *dst)
 {
     uint32_t run = 0;
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t word = gb_take(fx, 16);
         run += (uint32_t)gsym(c_bt, bt);
-        dst[k] = HVQ_BASIS(word, (run + ((word >> 13) & 3u)) & 0x3FFFFu);
+        GP_ST(dst[k], HVQ_BASIS(word, (run + ((word >> 13) & 3u)) & 0x3FFFFu));
     }
 }
 
-GP_FN void gp_literal(GBits *fx, uint32_t *dst)                                 /* h4m:543-549 */
+GP_FN void gp_literal(GBits *fx, GP_G uint32_t *dst)                                 /* h4m:543-549 */
 {
-    for (int k = 0; k < 4; ++k) dst[k] = __builtin_bswap32(gb_take(fx, 32));
+    for (int k = 0; k < 4; ++k) { const uint32_t v = __builtin_bswap32(gb_take(fx, 32)); GP_ST(dst[k], v); }
 }
 
-/* chain: payloads of plane i of an I picture, raster order == consumption order (h4m:2011-2015) */
-GP_FN void gp_ipayload(GPic *g, const GCode *codes, int i)
+/* chain: payloads of plane i, I and P/B alike: walk the plane's entries in consumption order.  Intra blocks: bases
+ * (h4m:1789-1827); literal blocks (h4m:543-549); MC-residual blocks: bases, then the two scalars from the DC
+ * buffer, whose cursor gp_pbdc left behind (h4m:1862-1910, 1405-1406). */
+GP_FN void gp_payload(GPic *g, const GCode *codes, int i)
 {
     if (g->status) return;
     const GPlane *q = &g->pl[i];
-    GBits fx = g->fx[i], bt = g->bt[i];
-    const GCode *c_bt = &codes[GC_BT];
-    uint32_t *pool = (uint32_t *)(g->blob + g->fixed_bytes);
-    uint32_t off = ((const uint32_t *)(g->blob + g->wave_base_off))[q->run_first];
-    for (int by = 0; by < q->vb; ++by) {
-        const uint8_t *row = gp_map_ent(g, i, by, 0);
-        for (int bx = 0; bx < q->hb; ++bx) {
-            const uint32_t k = row[2 * bx + 1];
-            if (k == 0 || k == 8) continue;
-            if (k == 6) { gp_literal(&fx, pool + off); off += 4; }
-            else { gp_emit_bases(c_bt, &fx, &bt, k, pool + off); off += k; }
-        }
+    GBits fx = g->fx[i], bt = g->bt[i], dc = g->dc[i];
+    const GCode *c_bt = &codes[GC_BT], *c_dc = &codes[GC_DC];
+    const int32_t lo = g->dc_lo, hi = g->dc_hi;
+    const int sh_dc = g->dc_shift & 31, sh_unk = g->unk_shift & 31;
+    GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
+    const GP_G uint32_t *ents = g->pinfo + q->blk_first;
+    const uint32_t n = q->nblocks;
+    uint32_t next = n ? ents[0] : 0u;
+    for (uint32_t e = 0; e < n; ++e) {
+        const uint32_t ent = next;
+        if (e + 1 < n) next = ents[e + 1];                              /* requested one block ahead */
+        const uint32_t mode = ent >> 30;
+        if (mode == GP_MODE_NONE) continue;
+        GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
+        const uint32_t nb = (ent >> 22) & 0xFFu;
+        if (mode == GP_MODE_LITERAL) { gp_literal(&fx, dst); continue; }
+        if (mode == GP_MODE_BASES) { gp_emit_bases(c_bt, &fx, &bt, nb, dst); continue; }
+        gp_emit_bases(c_bt, &fx, &bt, nb, dst + 2);
+        const int32_t s1 = gsym_sovf(c_dc, &dc, lo, hi);                /* h4m:1405-1406 */
+        const int32_t s2 = gsym_sovf(c_dc, &dc, lo, hi);
+        GP_ST(dst[0], (uint32_t)(s1 >> sh_dc) << sh_unk);
+        GP_ST(dst[1], (uint32_t)(s2 >> sh_dc));
     }
 }
 
@@ -685,7 +792,7 @@ GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
             count = (uint32_t)gsym_uovf(c, &b);
         }
         --count;
-        g->mbtype[m] = (uint8_t)value;
+        GP_ST(g->mbtype[m], (uint8_t)value);
         inter += value != 0;
     }
     /* proc value of the n-th inter macroblock from the mproc runs (h4m:1649-1668); same lane, so that exactly as
@@ -696,7 +803,7 @@ GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
     for (uint32_t m = 0; m < inter; ++m) {
         if (count == 0) { value ^= 1u; count = (uint32_t)gsym_uovf(c, &b); }
         --count;
-        g->procseq[m] = (uint8_t)value;
+        GP_ST(g->procseq[m], (uint8_t)value);
     }
 }
 
@@ -717,7 +824,7 @@ GP_FN void gp_tags_scan(GPic *g, int nthr)
 {
     if (g->status) return;
     uint32_t run = 0;
-    for (int t = 0; t < nthr; ++t) { const uint32_t c = g->part[t]; g->part[t] = run; run += c; }
+    for (int t = 0; t < nthr; ++t) { const uint32_t c = g->part[t]; GP_ST(g->part[t], run); run += c; }
 }
 
 /* parallel T3: tag of every macroblock; proc-1 macroblocks get their tag into all block types (h4m:1670-1690) */
@@ -761,10 +868,12 @@ GP_FN void gp_pbkinds(GPic *g, const GCode *codes, int which)
     GBits bn = g->bn[which], bnr = g->bnr[which];
     const GCode *c_bn = &codes[GC_BN], *c_run = &codes[GC_RUN];
     const GPlane *q = &g->pl[which];
-    uint32_t rl = 0, m = 0;
+    uint32_t rl = 0;
+    GBytes tags;
+    gby_init(&tags, g->mbtag);
     for (int my = 0; my < g->mh; ++my)
-        for (int mx = 0; mx < g->mw; ++mx, ++m) {
-            const uint32_t tag = g->mbtag[m];
+        for (int mx = 0; mx < g->mw; ++mx) {
+            const uint32_t tag = gby_next(&tags);
             if (tag & 0x10u) continue;                                  /* proc 1: done by gp_tags_assign */
             for (int j = 0; j < q->nblk; ++j) {
                 const int by = my * q->by_per + gp_dy(j), bx = mx * q->bx_per + gp_dx(j);
@@ -776,8 +885,8 @@ GP_FN void gp_pbkinds(GPic *g, const GCode *codes, int which)
                     else if (which == 0) tu = tag | (uint32_t)k;
                     else { tu = tag | ((uint32_t)k & 0xFu); tv = tag | (((uint32_t)k >> 4) & 0xFu); }
                 }
-                if (which == 0) gp_map_ent(g, 0, by, bx)[1] = (uint8_t)tu;
-                else { gp_map_ent(g, 1, by, bx)[1] = (uint8_t)tu; gp_map_ent(g, 2, by, bx)[1] = (uint8_t)tv; }
+                if (which == 0) GP_ST(gp_map_ent(g, 0, by, bx)[1], (uint8_t)tu);
+                else { GP_ST(gp_map_ent(g, 1, by, bx)[1], (uint8_t)tu); GP_ST(gp_map_ent(g, 2, by, bx)[1], (uint8_t)tv); }
             }
         }
 }
@@ -790,49 +899,18 @@ GP_FN void gp_pbdc(GPic *g, const GCode *codes, int i)
     GBits dc = g->dc[i];
     const GCode *c_dc = &codes[GC_DC];
     const int32_t lo = g->dc_lo, hi = g->dc_hi;
-    uint32_t pbdc = 0x7F, m = 0;
+    uint32_t pbdc = 0x7F;
+    GBytes types;
+    gby_init(&types, g->mbtype);
     for (int my = 0; my < g->mh; ++my)
-        for (int mx = 0; mx < g->mw; ++mx, ++m) {
-            if (g->mbtype[m]) { pbdc = 0x7F; continue; }
+        for (int mx = 0; mx < g->mw; ++mx) {
+            if (gby_next(&types)) { pbdc = 0x7F; continue; }
             for (int j = 0; j < q->nblk; ++j) {
                 pbdc += (uint32_t)gsym_sovf(c_dc, &dc, lo, hi);
-                gp_map_ent(g, i, my * q->by_per + gp_dy(j), mx * q->bx_per + gp_dx(j))[0] = (uint8_t)pbdc;
+                GP_ST(gp_map_ent(g, i, my * q->by_per + gp_dy(j), mx * q->bx_per + gp_dx(j))[0], (uint8_t)pbdc);
             }
         }
     g->dc[i] = dc;
-}
-
-/* chain: payloads of plane i of a P/B picture, macroblock order (h4m:1789-1827, 1862-1910, 1919-1967) */
-GP_FN void gp_pbpayload(GPic *g, const GCode *codes, int i)
-{
-    if (g->status) return;
-    const GPlane *q = &g->pl[i];
-    GBits fx = g->fx[i], bt = g->bt[i], dc = g->dc[i];
-    const GCode *c_bt = &codes[GC_BT], *c_dc = &codes[GC_DC];
-    const int32_t lo = g->dc_lo, hi = g->dc_hi;
-    const int sh_dc = g->dc_shift & 31, sh_unk = g->unk_shift & 31;
-    uint32_t *pool = (uint32_t *)(g->blob + g->fixed_bytes);
-    const uint32_t *blk_off = g->blk_off + q->blk_first;
-    uint32_t m = 0;
-    for (int my = 0; my < g->mh; ++my)
-        for (int mx = 0; mx < g->mw; ++mx, ++m) {
-            const uint32_t tag = g->mbtag[m];
-            const int inter = (tag & 0x60u) != 0;
-            if (tag & 0x10u) continue;                                  /* proc 1: plain MC, no payload (h4m:1327-1355) */
-            for (int j = 0; j < q->nblk; ++j) {
-                const int by = my * q->by_per + gp_dy(j), bx = mx * q->bx_per + gp_dx(j);
-                const uint32_t k = gp_map_ent(g, i, by, bx)[1] & 0xFu;
-                if (k == 0 || (!inter && k == 8)) continue;
-                uint32_t *dst = pool + blk_off[(uint32_t)by * (uint32_t)q->hb + (uint32_t)bx];
-                if (k == 6) { gp_literal(&fx, dst); continue; }
-                if (!inter) { gp_emit_bases(c_bt, &fx, &bt, k, dst); continue; }
-                gp_emit_bases(c_bt, &fx, &bt, k - 1, dst + 2);
-                const int32_t s1 = gsym_sovf(c_dc, &dc, lo, hi);        /* h4m:1405-1406 */
-                const int32_t s2 = gsym_sovf(c_dc, &dc, lo, hi);
-                dst[0] = (uint32_t)(s1 >> sh_dc) << sh_unk;
-                dst[1] = (uint32_t)(s2 >> sh_dc);
-            }
-        }
 }
 
 /* chain: one motion-vector component (comp 0: x from mvh, 1: y from mvv) of every inter macroblock
@@ -842,13 +920,15 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp)
     if (g->status) return 0;
     GBits b = comp ? g->mvv : g->mvh;
     const GCode *c = &codes[GC_MV];
-    int16_t *mvs = (int16_t *)(g->blob + g->mv_off);
+    GP_G int16_t *mvs = (GP_G int16_t *)(g->blob + g->mv_off);
     int cur_ref = -1;
     int32_t acc = 0;
     uint32_t fl = 0, m = 0;
+    GBytes types;
+    gby_init(&types, g->mbtype);
     for (int my = 0; my < g->mh; ++my)
         for (int mx = 0; mx < g->mw; ++mx, ++m) {
-            const int t = g->mbtype[m];
+            const int t = (int)gby_next(&types);
             if (t == 0) continue;
             const int r = t - 1;
             if (r != cur_ref) { cur_ref = r; acc = 0; }
@@ -862,13 +942,13 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp)
             int32_t pos = (comp ? my : mx) * 16 + acc;
             if (pos > 32767) { pos = 32767; fl |= HVQ_F_CLAMPED; }
             if (pos < -32768) { pos = -32768; fl |= HVQ_F_CLAMPED; }
-            mvs[2 * m + (uint32_t)comp] = (int16_t)pos;
+            GP_ST(mvs[2 * m + (uint32_t)comp], (int16_t)pos);
         }
     return fl;
 }
 
 /* serial (thread 0): result record */
-GP_FN void gp_result(const GPic *g, HvqParseResult *out, uint32_t extra_flags)
+GP_FN void gp_result(const GPic *g, GP_G HvqParseResult *out, uint32_t extra_flags)
 {
     out->status = g->status;
     out->flags = g->flags | extra_flags | (g->is15 ? HVQ_F_IS15 : 0u) | (g->landscape ? HVQ_F_LANDSCAPE : 0u);

@@ -35,9 +35,10 @@
 #include "hvq_gparse_core.h"
 
 extern "C" hipError_t hvq_launch_parse(const HvqParseJob *jobs_dev, HvqParseResult *results_dev, uint32_t n,
-                                       uint32_t rowbuf_stride, hipStream_t stream);
+                                       uint32_t rowbuf_stride, uint64_t *timing_dev, hipStream_t stream);
 extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t n, hipStream_t stream);
 extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
+extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
                                        uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
@@ -534,7 +535,14 @@ static int device_parse(HvqContext *c)
     }
     HIPCHK(hipMemcpyAsync(c->pj_dev, jobs.data(), jobs.size() * sizeof(HvqParseJob), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, c->stream));
+    /* HVQM4_AMD_PARSE_TIMING=1: per-phase times of the parse kernel (development aid, prints to stderr) */
+    static const bool want_timing = getenv("HVQM4_AMD_PARSE_TIMING") != nullptr;
+    uint64_t *timing_dev = nullptr;
+    if (want_timing) {
+        HIPCHK(hipMalloc((void **)&timing_dev, jobs.size() * 8 * sizeof(uint64_t)));
+        HIPCHK(hipMemsetAsync(timing_dev, 0, jobs.size() * 8 * sizeof(uint64_t), c->stream));
+    }
+    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, timing_dev, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     std::vector<HvqParseResult> res(idx.size());
     HIPCHK(hipMemcpyAsync(res.data(), c->pr_dev, res.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
@@ -542,6 +550,38 @@ static int device_parse(HvqContext *c)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->gpu_parse_ms = ms;
+    if (timing_dev) {
+        std::vector<uint64_t> tm(jobs.size() * 8);
+        HIPCHK(hipMemcpy(tm.data(), timing_dev, tm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipFree(timing_dev));
+        static const char *names[3][6] = {
+            { "setup+trees", "", "chains kinds/DC", "nest+run sums", "scan+entries", "chains payload" },
+            { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains payload/MV" },
+            { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains payload/MV" } };
+        double sum[3][6] = {}; size_t cnt[3] = {}; uint64_t t_min = ~0ull, t_max = 0;
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            const uint64_t *t = &tm[8 * k];
+            const int kind = (int)c->pending[idx[k]].kind;
+            uint64_t prev = t[0];
+            for (int ph = 1; ph <= 6; ++ph) { if (!t[ph]) continue; sum[kind][ph - 1] += (double)(t[ph] - prev) * 0.01; prev = t[ph]; }
+            cnt[kind]++; t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[6]);
+        }
+        uint64_t s_max = 0, d_min = ~0ull, d_max = 0;
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            const uint64_t *t = &tm[8 * k];
+            s_max = std::max(s_max, t[0]); d_min = std::min(d_min, t[6] - t[0]); d_max = std::max(d_max, t[6] - t[0]);
+        }
+        fprintf(stderr, "hvqm4_amd parse occupancy: %d workgroups per CU (runtime query)\n", hvq_parse_occupancy(rowbuf));
+        fprintf(stderr, "hvqm4_amd parse timing: %zu pictures, kernel %.3f ms, first start -> last end %.3f ms, last start +%.3f ms, "
+                "per picture %.3f .. %.3f ms\n",
+                jobs.size(), ms, (double)(t_max - t_min) * 1e-5, (double)(s_max - t_min) * 1e-5, (double)d_min * 1e-5, (double)d_max * 1e-5);
+        for (int kind = 0; kind < 3; ++kind) {
+            if (!cnt[kind]) continue;
+            fprintf(stderr, "  %c pictures (%zu): ", "IPB"[kind], cnt[kind]);
+            for (int ph = 0; ph < 6; ++ph) if (names[kind][ph][0]) fprintf(stderr, "%s %.1f us | ", names[kind][ph], sum[kind][ph] / (double)cnt[kind]);
+            fprintf(stderr, "\n");
+        }
+    }
     for (size_t k = 0; k < idx.size(); ++k) {
         Pending &p = c->pending[idx[k]];
         if (res[k].status)

@@ -58,7 +58,8 @@ int gparse_emul(const uint8_t *pic, uint32_t len, int frame_type, int w, int h, 
         for (int t = 0; t < NTHR; ++t) gp_nest(g, t, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_layout_sum(g, t, NTHR);
         gp_layout_scan(g, NTHR);
-        for (int i = 0; i < 3; ++i) gp_ipayload(g, codes, i);
+        for (int t = 0; t < NTHR; ++t) gp_layout_blocks(g, t, NTHR);
+        for (int i = 0; i < 3; ++i) gp_payload(g, codes, i);
     } else {
         gp_mbtypes(g, codes);
         for (int t = 0; t < NTHR; ++t) gp_tags_count(g, t, NTHR);
@@ -70,7 +71,7 @@ int gparse_emul(const uint8_t *pic, uint32_t len, int frame_type, int w, int h, 
         for (int t = 0; t < NTHR; ++t) gp_layout_sum(g, t, NTHR);
         gp_layout_scan(g, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_layout_blocks(g, t, NTHR);
-        for (int i = 0; i < 3; ++i) gp_pbpayload(g, codes, i);
+        for (int i = 0; i < 3; ++i) gp_payload(g, codes, i);
         extra |= gp_mvs(g, codes, 0);
         extra |= gp_mvs(g, codes, 1);
     }
