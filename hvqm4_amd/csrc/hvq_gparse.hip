@@ -6,10 +6,12 @@
  *   all pictures : setup + section cursors (thread 0) | maps/MVs/tree tables cleared (all threads) |
  *                  prefix trees read, one per wave (lane 0) | first-level tables filled (all threads)
  *   I picture    : 5 chains (kinds Y, kinds UV, DC Y, DC U, DC V) | nest + run sums (all) | run scan, header (thread 0) |
- *                  payload entries (all) | 3 chains (payload Y, U, V)
+ *                  payload entries, fixed-length offsets, compaction (all) | 3 chains (coefficient symbols Y, U, V) |
+ *                  basis words merged in, literal blocks copied (all)
  *   P/B picture  : 1 chain (macroblock types, procs) | inter ranks + tags (all, 3 steps) |
  *                  5 chains (kinds Y, kinds UV, DC Y, DC U, DC V) | run sums (all) | run scan, header (thread 0) |
- *                  payload entries (all) | 5 chains (payload Y, U, V, MV x, MV y)
+ *                  payload entries, fixed-length offsets, compaction (all) | 5 chains (coefficient symbols Y, U, V,
+ *                  MV x, MV y) | basis words merged in, literal blocks copied (all)
  * A chain runs wave-uniform (all lanes compute the same values, so its cursors and counters live in scalar registers
  * and its logic runs on the scalar unit; one lane does the stores); the four waves of a workgroup run different
  * chains at the same time and 8 workgroups share a CU, so the serial bit-level work of thousands of pictures overlaps.
@@ -72,6 +74,12 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         __syncthreads();
         gp_layout_blocks(&g, tid, GPW);
         __syncthreads();
+        gp_emit_count(&g, tid, GPW);
+        __syncthreads();
+        if (wave == 0) gp_emit_scan(&g, GPW);
+        __syncthreads();
+        gp_emit_compact(&g, tid, GPW);
+        __syncthreads();
         GP_STAMP(5);
         if (wave == 0) gp_payload(&g, codes, 0);
         else if (wave == 1) { gp_payload(&g, codes, 1); gp_payload(&g, codes, 2); }
@@ -97,6 +105,12 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         __syncthreads();
         gp_layout_blocks(&g, tid, GPW);
         __syncthreads();
+        gp_emit_count(&g, tid, GPW);
+        __syncthreads();
+        if (wave == 0) gp_emit_scan(&g, GPW);
+        __syncthreads();
+        gp_emit_compact(&g, tid, GPW);
+        __syncthreads();
         GP_STAMP(5);
         if (wave == 0) gp_payload(&g, codes, 0);
         else if (wave == 1) { gp_payload(&g, codes, 1); gp_payload(&g, codes, 2); }
@@ -107,6 +121,9 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
     }
     __syncthreads();
     GP_STAMP(6);
+    gp_emit_merge(&g, tid, GPW);
+    __syncthreads();
+    GP_STAMP(7);
     if (tid == 0) gp_result(&g, (GP_G HvqParseResult *)(results + blockIdx.x), g.part[GP_MISC + 13] | g.part[GP_MISC + 14]);
 #undef GP_STAMP
 }

@@ -90,7 +90,7 @@ typedef struct HvqParseResult {   /* what the host needs back to size and order 
  * instead of one per 4.  (Keeping look-ahead dwords in registers does not work: the compiler's register copies of a
  * freshly requested dword make it wait for the load on the spot.) */
 #define GP_BLK 32
-#define GP_SLOTS 17
+#define GP_SLOTS 14
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 __shared__ uint32_t gp_stage[GP_SLOTS * GP_BLK];
@@ -285,6 +285,7 @@ typedef struct {
     GPlane pl[3];
     uint32_t mv_off, wave_base_off, fixed_bytes, pic_bytes, total_tiles, total_runs, total_blocks;
     /* scratch */
+    GP_G uint32_t *clist;        /* [total_blocks] the entries that carry bases, compacted, per plane in consumption order */
     GP_G uint32_t *pinfo;        /* [total_blocks] payload entry of every block, in CONSUMPTION order (GP_ENT) */
     GP_G uint16_t *run_items;    /* [total_runs] */
     GP_G uint16_t *run_pairs;    /* [total_runs] */
@@ -298,14 +299,18 @@ typedef struct {
     uint8_t res[8];              /* h0 h1 v0 v1 0 0 (h4m:2023-2026; indexed by reference 0..2 like hvq_parse.c) */
     uint32_t flags, status;
     uint32_t max_items, max_pairs, pool_dwords, total, nest_off;
-    GBits bn[2], bnr[2], dc[3], bt[3], rle[3], fx[3], mvh, mvv, mtype, mproc;
+    uint64_t fx_off[3];          /* byte offset of the fixed-length sections (basis words, literal blocks) */
+    uint32_t nchain[3];          /* entries in clist per plane */
+    GBits bn[2], bnr[2], dc[3], bt[3], rle[3], mvh, mvv, mtype, mproc;
 } GPic;
 
-/* part[]: [0, 512) one word per thread, [512, 992) a second word per thread, the rest single-purpose slots */
-#define GP_PART 1024
+/* part[]: [0, 512) one word per thread, [512, 992) a second word per thread, [992, 1024) single-purpose slots,
+ * [1024, 4096) GP_EP: per plane and thread, the partial sums of the payload emission */
+#define GP_PART 4096
 #define GP_PART2 512
 #define GP_MISC 992
 #define GP_MAX_THREADS 480
+#define GP_EP(plane, which, tid) (1024 + ((plane) * 2 + (which)) * 512 + (tid))
 
 GP_FN uint32_t gp_be32(const GPic *g, uint64_t off)
 {
@@ -322,7 +327,7 @@ GP_FN uint32_t gp_byte(const GPic *g, uint32_t off) { return (gp_be32(g, off & ~
 /* bytes of scratch one picture of this geometry needs */
 GP_FN uint32_t gp_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb)
 {
-    return GP_ALIGN16(4u * total_blocks) + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb + 16u) * 3u + 4u * GP_PART;
+    return GP_ALIGN16(4u * total_blocks) * 2u + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb + 16u) * 3u + 4u * GP_PART;
 }
 
 /* serial (thread 0): geometry exactly as hvq_parser_create lays the blob out */
@@ -369,6 +374,7 @@ GP_FN void gp_setup(GPic *g, const HvqParseJob *job)
     const uint32_t nmb = (uint32_t)g->mw * (uint32_t)g->mh;
     GP_G uint8_t *s = (GP_G uint8_t *)(uintptr_t)job->scratch;
     g->pinfo = (GP_G uint32_t *)s;       s += GP_ALIGN16(4u * blocks);
+    g->clist = (GP_G uint32_t *)s;       s += GP_ALIGN16(4u * blocks);
     g->run_items = (GP_G uint16_t *)s;   s += GP_ALIGN16(2u * runs);
     g->run_pairs = (GP_G uint16_t *)s;   s += GP_ALIGN16(2u * runs);
     g->mbtype = s;                       s += GP_ALIGN16(nmb + 16u);
@@ -410,7 +416,7 @@ GP_FN void gp_sections(GPic *g)
     } else {
         g->nx = (int)(gp_be32(g, 4) >> 16); g->ny = (int)(gp_be32(g, 4) & 0xFFFFu);
     }
-    /* staging slots: bn 0-1, bnr 2-3, dc 4-6, bt 7-9, fx 10-12, then rle 13-15 (I) or mvh, mvv, mtype, mproc 13-16 (P/B) */
+    /* staging slots: bn 0-1, bnr 2-3, dc 4-6, bt 7-9, then rle 10-12 (I) or mvh, mvv, mtype, mproc 10-13 (P/B) */
     for (int i = 0; i < 2; ++i) {
         gp_section_bits(g, &g->bn[i], data, tab, 2 * i, (uint32_t)i);
         gp_section_bits(g, &g->bnr[i], data, tab, 2 * i + 1, 2u + (uint32_t)i);
@@ -418,15 +424,15 @@ GP_FN void gp_sections(GPic *g)
     for (int k = 0; k < 3; ++k) {
         gp_section_bits(g, &g->dc[k], data, tab, 4 + 3 * k, 4u + (uint32_t)k);
         gp_section_bits(g, &g->bt[k], data, tab, 5 + 3 * k, 7u + (uint32_t)k);
-        gp_section_bits(g, &g->fx[k], data, tab, 6 + 3 * k, 10u + (uint32_t)k);
+        { int live; g->fx_off[k] = gp_section(g, data, tab, 6 + 3 * k, &live); }
     }
     if (g->is_pb) {
-        gp_section_bits(g, &g->mvh, data, tab, 13, 13u);
-        gp_section_bits(g, &g->mvv, data, tab, 14, 14u);
-        gp_section_bits(g, &g->mtype, data, tab, 15, 15u);
-        gp_section_bits(g, &g->mproc, data, tab, 16, 16u);
+        gp_section_bits(g, &g->mvh, data, tab, 13, 10u);
+        gp_section_bits(g, &g->mvv, data, tab, 14, 11u);
+        gp_section_bits(g, &g->mtype, data, tab, 15, 12u);
+        gp_section_bits(g, &g->mproc, data, tab, 16, 13u);
     } else {
-        for (int k = 0; k < 3; ++k) gp_section_bits(g, &g->rle[k], data, tab, 13 + k, 13u + (uint32_t)k);
+        for (int k = 0; k < 3; ++k) gp_section_bits(g, &g->rle[k], data, tab, 13 + k, 10u + (uint32_t)k);
     }
     g->dc_hi = (int32_t)((uint32_t)0x7F << (g->dc_shift & 31));
     g->dc_lo = (int32_t)((uint32_t)-0x80 << (g->dc_shift & 31));
@@ -722,51 +728,136 @@ GP_FN void gp_layout_blocks(GPic *g, int tid, int nthr)
 }
 
 /* ------------------------------------------------------------------ payloads */
-/* `n` bases of one block: word from fixvl, coefficient from bufTree0 (h4m:691-692, 726-731 / 738-739, 767-772) */
-GP_FN void gp_emit_bases(const GCode *c_bt, GBits *fx, GBits *bt, uint32_t n, GP_G uint32_t *dst)
+/* The payload of a block interleaves two sources in the reference: fixed-length data (16-bit basis words, 16-byte
+ * literal blocks; h4m:543-549, 691-692) whose position is a prefix sum over the blocks before it, and the coefficient
+ * symbols of bufTree0 plus, for MC-residual blocks, two DC-buffer values (h4m:726-731, 1405-1406), which only a serial
+ * decode can find.  So the chain decodes nothing but symbols -- it leaves the RUNNING COEFFICIENT SUM of every basis in
+ * the basis' pool slot -- and all threads afterwards merge the words in (gp_emit_*). */
+GP_FN uint32_t gp_ent_fx_bytes(uint32_t ent)
 {
-    uint32_t run = 0;
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t word = gb_take(fx, 16);
-        run += (uint32_t)gsym(c_bt, bt);
-        GP_ST(dst[k], HVQ_BASIS(word, (run + ((word >> 13) & 3u)) & 0x3FFFFu));
+    const uint32_t mode = ent >> 30;
+    return mode == GP_MODE_LITERAL ? 16u : (mode >= GP_MODE_BASES ? 2u * ((ent >> 22) & 0xFFu) : 0u);
+}
+
+GP_FN void gp_chunk(uint32_t n, int tid, int nthr, uint32_t *lo, uint32_t *hi)
+{
+    const uint32_t per = (n + (uint32_t)nthr - 1) / (uint32_t)nthr;
+    *lo = per * (uint32_t)tid < n ? per * (uint32_t)tid : n;
+    *hi = *lo + per < n ? *lo + per : n;
+}
+
+/* parallel E1: per thread chunk of each plane's entries: fixed-length bytes, entries with bases */
+GP_FN void gp_emit_count(GPic *g, int tid, int nthr)
+{
+    if (g->status) return;
+    for (int i = 0; i < 3; ++i) {
+        const GP_G uint32_t *ents = g->pinfo + g->pl[i].blk_first;
+        uint32_t lo, hi, bytes = 0, cnt = 0;
+        gp_chunk(g->pl[i].nblocks, tid, nthr, &lo, &hi);
+        for (uint32_t e = lo; e < hi; ++e) { const uint32_t ent = ents[e]; bytes += gp_ent_fx_bytes(ent); cnt += (ent >> 30) >= GP_MODE_BASES; }
+        g->part[GP_EP(i, 0, tid)] = bytes;
+        g->part[GP_EP(i, 1, tid)] = cnt;
     }
 }
 
-GP_FN void gp_literal(GBits *fx, GP_G uint32_t *dst)                                 /* h4m:543-549 */
+/* serial E2: exclusive scans of the chunk sums */
+GP_FN void gp_emit_scan(GPic *g, int nthr)
 {
-    for (int k = 0; k < 4; ++k) { const uint32_t v = __builtin_bswap32(gb_take(fx, 32)); GP_ST(dst[k], v); }
+    if (g->status) return;
+    for (int i = 0; i < 3; ++i) {
+        uint32_t bytes = 0, cnt = 0;
+        for (int t = 0; t < nthr; ++t) {
+            const uint32_t b = g->part[GP_EP(i, 0, t)], c = g->part[GP_EP(i, 1, t)];
+            GP_ST(g->part[GP_EP(i, 0, t)], bytes); GP_ST(g->part[GP_EP(i, 1, t)], cnt);
+            bytes += b; cnt += c;
+        }
+        g->nchain[i] = cnt;
+    }
 }
 
-/* chain: payloads of plane i, I and P/B alike: walk the plane's entries in consumption order.  Intra blocks: bases
- * (h4m:1789-1827); literal blocks (h4m:543-549); MC-residual blocks: bases, then the two scalars from the DC
- * buffer, whose cursor gp_pbdc left behind (h4m:1862-1910, 1405-1406). */
+/* parallel E3: compact the entries that carry bases (what the chain walks) */
+GP_FN void gp_emit_compact(GPic *g, int tid, int nthr)
+{
+    if (g->status) return;
+    for (int i = 0; i < 3; ++i) {
+        const GP_G uint32_t *ents = g->pinfo + g->pl[i].blk_first;
+        GP_G uint32_t *out = g->clist + g->pl[i].blk_first;
+        uint32_t lo, hi, at = g->part[GP_EP(i, 1, tid)];
+        gp_chunk(g->pl[i].nblocks, tid, nthr, &lo, &hi);
+        for (uint32_t e = lo; e < hi; ++e) { const uint32_t ent = ents[e]; if ((ent >> 30) >= GP_MODE_BASES) out[at++] = ent; }
+    }
+}
+
+/* chain: coefficient symbols of plane i, I and P/B alike; MC-residual blocks also take their two scalars from the DC
+ * buffer, whose cursor gp_pbdc left behind (h4m:1862-1910, 1405-1406) */
 GP_FN void gp_payload(GPic *g, const GCode *codes, int i)
 {
     if (g->status) return;
-    const GPlane *q = &g->pl[i];
-    GBits fx = g->fx[i], bt = g->bt[i], dc = g->dc[i];
+    GBits bt = g->bt[i], dc = g->dc[i];
     const GCode *c_bt = &codes[GC_BT], *c_dc = &codes[GC_DC];
     const int32_t lo = g->dc_lo, hi = g->dc_hi;
     const int sh_dc = g->dc_shift & 31, sh_unk = g->unk_shift & 31;
     GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
-    const GP_G uint32_t *ents = g->pinfo + q->blk_first;
-    const uint32_t n = q->nblocks;
+    const GP_G uint32_t *ents = g->clist + g->pl[i].blk_first;
+    const uint32_t n = g->nchain[i];
     uint32_t next = n ? ents[0] : 0u;
     for (uint32_t e = 0; e < n; ++e) {
         const uint32_t ent = next;
-        if (e + 1 < n) next = ents[e + 1];                              /* requested one block ahead */
-        const uint32_t mode = ent >> 30;
-        if (mode == GP_MODE_NONE) continue;
-        GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
+        if (e + 1 < n) next = ents[e + 1];                              /* requested one entry ahead */
         const uint32_t nb = (ent >> 22) & 0xFFu;
-        if (mode == GP_MODE_LITERAL) { gp_literal(&fx, dst); continue; }
-        if (mode == GP_MODE_BASES) { gp_emit_bases(c_bt, &fx, &bt, nb, dst); continue; }
-        gp_emit_bases(c_bt, &fx, &bt, nb, dst + 2);
-        const int32_t s1 = gsym_sovf(c_dc, &dc, lo, hi);                /* h4m:1405-1406 */
-        const int32_t s2 = gsym_sovf(c_dc, &dc, lo, hi);
-        GP_ST(dst[0], (uint32_t)(s1 >> sh_dc) << sh_unk);
-        GP_ST(dst[1], (uint32_t)(s2 >> sh_dc));
+        GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
+        if ((ent >> 30) == GP_MODE_PREDI) {
+            dst += 2;
+            uint32_t run = 0;
+            for (uint32_t k = 0; k < nb; ++k) { run += (uint32_t)gsym(c_bt, &bt); GP_ST(dst[k], run); }
+            const int32_t s1 = gsym_sovf(c_dc, &dc, lo, hi);            /* h4m:1405-1406 */
+            const int32_t s2 = gsym_sovf(c_dc, &dc, lo, hi);
+            GP_ST(dst[-2], (uint32_t)(s1 >> sh_dc) << sh_unk);
+            GP_ST(dst[-1], (uint32_t)(s2 >> sh_dc));
+        } else {
+            uint32_t run = 0;
+            for (uint32_t k = 0; k < nb; ++k) { run += (uint32_t)gsym(c_bt, &bt); GP_ST(dst[k], run); }
+        }
+    }
+}
+
+GP_FN uint32_t gp_be16(const GPic *g, uint64_t off)
+{
+    if (off + 2 > g->len) return 0;
+    const uint32_t i = (uint32_t)(off >> 2), sh = (uint32_t)(off & 3u);
+    const uint32_t w0 = __builtin_bswap32(g->d[i]);
+    if (sh < 3) return (w0 >> (16 - 8 * sh)) & 0xFFFFu;
+    const uint32_t w1 = i + 1 < g->nd ? __builtin_bswap32(g->d[i + 1]) : 0u;
+    return ((w0 & 0xFFu) << 8) | (w1 >> 24);
+}
+
+/* parallel E4, after the chains: basis word + running sum -> basis dword (h4m:726-731), literal blocks copied */
+GP_FN void gp_emit_merge(GPic *g, int tid, int nthr)
+{
+    if (g->status) return;
+    GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
+    for (int i = 0; i < 3; ++i) {
+        const GP_G uint32_t *ents = g->pinfo + g->pl[i].blk_first;
+        uint32_t lo, hi;
+        gp_chunk(g->pl[i].nblocks, tid, nthr, &lo, &hi);
+        uint64_t fx = g->fx_off[i] + g->part[GP_EP(i, 0, tid)];
+        for (uint32_t e = lo; e < hi; ++e) {
+            const uint32_t ent = ents[e], mode = ent >> 30;
+            if (mode == GP_MODE_NONE) continue;
+            GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
+            if (mode == GP_MODE_LITERAL) {
+                for (int k = 0; k < 4; ++k) dst[k] = __builtin_bswap32(gp_be32(g, fx + 4u * (uint32_t)k));
+                fx += 16;
+                continue;
+            }
+            const uint32_t nb = (ent >> 22) & 0xFFu;
+            if (mode == GP_MODE_PREDI) dst += 2;
+            for (uint32_t k = 0; k < nb; ++k) {
+                const uint32_t word = gp_be16(g, fx + 2u * k);
+                dst[k] = HVQ_BASIS(word, (dst[k] + ((word >> 13) & 3u)) & 0x3FFFFu);
+            }
+            fx += 2u * nb;
+        }
     }
 }
 

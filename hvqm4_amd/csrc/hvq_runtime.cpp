@@ -130,6 +130,7 @@ struct HvqContext {
     /* staging: pinned host arena mirrored by a device arena */
     uint8_t *host_arena = nullptr, *dev_arena = nullptr;
     size_t arena_cap = 0, arena_used = 0;
+    size_t arena_uploaded = 0;         /* [0, arena_uploaded) is already on its way to dev_arena (early H2D of bitstreams) */
     std::vector<Pending> pending;
     /* last flushed batch (kept resident for hvq_replay) */
     HvqJob *jobs_dev = nullptr;
@@ -167,6 +168,7 @@ static int arena_reserve(HvqContext *c, size_t need)
         HIPCHK(hipFree(c->dev_arena));
     }
     c->host_arena = nh; c->dev_arena = nd; c->arena_cap = ncap;
+    c->arena_uploaded = 0;             /* the new device arena holds nothing yet */
     return HVQ_OK;
 }
 
@@ -450,6 +452,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
     HIPCHK(hipSetDevice(c->device));
     int rc = arena_reserve(c, need);
     if (rc) return rc;
+    std::vector<size_t> offs((size_t)n);
     for (int i = 0; i < n; ++i) {
         Stream &s = c->streams[(size_t)streams[i]];
         if (s.parse_mode == 0) {
@@ -463,13 +466,11 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
             HIPCHK(hipMalloc((void **)&s.nest_keep, 2 * GP_ALIGN16(HVQ_NESTP_BYTES)));
             HIPCHK(hipMemsetAsync(s.nest_keep, 0, 2 * GP_ALIGN16(HVQ_NESTP_BYTES), c->stream));
         }
-        const size_t off = c->arena_used, span = align_up(lens[i] + 16, 256);
-        memcpy(c->host_arena + off, pics[i], lens[i]);
-        memset(c->host_arena + off + lens[i], 0, span - lens[i]);       /* the device reader sees zeros past the end */
-        c->arena_used = off + span;
+        offs[(size_t)i] = c->arena_used;
+        c->arena_used += align_up(lens[i] + 16, 256);
         Pending q{};
         q.dev = true;
-        q.blob_off = off; q.blob_len = lens[i];
+        q.blob_off = offs[(size_t)i]; q.blob_len = lens[i];
         q.ntiles = s.layout.tile_first[3];
         q.kind = frame_types[i] == HVQ_FRAME_I ? HVQ_PIC_I : (frame_types[i] == HVQ_FRAME_P ? HVQ_PIC_P : HVQ_PIC_B);
         q.w = s.layout.width; q.h = s.layout.height;
@@ -481,6 +482,39 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
             c->pending.back().nest_ref = s.nest_src;
         }
         if (ordinals) ordinals[i] = ord;
+    }
+    /* bitstreams -> pinned arena -> HBM, pipelined: a few threads copy a chunk of pictures (zero padded: the device
+     * reader sees zeros past the end), its H2D is queued at once and runs while the next chunk is being copied */
+    auto copy_range = [&](int lo, int hi) {
+        for (int i = lo; i < hi; ++i) {
+            uint8_t *dst = c->host_arena + offs[(size_t)i];
+            const size_t span = align_up(lens[i] + 16, 256);
+            memcpy(dst, pics[i], lens[i]);
+            memset(dst + lens[i], 0, span - lens[i]);
+        }
+    };
+    const size_t chunk_bytes = (size_t)16 << 20;
+    const bool early = c->arena_uploaded == offs[0];          /* nothing older is waiting for the flush-time upload */
+    int lo = 0;
+    while (lo < n) {
+        int hi = lo;
+        size_t bytes = 0;
+        while (hi < n && bytes < chunk_bytes) { bytes += align_up(lens[hi] + 16, 256); ++hi; }
+        const int nt = bytes >= ((size_t)4 << 20) ? 4 : 1;
+        if (nt == 1) copy_range(lo, hi);
+        else {
+            std::vector<std::thread> pool;
+            const int per = (hi - lo + nt - 1) / nt;
+            for (int t = 1; t < nt; ++t) pool.emplace_back(copy_range, std::min(hi, lo + t * per), std::min(hi, lo + (t + 1) * per));
+            copy_range(lo, std::min(hi, lo + per));
+            for (auto &t : pool) t.join();
+        }
+        if (early) {
+            const size_t b0 = offs[(size_t)lo], b1 = hi < n ? offs[(size_t)hi] : c->arena_used;
+            HIPCHK(hipMemcpyAsync(c->dev_arena + b0, c->host_arena + b0, b1 - b0, hipMemcpyHostToDevice, c->stream));
+            c->arena_uploaded = b1;
+        }
+        lo = hi;
     }
     return HVQ_OK;
 }
@@ -554,22 +588,22 @@ static int device_parse(HvqContext *c)
         std::vector<uint64_t> tm(jobs.size() * 8);
         HIPCHK(hipMemcpy(tm.data(), timing_dev, tm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
         HIPCHK(hipFree(timing_dev));
-        static const char *names[3][6] = {
-            { "setup+trees", "", "chains kinds/DC", "nest+run sums", "scan+entries", "chains payload" },
-            { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains payload/MV" },
-            { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains payload/MV" } };
-        double sum[3][6] = {}; size_t cnt[3] = {}; uint64_t t_min = ~0ull, t_max = 0;
+        static const char *names[3][7] = {
+            { "setup+trees", "", "chains kinds/DC", "nest+run sums", "scan+entries", "chains coefficients", "merge words" },
+            { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains coefficients/MV", "merge words" },
+            { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains coefficients/MV", "merge words" } };
+        double sum[3][7] = {}; size_t cnt[3] = {}; uint64_t t_min = ~0ull, t_max = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
             const uint64_t *t = &tm[8 * k];
             const int kind = (int)c->pending[idx[k]].kind;
             uint64_t prev = t[0];
-            for (int ph = 1; ph <= 6; ++ph) { if (!t[ph]) continue; sum[kind][ph - 1] += (double)(t[ph] - prev) * 0.01; prev = t[ph]; }
-            cnt[kind]++; t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[6]);
+            for (int ph = 1; ph <= 7; ++ph) { if (!t[ph]) continue; sum[kind][ph - 1] += (double)(t[ph] - prev) * 0.01; prev = t[ph]; }
+            cnt[kind]++; t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[7]);
         }
         uint64_t s_max = 0, d_min = ~0ull, d_max = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
             const uint64_t *t = &tm[8 * k];
-            s_max = std::max(s_max, t[0]); d_min = std::min(d_min, t[6] - t[0]); d_max = std::max(d_max, t[6] - t[0]);
+            s_max = std::max(s_max, t[0]); d_min = std::min(d_min, t[7] - t[0]); d_max = std::max(d_max, t[7] - t[0]);
         }
         fprintf(stderr, "hvqm4_amd parse occupancy: %d workgroups per CU (runtime query)\n", hvq_parse_occupancy(rowbuf));
         fprintf(stderr, "hvqm4_amd parse timing: %zu pictures, kernel %.3f ms, first start -> last end %.3f ms, last start +%.3f ms, "
@@ -578,7 +612,7 @@ static int device_parse(HvqContext *c)
         for (int kind = 0; kind < 3; ++kind) {
             if (!cnt[kind]) continue;
             fprintf(stderr, "  %c pictures (%zu): ", "IPB"[kind], cnt[kind]);
-            for (int ph = 0; ph < 6; ++ph) if (names[kind][ph][0]) fprintf(stderr, "%s %.1f us | ", names[kind][ph], sum[kind][ph] / (double)cnt[kind]);
+            for (int ph = 0; ph < 7; ++ph) if (names[kind][ph][0]) fprintf(stderr, "%s %.1f us | ", names[kind][ph], sum[kind][ph] / (double)cnt[kind]);
             fprintf(stderr, "\n");
         }
     }
@@ -619,9 +653,12 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
     if (c->pending.empty()) return HVQ_OK;
     HIPCHK(hipSetDevice(c->device));
     /* 1. descriptors -> HBM (one copy) */
-    HIPCHK(hipMemcpyAsync(c->dev_arena, c->host_arena, c->arena_used, hipMemcpyHostToDevice, c->stream));
+    if (c->arena_used > c->arena_uploaded)
+        HIPCHK(hipMemcpyAsync(c->dev_arena + c->arena_uploaded, c->host_arena + c->arena_uploaded,
+                              c->arena_used - c->arena_uploaded, hipMemcpyHostToDevice, c->stream));
+    c->arena_uploaded = 0;
     /* 1b. streams parsed on the GPU: bitstreams -> blobs, one launch */
-    { int rc = device_parse(c); if (rc) { c->pending.clear(); c->arena_used = 0; for (auto &s : c->streams) s.nest_src = -1; return rc; } }
+    { int rc = device_parse(c); if (rc) { c->pending.clear(); c->arena_used = 0; c->arena_uploaded = 0; for (auto &s : c->streams) s.nest_src = -1; return rc; } }
     /* 2. job + tile tables, level by level, tiles dealt so that a picture stays on one XCD */
     int max_level = 0;
     for (auto &p : c->pending) max_level = std::max(max_level, p.level);

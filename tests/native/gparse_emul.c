@@ -59,6 +59,9 @@ int gparse_emul(const uint8_t *pic, uint32_t len, int frame_type, int w, int h, 
         for (int t = 0; t < NTHR; ++t) gp_layout_sum(g, t, NTHR);
         gp_layout_scan(g, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_layout_blocks(g, t, NTHR);
+        for (int t = 0; t < NTHR; ++t) gp_emit_count(g, t, NTHR);
+        gp_emit_scan(g, NTHR);
+        for (int t = 0; t < NTHR; ++t) gp_emit_compact(g, t, NTHR);
         for (int i = 0; i < 3; ++i) gp_payload(g, codes, i);
     } else {
         gp_mbtypes(g, codes);
@@ -71,10 +74,14 @@ int gparse_emul(const uint8_t *pic, uint32_t len, int frame_type, int w, int h, 
         for (int t = 0; t < NTHR; ++t) gp_layout_sum(g, t, NTHR);
         gp_layout_scan(g, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_layout_blocks(g, t, NTHR);
+        for (int t = 0; t < NTHR; ++t) gp_emit_count(g, t, NTHR);
+        gp_emit_scan(g, NTHR);
+        for (int t = 0; t < NTHR; ++t) gp_emit_compact(g, t, NTHR);
         for (int i = 0; i < 3; ++i) gp_payload(g, codes, i);
         extra |= gp_mvs(g, codes, 0);
         extra |= gp_mvs(g, codes, 1);
     }
+    for (int t = 0; t < NTHR; ++t) gp_emit_merge(g, t, NTHR);
     gp_result(g, res, extra);
     free(d); free(scratch); free(rowbuf); free(g); free(codes);
     return 0;

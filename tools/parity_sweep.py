@@ -1,6 +1,6 @@
 """GPU box: randomized parity sweep -- many synthetic clips (geometry, version, sampling, preset, GOP, shifts, ring
 size drawn from a seed) through the batched C-ABI path vs the CPU oracle, bit-exact.  Test infrastructure
-(uses oracle/); usage: python tools/parity_sweep.py [n_clips] [seed]."""
+(uses oracle/); usage: python tools/parity_sweep.py [n_clips] [seed] [host|gpu|both]  (which entropy parser)."""
 import os
 import sys
 import time
@@ -26,13 +26,17 @@ def draw(rng) -> SynthConfig:
         mv_res_bits=tuple(int(x) for x in rng.choice([0, 1, 2], 2)))
 
 
-def decode_last(ctx, data, nslots):
+def decode_last(ctx, data, nslots, gpu_parse=False):
     from hvqm4_amd.container import parse_header, video_pictures
     hdr = parse_header(data)
     sid = ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, nslots)
     last = -1
-    for ft, _disp, pic in video_pictures(data):
-        last = ctx.submit(sid, ft, pic)
+    pics = list(video_pictures(data))
+    if gpu_parse:
+        last = ctx.submit_many_device([sid] * len(pics), [p[0] for p in pics], [bytes(p[2]) for p in pics])[-1]
+    else:
+        for ft, _disp, pic in pics:
+            last = ctx.submit(sid, ft, pic)
     ctx.flush()
     out = ctx.read_picture(sid, last)
     ctx.close_stream(sid)
@@ -42,6 +46,7 @@ def decode_last(ctx, data, nslots):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    which = sys.argv[3] if len(sys.argv) > 3 else "host"
     ctx = batch.Context(0)
     bad = pics = 0
     t0 = time.time()
@@ -50,12 +55,15 @@ def main():
         clip = make_clip(cfg)
         want = bridge.oracle_decode(clip.data, clip.n_pictures)
         nslots = [None, 3, 4, 6][int(rng.integers(0, 4))]      # None: every picture stays resident
-        if nslots is None:
-            got = batch.decode_clip(ctx, clip.data)
-            ok = np.array_equal(got, want)
-        else:                                                  # small ring: only the last picture is guaranteed resident
-            got = decode_last(ctx, clip.data, nslots)
-            ok = np.array_equal(got, want[-1])
+        every = [None, 1, 3][int(rng.integers(0, 3))]          # flushes per clip (nest of the last I picture across batches)
+        ok = True
+        for gpu_parse in ([False, True] if which == "both" else [which == "gpu"]):
+            if nslots is None:
+                got = batch.decode_clip(ctx, clip.data, gpu_parse=gpu_parse, flush_every=every)
+                ok = ok and np.array_equal(got, want)
+            else:                                              # small ring: only the last picture is guaranteed resident
+                got = decode_last(ctx, clip.data, nslots, gpu_parse)
+                ok = ok and np.array_equal(got, want[-1])
         pics += clip.n_pictures
         if not ok:
             bad += 1
