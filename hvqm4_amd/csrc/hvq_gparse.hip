@@ -8,8 +8,9 @@
  *   I picture    : 5 chains (kinds Y, kinds UV, DC Y, DC U, DC V) | nest + run sums (all) | run scan, header (thread 0) |
  *                  payload entries, fixed-length offsets, compaction (all) | 3 chains (coefficient symbols Y, U, V) |
  *                  basis words merged in, literal blocks copied (all)
- *   P/B picture  : 1 chain (macroblock types, procs) | inter ranks + tags (all, 3 steps) |
- *                  5 chains (kinds Y, kinds UV, DC Y, DC U, DC V) | run sums (all) | run scan, header (thread 0) |
+ *   P/B picture  : 1 chain (macroblock types, procs) | inter ranks, tags, lists of coded / intra macroblocks (all, 5
+ *                  steps) | 5 chains (kinds Y, kinds UV, DC Y, DC U, DC V: symbols only) | kinds and DC values placed in
+ *                  the maps (all) | run sums (all) | run scan, header (thread 0) |
  *                  payload entries, fixed-length offsets, compaction (all) | 5 chains (coefficient symbols Y, U, V,
  *                  MV x, MV y) | basis words merged in, literal blocks copied (all)
  * A chain runs wave-uniform (all lanes compute the same values, so its cursors and counters live in scalar registers
@@ -93,9 +94,16 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         __syncthreads();
         gp_tags_assign(&g, tid, GPW);
         __syncthreads();
+        if (wave == 0) gp_lists_scan(&g, GPW);
+        __syncthreads();
+        gp_lists_write(&g, tid, GPW);
+        __syncthreads();
         if (wave < 2) gp_pbkinds(&g, codes, wave);
         else if (wave == 2) gp_pbdc(&g, codes, 0);
         else { gp_pbdc(&g, codes, 1); gp_pbdc(&g, codes, 2); }
+        __syncthreads();
+        gp_kinds_scatter(&g, tid, GPW);
+        gp_dc_scatter(&g, tid, GPW);
         __syncthreads();
         GP_STAMP(3);
         gp_layout_sum(&g, tid, GPW);

@@ -292,6 +292,8 @@ typedef struct {
     GP_G uint8_t *mbtype;        /* [mw*mh] macroblock type 0..3 */
     GP_G uint8_t *procseq;       /* [mw*mh] proc value of the n-th inter macroblock */
     GP_G uint8_t *mbtag;         /* [mw*mh] (type << 5) | (proc << 4) */
+    GP_G uint32_t *cmb;          /* [mw*mh] macroblocks whose block kinds are coded (all but proc 1), in order */
+    GP_G uint32_t *t0;           /* [mw*mh] intra (type 0) macroblocks, in order */
     GP_G uint32_t *part;         /* [GP_PART] partial counts of the parallel phases */
     /* picture */
     int dc_shift, unk_shift, nx, ny;
@@ -301,6 +303,8 @@ typedef struct {
     uint32_t max_items, max_pairs, pool_dwords, total, nest_off;
     uint64_t fx_off[3];          /* byte offset of the fixed-length sections (basis words, literal blocks) */
     uint32_t nchain[3];          /* entries in clist per plane */
+    uint32_t ncoded, ntype0;     /* entries of cmb / t0 */
+    uint32_t nks[2];             /* coded kinds found by the kinds chains (luma, chroma) */
     GBits bn[2], bnr[2], dc[3], bt[3], rle[3], mvh, mvv, mtype, mproc;
 } GPic;
 
@@ -327,7 +331,7 @@ GP_FN uint32_t gp_byte(const GPic *g, uint32_t off) { return (gp_be32(g, off & ~
 /* bytes of scratch one picture of this geometry needs */
 GP_FN uint32_t gp_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb)
 {
-    return GP_ALIGN16(4u * total_blocks) * 2u + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb + 16u) * 3u + 4u * GP_PART;
+    return GP_ALIGN16(4u * total_blocks) * 2u + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb + 16u) * 3u + GP_ALIGN16(4u * nmb + 16u) * 2u + 4u * GP_PART;
 }
 
 /* serial (thread 0): geometry exactly as hvq_parser_create lays the blob out */
@@ -380,6 +384,8 @@ GP_FN void gp_setup(GPic *g, const HvqParseJob *job)
     g->mbtype = s;                       s += GP_ALIGN16(nmb + 16u);
     g->procseq = s;                      s += GP_ALIGN16(nmb + 16u);
     g->mbtag = s;                        s += GP_ALIGN16(nmb + 16u);
+    g->cmb = (GP_G uint32_t *)s;         s += GP_ALIGN16(4u * nmb + 16u);
+    g->t0 = (GP_G uint32_t *)s;          s += GP_ALIGN16(4u * nmb + 16u);
     g->part = (GP_G uint32_t *)s;
     g->flags = 0; g->status = 0; g->max_items = 0; g->max_pairs = 0; g->pool_dwords = 0; g->total = 0; g->nest_off = 0;
     if (g->cap < g->fixed_bytes || g->len < 8 + 0x44 + 4) g->status |= GP_ST_BADARG;
@@ -459,6 +465,14 @@ GP_FN void gp_collect_tree_status(GPic *g, int ntrees)      /* serial (thread 0)
 {
     if (g->status) return;
     for (int t = 0; t < ntrees; ++t) { g->status |= g->part[GP_MISC + t]; g->flags |= g->part[GP_MISC + GC_COUNT + t]; }
+}
+
+/* thread `tid`'s contiguous share [lo, hi) of n items */
+GP_FN void gp_chunk(uint32_t n, int tid, int nthr, uint32_t *lo, uint32_t *hi)
+{
+    const uint32_t per = (n + (uint32_t)nthr - 1) / (uint32_t)nthr;
+    *lo = per * (uint32_t)tid < n ? per * (uint32_t)tid : n;
+    *hi = *lo + per < n ? *lo + per : n;
 }
 
 /* ------------------------------------------------------------------ blob helpers */
@@ -739,13 +753,6 @@ GP_FN uint32_t gp_ent_fx_bytes(uint32_t ent)
     return mode == GP_MODE_LITERAL ? 16u : (mode >= GP_MODE_BASES ? 2u * ((ent >> 22) & 0xFFu) : 0u);
 }
 
-GP_FN void gp_chunk(uint32_t n, int tid, int nthr, uint32_t *lo, uint32_t *hi)
-{
-    const uint32_t per = (n + (uint32_t)nthr - 1) / (uint32_t)nthr;
-    *lo = per * (uint32_t)tid < n ? per * (uint32_t)tid : n;
-    *hi = *lo + per < n ? *lo + per : n;
-}
-
 /* parallel E1: per thread chunk of each plane's entries: fixed-length bytes, entries with bases */
 GP_FN void gp_emit_count(GPic *g, int tid, int nthr)
 {
@@ -915,14 +922,14 @@ GP_FN void gp_tags_scan(GPic *g, int nthr)
     for (int t = 0; t < nthr; ++t) { const uint32_t c = g->part[t]; GP_ST(g->part[t], run); run += c; }
 }
 
-/* parallel T3: tag of every macroblock; proc-1 macroblocks get their tag into all block types (h4m:1670-1690) */
+/* parallel T3: tag of every macroblock, written into the type byte of all its blocks (h4m:1670-1690: the kind bits
+ * of the coded blocks are OR-ed in later); counts of coded and of intra macroblocks per chunk */
 GP_FN void gp_tags_assign(GPic *g, int tid, int nthr)
 {
     if (g->status) return;
-    const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
-    const uint32_t per = (n + (uint32_t)nthr - 1) / (uint32_t)nthr;
-    const uint32_t lo = per * (uint32_t)tid, hi = lo + per < n ? lo + per : n;
-    uint32_t rank = g->part[tid], fl = 0;
+    uint32_t lo, hi;
+    gp_chunk((uint32_t)g->mw * (uint32_t)g->mh, tid, nthr, &lo, &hi);
+    uint32_t rank = g->part[tid], fl = 0, ncoded = 0, nt0 = 0;
     for (uint32_t m = lo; m < hi; ++m) {
         const uint32_t type = g->mbtype[m];
         uint32_t tag = 0;
@@ -930,75 +937,136 @@ GP_FN void gp_tags_assign(GPic *g, int tid, int nthr)
             const uint32_t proc = g->procseq[rank++];
             tag = (type << 5) | (proc << 4);
             if (g->is_P && type >= 2) fl |= HVQ_F_SELF_REF;
-            if (proc) {
-                const int my = (int)(m / (uint32_t)g->mw), mx = (int)(m - (uint32_t)my * (uint32_t)g->mw);
-                for (int i = 0; i < 3; ++i) {
-                    const GPlane *q = &g->pl[i];
-                    for (int dy = 0; dy < q->by_per; ++dy)
-                        for (int dx = 0; dx < q->bx_per; ++dx)
-                            gp_map_ent(g, i, my * q->by_per + dy, mx * q->bx_per + dx)[1] = (uint8_t)tag;
-                }
+            const int my = (int)(m / (uint32_t)g->mw), mx = (int)(m - (uint32_t)my * (uint32_t)g->mw);
+            for (int i = 0; i < 3; ++i) {
+                const GPlane *q = &g->pl[i];
+                for (int dy = 0; dy < q->by_per; ++dy)
+                    for (int dx = 0; dx < q->bx_per; ++dx)
+                        gp_map_ent(g, i, my * q->by_per + dy, mx * q->bx_per + dx)[1] = (uint8_t)tag;
             }
-        }
+        } else ++nt0;
+        ncoded += !(tag & 0x10u);
         g->mbtag[m] = (uint8_t)tag;
     }
     g->part[GP_PART2 + tid] = fl;
+    g->part[GP_EP(0, 0, tid)] = ncoded;
+    g->part[GP_EP(0, 1, tid)] = nt0;
+}
+
+/* serial T4: exclusive scans of those counts */
+GP_FN void gp_lists_scan(GPic *g, int nthr)
+{
+    if (g->status) return;
+    uint32_t a = 0, b = 0;
+    for (int t = 0; t < nthr; ++t) {
+        const uint32_t ca = g->part[GP_EP(0, 0, t)], cb = g->part[GP_EP(0, 1, t)];
+        GP_ST(g->part[GP_EP(0, 0, t)], a); GP_ST(g->part[GP_EP(0, 1, t)], b);
+        a += ca; b += cb;
+    }
+    g->ncoded = a; g->ntype0 = b;
+}
+
+/* parallel T5: the two macroblock lists the chains walk */
+GP_FN void gp_lists_write(GPic *g, int tid, int nthr)
+{
+    if (g->status) return;
+    uint32_t lo, hi;
+    gp_chunk((uint32_t)g->mw * (uint32_t)g->mh, tid, nthr, &lo, &hi);
+    uint32_t a = g->part[GP_EP(0, 0, tid)], b = g->part[GP_EP(0, 1, tid)];
+    for (uint32_t m = lo; m < hi; ++m) {
+        const uint32_t tag = g->mbtag[m];
+        if (!(tag & 0x10u)) g->cmb[a++] = m;
+        if (!(tag & 0x60u)) g->t0[b++] = m;
+    }
 }
 
 /* block j of a macroblock, order TL, BL, BR, TR (h4m:447-455, 862-865) */
 GP_FN int gp_dx(int j) { return j >> 1; }
 GP_FN int gp_dy(int j) { return (j == 1 || j == 2) ? 1 : 0; }
 
-/* chain: block kinds of the luma plane (which = 0) or both chroma planes (which = 1) of a P/B picture (h4m:1692-1740) */
+/* chain: block kinds of the luma plane (which = 0) or of both chroma planes (which = 1) of a P/B picture
+ * (h4m:1692-1740).  The coded blocks are the blocks of the macroblocks in cmb, in order: "slots".  A non-zero symbol
+ * is the kind of the next slot, a zero symbol leaves that slot and `run` more at kind 0.  The chain only records
+ * (slot, kind) of the non-zero ones -- a run is skipped by an addition -- and all threads put them into the map
+ * afterwards (gp_kinds_scatter). */
 GP_FN void gp_pbkinds(GPic *g, const GCode *codes, int which)
 {
     if (g->status) return;
     GBits bn = g->bn[which], bnr = g->bnr[which];
     const GCode *c_bn = &codes[GC_BN], *c_run = &codes[GC_RUN];
-    const GPlane *q = &g->pl[which];
-    uint32_t rl = 0;
-    GBytes tags;
-    gby_init(&tags, g->mbtag);
-    for (int my = 0; my < g->mh; ++my)
-        for (int mx = 0; mx < g->mw; ++mx) {
-            const uint32_t tag = gby_next(&tags);
-            if (tag & 0x10u) continue;                                  /* proc 1: done by gp_tags_assign */
-            for (int j = 0; j < q->nblk; ++j) {
-                const int by = my * q->by_per + gp_dy(j), bx = mx * q->bx_per + gp_dx(j);
-                uint32_t tu = tag, tv = tag;
-                if (rl) --rl;
-                else {
-                    const int16_t k = (int16_t)gsym(c_bn, &bn);
-                    if (k == 0) rl = (uint32_t)gsym(c_run, &bnr);
-                    else if (which == 0) tu = tag | (uint32_t)k;
-                    else { tu = tag | ((uint32_t)k & 0xFu); tv = tag | (((uint32_t)k >> 4) & 0xFu); }
-                }
-                if (which == 0) GP_ST(gp_map_ent(g, 0, by, bx)[1], (uint8_t)tu);
-                else { GP_ST(gp_map_ent(g, 1, by, bx)[1], (uint8_t)tu); GP_ST(gp_map_ent(g, 2, by, bx)[1], (uint8_t)tv); }
-            }
-        }
+    GP_G uint32_t *ks = g->clist + g->pl[which].blk_first;
+    const uint32_t total = g->ncoded * (uint32_t)g->pl[which].nblk;
+    uint32_t s = 0, n = 0;
+    while (s < total) {
+        const uint32_t k = (uint32_t)gsym(c_bn, &bn) & 0xFFFFu;
+        if ((int16_t)k == 0) s += 1u + (uint32_t)gsym(c_run, &bnr);
+        else { GP_ST(ks[n], (s << 8) | (k & 0xFFu)); ++n; ++s; }
+    }
+    g->nks[which] = n;
 }
 
-/* chain: DC values of the intra macroblocks of plane i (h4m:1742-1776); leaves the cursor for the payload chain */
+/* parallel, after the kinds chains: OR the recorded kinds into the type bytes */
+GP_FN void gp_kinds_scatter(GPic *g, int tid, int nthr)
+{
+    if (g->status) return;
+    for (int which = 0; which < 2; ++which) {
+        const GPlane *q = &g->pl[which];
+        const GP_G uint32_t *ks = g->clist + q->blk_first;
+        const uint32_t n = g->nks[which];
+        for (uint32_t e = (uint32_t)tid; e < n; e += (uint32_t)nthr) {
+            const uint32_t v = ks[e], slot = v >> 8, k = v & 0xFFu;
+            const uint32_t r = slot / (uint32_t)q->nblk, j = slot - r * (uint32_t)q->nblk;
+            const uint32_t m = g->cmb[r], tag = g->mbtag[m];
+            const int my = (int)(m / (uint32_t)g->mw), mx = (int)(m - (uint32_t)my * (uint32_t)g->mw);
+            const int by = my * q->by_per + gp_dy((int)j), bx = mx * q->bx_per + gp_dx((int)j);
+            if (which == 0) gp_map_ent(g, 0, by, bx)[1] = (uint8_t)(tag | k);
+            else { gp_map_ent(g, 1, by, bx)[1] = (uint8_t)(tag | (k & 0xFu)); gp_map_ent(g, 2, by, bx)[1] = (uint8_t)(tag | ((k >> 4) & 0xFu)); }
+        }
+    }
+}
+
+/* chain: DC values of the intra macroblocks of plane i (h4m:1742-1776): cumulative within a run of consecutive intra
+ * macroblocks; values are recorded in order (all threads place them, gp_dc_scatter); leaves the cursor for the
+ * coefficient chain */
 GP_FN void gp_pbdc(GPic *g, const GCode *codes, int i)
 {
     if (g->status) return;
-    const GPlane *q = &g->pl[i];
+    const int nblk = g->pl[i].nblk;
     GBits dc = g->dc[i];
     const GCode *c_dc = &codes[GC_DC];
     const int32_t lo = g->dc_lo, hi = g->dc_hi;
-    uint32_t pbdc = 0x7F;
-    GBytes types;
-    gby_init(&types, g->mbtype);
-    for (int my = 0; my < g->mh; ++my)
-        for (int mx = 0; mx < g->mw; ++mx) {
-            if (gby_next(&types)) { pbdc = 0x7F; continue; }
-            for (int j = 0; j < q->nblk; ++j) {
-                pbdc += (uint32_t)gsym_sovf(c_dc, &dc, lo, hi);
-                GP_ST(gp_map_ent(g, i, my * q->by_per + gp_dy(j), mx * q->bx_per + gp_dx(j))[0], (uint8_t)pbdc);
-            }
+    GP_G uint8_t *dv = (GP_G uint8_t *)g->pinfo + g->pl[i].blk_first;
+    const uint32_t n = g->ntype0;
+    uint32_t pbdc = 0x7F, prev = ~0u, at = 0;
+    uint32_t next = n ? g->t0[0] : 0u;
+    for (uint32_t r = 0; r < n; ++r) {
+        const uint32_t m = next;
+        if (r + 1 < n) next = g->t0[r + 1];
+        if (m != prev + 1u) pbdc = 0x7F;                                /* a non-intra macroblock in between resets */
+        prev = m;
+        for (int j = 0; j < nblk; ++j) {
+            pbdc += (uint32_t)gsym_sovf(c_dc, &dc, lo, hi);
+            GP_ST(dv[at], (uint8_t)pbdc); ++at;
         }
+    }
     g->dc[i] = dc;
+}
+
+/* parallel, after the DC chains */
+GP_FN void gp_dc_scatter(GPic *g, int tid, int nthr)
+{
+    if (g->status) return;
+    for (int i = 0; i < 3; ++i) {
+        const GPlane *q = &g->pl[i];
+        const GP_G uint8_t *dv = (const GP_G uint8_t *)g->pinfo + q->blk_first;
+        const uint32_t n = g->ntype0 * (uint32_t)q->nblk;
+        for (uint32_t e = (uint32_t)tid; e < n; e += (uint32_t)nthr) {
+            const uint32_t r = e / (uint32_t)q->nblk, j = e - r * (uint32_t)q->nblk;
+            const uint32_t m = g->t0[r];
+            const int my = (int)(m / (uint32_t)g->mw), mx = (int)(m - (uint32_t)my * (uint32_t)g->mw);
+            gp_map_ent(g, i, my * q->by_per + gp_dy((int)j), mx * q->bx_per + gp_dx((int)j))[0] = dv[e];
+        }
+    }
 }
 
 /* chain: one motion-vector component (comp 0: x from mvh, 1: y from mvv) of every inter macroblock

@@ -68,9 +68,13 @@ int gparse_emul(const uint8_t *pic, uint32_t len, int frame_type, int w, int h, 
         for (int t = 0; t < NTHR; ++t) gp_tags_count(g, t, NTHR);
         gp_tags_scan(g, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_tags_assign(g, t, NTHR);
+        gp_lists_scan(g, NTHR);
+        for (int t = 0; t < NTHR; ++t) gp_lists_write(g, t, NTHR);
         gp_pbkinds(g, codes, 0);
         gp_pbkinds(g, codes, 1);
         for (int i = 0; i < 3; ++i) gp_pbdc(g, codes, i);
+        for (int t = 0; t < NTHR; ++t) gp_kinds_scatter(g, t, NTHR);
+        for (int t = 0; t < NTHR; ++t) gp_dc_scatter(g, t, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_layout_sum(g, t, NTHR);
         gp_layout_scan(g, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_layout_blocks(g, t, NTHR);

@@ -111,3 +111,9 @@ def test_gpu_parse_core_random_geometries(emul):
                           sampling=str(rng.choice(["420", "444"])), weird_kinds=bool(rng.random() < 0.3),
                           runoff_prob=float(rng.choice([0.0, 0.3])))
         compare_clip(emul, make_clip(cfg))
+
+
+@pytest.mark.parametrize("w,h,samp", [(1920, 1088, "420"), (2048, 8, "420"), (8, 2048, "420"), (1024, 16, "444")])
+def test_gpu_parse_core_large_and_extreme_geometries(emul, w, h, samp):
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    compare_clip(emul, make_clip(SynthConfig(width=w, height=h, gop="IPB", seed=w + h, sampling=samp, runoff_prob=0.2)))

@@ -116,3 +116,17 @@ def test_corrupted_streams_do_not_fault_the_gpu_parser(gpu_ctx):
         gpu_ctx.close_stream(sid)
     # the context is still healthy
     test_nest_of_the_last_I_picture_survives_flushes(gpu_ctx, 2)
+
+
+@pytest.mark.parametrize("w,h,samp", [(1920, 1088, "420"), (2048, 8, "420"), (8, 2048, "420"), (1024, 16, "444"), (720, 576, "444")])
+def test_large_and_extreme_geometries(gpu_ctx, w, h, samp):
+    """full-HD, one-macroblock-high strips (longest DC row buffer, ragged last tiles) and wide 4:4:4, through both
+    parsers; the oracle is the checker"""
+    from hvqm4_amd import batch
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    from oracle import bridge
+    clip = make_clip(SynthConfig(width=w, height=h, gop="IPB", seed=w + h, sampling=samp, runoff_prob=0.2))
+    want = bridge.oracle_decode(clip.data, clip.n_pictures)
+    for gpu_parse in (False, True):
+        got = batch.decode_clip(gpu_ctx, clip.data, gpu_parse=gpu_parse)
+        assert np.array_equal(got, want), ("gpu parse" if gpu_parse else "host parse")
