@@ -153,7 +153,7 @@ def main():
                 ok += 1
         gpu_e2e = {"value": round(int(st.luma_pixels) / min(t_pass[1:]) / 1e6, 1), "unit": "Mpixels/s",
                    "parse_kernel_ms": round(min(parse_ms[1:]), 3), "pass_ms": [round(t * 1e3, 2) for t in t_pass], "submit_flush_sync_ms": t_split,
-                   "host_threads": 1, "pictures_checked_against_host_parsed": ok,
+                   "host_copy_threads": 4, "pictures_checked_against_host_parsed": ok,
                    "what": "raw bitstreams in host memory -> H2D -> entropy parse kernel (one workgroup per picture) -> "
                            "reconstruction launches -> pictures in HBM; no host entropy parse"}
         ctx2.close()
