@@ -28,9 +28,9 @@
 
 extern "C" __global__ __launch_bounds__(GPW) __attribute__((amdgpu_num_sgpr(80)))
 void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__restrict__ results, uint32_t rowbuf_stride,
-                      uint64_t *__restrict__ timing)     /* optional: 8 phase timestamps per picture (100 MHz clock) */
+                      uint64_t *__restrict__ timing)     /* optional: 16 phase timestamps per picture (100 MHz clock) */
 {
-#define GP_STAMP(k) do { if (timing && tid == 0) timing[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#define GP_STAMP(k) do { if (timing && tid == 0) timing[16 * blockIdx.x + (k)] = wall_clock64(); } while (0)
     extern __shared__ uint8_t s_rowbuf[];            /* 3 * rowbuf_stride */
     __shared__ GPic g;
     __shared__ GCode codes[GC_COUNT];
@@ -98,10 +98,12 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         __syncthreads();
         gp_lists_write(&g, tid, GPW);
         __syncthreads();
+        GP_STAMP(12);
         if (wave < 2) gp_pbkinds(&g, codes, wave);
         else if (wave == 2) gp_pbdc(&g, codes, 0);
         else { gp_pbdc(&g, codes, 1); gp_pbdc(&g, codes, 2); }
         __syncthreads();
+        GP_STAMP(13);
         gp_kinds_scatter(&g, tid, GPW);
         gp_dc_scatter(&g, tid, GPW);
         __syncthreads();
@@ -111,12 +113,16 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         GP_STAMP(4);
         if (wave == 0) gp_layout_scan(&g, GPW);
         __syncthreads();
+        GP_STAMP(8);
         gp_layout_blocks(&g, tid, GPW);
         __syncthreads();
+        GP_STAMP(9);
         gp_emit_count(&g, tid, GPW);
         __syncthreads();
+        GP_STAMP(10);
         if (wave == 0) gp_emit_scan(&g, GPW);
         __syncthreads();
+        GP_STAMP(11);
         gp_emit_compact(&g, tid, GPW);
         __syncthreads();
         GP_STAMP(5);

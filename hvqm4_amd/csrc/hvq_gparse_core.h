@@ -853,15 +853,25 @@ GP_FN void gp_emit_merge(GPic *g, int tid, int nthr)
             if (mode == GP_MODE_NONE) continue;
             GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
             if (mode == GP_MODE_LITERAL) {
-                for (int k = 0; k < 4; ++k) dst[k] = __builtin_bswap32(gp_be32(g, fx + 4u * (uint32_t)k));
+                uint32_t v[4];
+                for (int k = 0; k < 4; ++k) v[k] = __builtin_bswap32(gp_be32(g, fx + 4u * (uint32_t)k));
+                for (int k = 0; k < 4; ++k) dst[k] = v[k];
                 fx += 16;
                 continue;
             }
             const uint32_t nb = (ent >> 22) & 0xFFu;
             if (mode == GP_MODE_PREDI) dst += 2;
-            for (uint32_t k = 0; k < nb; ++k) {
-                const uint32_t word = gp_be16(g, fx + 2u * k);
-                dst[k] = HVQ_BASIS(word, (dst[k] + ((word >> 13) & 3u)) & 0x3FFFFu);
+            /* four bases at a time: all loads first (they are independent), then the stores -- a thread's speed here is
+             * the number of HBM round trips it waits for */
+            for (uint32_t k0 = 0; k0 < nb; k0 += 4) {
+                uint32_t w[4], r[4];
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const int live = k0 + j < nb;
+                    w[j] = live ? gp_be16(g, fx + 2u * (k0 + j)) : 0u;
+                    r[j] = live ? dst[k0 + j] : 0u;
+                }
+                for (uint32_t j = 0; j < 4; ++j)
+                    if (k0 + j < nb) dst[k0 + j] = HVQ_BASIS(w[j], (r[j] + ((w[j] >> 13) & 3u)) & 0x3FFFFu);
             }
             fx += 2u * nb;
         }

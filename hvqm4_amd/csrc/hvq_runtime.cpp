@@ -573,8 +573,8 @@ static int device_parse(HvqContext *c)
     static const bool want_timing = getenv("HVQM4_AMD_PARSE_TIMING") != nullptr;
     uint64_t *timing_dev = nullptr;
     if (want_timing) {
-        HIPCHK(hipMalloc((void **)&timing_dev, jobs.size() * 8 * sizeof(uint64_t)));
-        HIPCHK(hipMemsetAsync(timing_dev, 0, jobs.size() * 8 * sizeof(uint64_t), c->stream));
+        HIPCHK(hipMalloc((void **)&timing_dev, jobs.size() * 16 * sizeof(uint64_t)));
+        HIPCHK(hipMemsetAsync(timing_dev, 0, jobs.size() * 16 * sizeof(uint64_t), c->stream));
     }
     HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, timing_dev, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
@@ -585,7 +585,7 @@ static int device_parse(HvqContext *c)
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->gpu_parse_ms = ms;
     if (timing_dev) {
-        std::vector<uint64_t> tm(jobs.size() * 8);
+        std::vector<uint64_t> tm(jobs.size() * 16);
         HIPCHK(hipMemcpy(tm.data(), timing_dev, tm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
         HIPCHK(hipFree(timing_dev));
         static const char *names[3][7] = {
@@ -594,7 +594,7 @@ static int device_parse(HvqContext *c)
             { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains coefficients/MV", "merge words" } };
         double sum[3][7] = {}; size_t cnt[3] = {}; uint64_t t_min = ~0ull, t_max = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
-            const uint64_t *t = &tm[8 * k];
+            const uint64_t *t = &tm[16 * k];
             const int kind = (int)c->pending[idx[k]].kind;
             uint64_t prev = t[0];
             for (int ph = 1; ph <= 7; ++ph) { if (!t[ph]) continue; sum[kind][ph - 1] += (double)(t[ph] - prev) * 0.01; prev = t[ph]; }
@@ -602,13 +602,27 @@ static int device_parse(HvqContext *c)
         }
         uint64_t s_max = 0, d_min = ~0ull, d_max = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
-            const uint64_t *t = &tm[8 * k];
+            const uint64_t *t = &tm[16 * k];
             s_max = std::max(s_max, t[0]); d_min = std::min(d_min, t[7] - t[0]); d_max = std::max(d_max, t[7] - t[0]);
         }
         fprintf(stderr, "hvqm4_amd parse occupancy: %d workgroups per CU (runtime query)\n", hvq_parse_occupancy(rowbuf));
         fprintf(stderr, "hvqm4_amd parse timing: %zu pictures, kernel %.3f ms, first start -> last end %.3f ms, last start +%.3f ms, "
                 "per picture %.3f .. %.3f ms\n",
                 jobs.size(), ms, (double)(t_max - t_min) * 1e-5, (double)(s_max - t_min) * 1e-5, (double)d_min * 1e-5, (double)d_max * 1e-5);
+        {   /* finer split of the P/B phases */
+            double d[8] = {}; size_t n = 0;
+            for (size_t k = 0; k < jobs.size(); ++k) {
+                const uint64_t *t = &tm[16 * k];
+                if (c->pending[idx[k]].kind == HVQ_PIC_I || !t[12]) continue;
+                d[0] += (double)(t[12] - t[2]); d[1] += (double)(t[13] - t[12]); d[2] += (double)(t[3] - t[13]);
+                d[3] += (double)(t[8] - t[4]); d[4] += (double)(t[9] - t[8]); d[5] += (double)(t[10] - t[9]);
+                d[6] += (double)(t[11] - t[10]); d[7] += (double)(t[5] - t[11]);
+                ++n;
+            }
+            if (n) fprintf(stderr, "  P/B detail: tags+lists %.1f | kinds/DC chains %.1f | scatter %.1f | run scan %.1f | entries %.1f | "
+                           "emit count %.1f | emit scan %.1f | compact %.1f us\n", d[0] * 0.01 / n, d[1] * 0.01 / n, d[2] * 0.01 / n,
+                           d[3] * 0.01 / n, d[4] * 0.01 / n, d[5] * 0.01 / n, d[6] * 0.01 / n, d[7] * 0.01 / n);
+        }
         for (int kind = 0; kind < 3; ++kind) {
             if (!cnt[kind]) continue;
             fprintf(stderr, "  %c pictures (%zu): ", "IPB"[kind], cnt[kind]);
