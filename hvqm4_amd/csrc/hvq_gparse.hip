@@ -8,13 +8,13 @@
  *   I picture    : 5 chains (kinds Y, kinds UV, DC Y, DC U, DC V) | nest + run sums (all) | run scan, header (thread 0) |
  *                  payload entries, fixed-length offsets, compaction (all) | 3 chains (coefficient symbols Y, U, V) |
  *                  basis words merged in, literal blocks copied (all)
- *   P/B picture  : 1 chain (macroblock types, procs) | inter ranks, tags, lists of coded / intra macroblocks (all, 5
+ *   P/B picture  : 2 chains (macroblock types; proc runs) | inter ranks, tags, lists of coded / intra macroblocks (all, 5
  *                  steps) | 5 chains (kinds Y, kinds UV, DC Y, DC U, DC V: symbols only) | kinds and DC values placed in
  *                  the maps (all) | run sums (all) | run scan, header (thread 0) |
- *                  payload entries, fixed-length offsets, compaction (all) | 5 chains (coefficient symbols Y, U, V,
- *                  MV x, MV y) | basis words merged in, literal blocks copied (all)
+ *                  payload entries, fixed-length offsets, compaction (all) | 4 waves: coefficient symbols Y; U, V; MV x, y;
+ *                  DC-buffer scalars of the MC-residual blocks Y, U, V | basis words merged in, literal blocks copied (all)
  * A chain runs wave-uniform (all lanes compute the same values, so its cursors and counters live in scalar registers
- * and its logic runs on the scalar unit; one lane does the stores); the four waves of a workgroup run different
+ * and its logic runs on the scalar unit); the four waves of a workgroup run different
  * chains at the same time and 8 workgroups share a CU, so the serial bit-level work of thousands of pictures overlaps.
  *
  * LDS per workgroup: the picture state (cursors, geometry), six prefix trees with 9-bit tables (2.5 KB each) and
@@ -86,6 +86,7 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         else if (wave == 1) { gp_payload(&g, codes, 1); gp_payload(&g, codes, 2); }
     } else {
         if (wave == 0) gp_mbtypes(&g, codes);
+        else if (wave == 1) gp_mbprocs(&g, codes);
         __syncthreads();
         GP_STAMP(2);
         gp_tags_count(&g, tid, GPW);
@@ -131,7 +132,7 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         else if (wave == 2) {
             const uint32_t fx = gp_mvs(&g, codes, 0), fy = gp_mvs(&g, codes, 1);
             GP_ST(g.part[GP_MISC + 13], fx | fy);
-        }
+        } else { gp_predi_params(&g, codes, 0); gp_predi_params(&g, codes, 1); gp_predi_params(&g, codes, 2); }
     }
     __syncthreads();
     GP_STAMP(6);

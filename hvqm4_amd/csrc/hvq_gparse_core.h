@@ -795,15 +795,12 @@ GP_FN void gp_emit_compact(GPic *g, int tid, int nthr)
     }
 }
 
-/* chain: coefficient symbols of plane i, I and P/B alike; MC-residual blocks also take their two scalars from the DC
- * buffer, whose cursor gp_pbdc left behind (h4m:1862-1910, 1405-1406) */
+/* chain: coefficient symbols of plane i, I and P/B alike: the running sum of every basis goes into its pool slot */
 GP_FN void gp_payload(GPic *g, const GCode *codes, int i)
 {
     if (g->status) return;
-    GBits bt = g->bt[i], dc = g->dc[i];
-    const GCode *c_bt = &codes[GC_BT], *c_dc = &codes[GC_DC];
-    const int32_t lo = g->dc_lo, hi = g->dc_hi;
-    const int sh_dc = g->dc_shift & 31, sh_unk = g->unk_shift & 31;
+    GBits bt = g->bt[i];
+    const GCode *c_bt = &codes[GC_BT];
     GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
     const GP_G uint32_t *ents = g->clist + g->pl[i].blk_first;
     const uint32_t n = g->nchain[i];
@@ -812,19 +809,34 @@ GP_FN void gp_payload(GPic *g, const GCode *codes, int i)
         const uint32_t ent = next;
         if (e + 1 < n) next = ents[e + 1];                              /* requested one entry ahead */
         const uint32_t nb = (ent >> 22) & 0xFFu;
+        GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu) + ((ent >> 30) == GP_MODE_PREDI ? 2u : 0u);
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < nb; ++k) { run += (uint32_t)gsym(c_bt, &bt); GP_ST(dst[k], run); }
+    }
+}
+
+/* chain, concurrent with gp_payload (its own cursor): the two scalars of every MC-residual block of plane i from the DC
+ * buffer, continuing where gp_pbdc stopped (h4m:1862-1910, 1405-1406) */
+GP_FN void gp_predi_params(GPic *g, const GCode *codes, int i)
+{
+    if (g->status || !g->is_pb) return;
+    GBits dc = g->dc[i];
+    const GCode *c_dc = &codes[GC_DC];
+    const int32_t lo = g->dc_lo, hi = g->dc_hi;
+    const int sh_dc = g->dc_shift & 31, sh_unk = g->unk_shift & 31;
+    GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
+    const GP_G uint32_t *ents = g->clist + g->pl[i].blk_first;
+    const uint32_t n = g->nchain[i];
+    uint32_t next = n ? ents[0] : 0u;
+    for (uint32_t e = 0; e < n; ++e) {
+        const uint32_t ent = next;
+        if (e + 1 < n) next = ents[e + 1];
+        if ((ent >> 30) != GP_MODE_PREDI) continue;
         GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
-        if ((ent >> 30) == GP_MODE_PREDI) {
-            dst += 2;
-            uint32_t run = 0;
-            for (uint32_t k = 0; k < nb; ++k) { run += (uint32_t)gsym(c_bt, &bt); GP_ST(dst[k], run); }
-            const int32_t s1 = gsym_sovf(c_dc, &dc, lo, hi);            /* h4m:1405-1406 */
-            const int32_t s2 = gsym_sovf(c_dc, &dc, lo, hi);
-            GP_ST(dst[-2], (uint32_t)(s1 >> sh_dc) << sh_unk);
-            GP_ST(dst[-1], (uint32_t)(s2 >> sh_dc));
-        } else {
-            uint32_t run = 0;
-            for (uint32_t k = 0; k < nb; ++k) { run += (uint32_t)gsym(c_bt, &bt); GP_ST(dst[k], run); }
-        }
+        const int32_t s1 = gsym_sovf(c_dc, &dc, lo, hi);
+        const int32_t s2 = gsym_sovf(c_dc, &dc, lo, hi);
+        GP_ST(dst[0], (uint32_t)(s1 >> sh_dc) << sh_unk);
+        GP_ST(dst[1], (uint32_t)(s2 >> sh_dc));
     }
 }
 
@@ -879,13 +891,13 @@ GP_FN void gp_emit_merge(GPic *g, int tid, int nthr)
 }
 
 /* ------------------------------------------------------------------ P/B picture chains */
-/* chain: macroblock types from the mtype runs (h4m:1545-1622), then the proc runs */
+/* chain: macroblock types from the mtype runs (h4m:1545-1622) */
 GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
 {
     if (g->status) return;
     GBits b = g->mtype;
     const GCode *c = &codes[GC_MCB];
-    uint32_t value = 0, count = 0, inter = 0;
+    uint32_t value = 0, count = 0;
     if (b.live) { value = gb_take(&b, 2); count = (uint32_t)gsym_uovf(c, &b); }
     const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
     for (uint32_t m = 0; m < n; ++m) {
@@ -898,15 +910,27 @@ GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
         }
         --count;
         GP_ST(g->mbtype[m], (uint8_t)value);
-        inter += value != 0;
     }
-    /* proc value of the n-th inter macroblock from the mproc runs (h4m:1649-1668); same lane, so that exactly as
-     * many runs are read as the picture has inter macroblocks */
-    b = g->mproc;
-    value = 0; count = 0;
+}
+
+/* chain, concurrent with gp_mbtypes: proc value of the n-th INTER macroblock from the mproc runs (h4m:1649-1668).
+ * How many inter macroblocks there are is only known when the types are done, so this decodes runs for as many
+ * entries as the picture has macroblocks (an upper bound; surplus entries are never looked at) and stops early once
+ * the cursor is past the picture's data, where nothing but zero padding is left to decode. */
+GP_FN void gp_mbprocs(GPic *g, const GCode *codes)
+{
+    if (g->status) return;
+    GBits b = g->mproc;
+    const GCode *c = &codes[GC_MCB];
+    uint32_t value = 0, count = 0;
     if (b.live) { value = gb_take(&b, 1); count = (uint32_t)gsym_uovf(c, &b); }
-    for (uint32_t m = 0; m < inter; ++m) {
-        if (count == 0) { value ^= 1u; count = (uint32_t)gsym_uovf(c, &b); }
+    const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
+    for (uint32_t m = 0; m < n; ++m) {
+        if (count == 0) {
+            if (b.idx > b.nd + 2u) break;
+            value ^= 1u;
+            count = (uint32_t)gsym_uovf(c, &b);
+        }
         --count;
         GP_ST(g->procseq[m], (uint8_t)value);
     }

@@ -65,6 +65,7 @@ int gparse_emul(const uint8_t *pic, uint32_t len, int frame_type, int w, int h, 
         for (int i = 0; i < 3; ++i) gp_payload(g, codes, i);
     } else {
         gp_mbtypes(g, codes);
+        gp_mbprocs(g, codes);
         for (int t = 0; t < NTHR; ++t) gp_tags_count(g, t, NTHR);
         gp_tags_scan(g, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_tags_assign(g, t, NTHR);
@@ -82,6 +83,7 @@ int gparse_emul(const uint8_t *pic, uint32_t len, int frame_type, int w, int h, 
         gp_emit_scan(g, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_emit_compact(g, t, NTHR);
         for (int i = 0; i < 3; ++i) gp_payload(g, codes, i);
+        for (int i = 0; i < 3; ++i) gp_predi_params(g, codes, i);
         extra |= gp_mvs(g, codes, 0);
         extra |= gp_mvs(g, codes, 1);
     }
