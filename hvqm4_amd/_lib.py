@@ -85,6 +85,8 @@ SYMBOLS = {
     "hvq_submit_many_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p),
                                          C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "hvq_flush": (C.c_int, [C.c_void_p]),
+    "hvq_flush_begin": (C.c_int, [C.c_void_p]),
+    "hvq_flush_end": (C.c_int, [C.c_void_p]),
     "hvq_sync": (C.c_int, [C.c_void_p]),
     "hvq_replay": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "hvq_read_picture": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),

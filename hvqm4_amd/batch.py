@@ -49,6 +49,13 @@ class Context:
     def flush(self) -> None:
         check(lib().hvq_flush(self._h))
 
+    def flush_begin(self) -> None:
+        """first half of a flush (uploads + entropy-parse kernel queued); the next batch may be submitted before flush_end"""
+        check(lib().hvq_flush_begin(self._h))
+
+    def flush_end(self) -> None:
+        check(lib().hvq_flush_end(self._h))
+
     def sync(self) -> None:
         check(lib().hvq_sync(self._h))
 

@@ -112,12 +112,13 @@ struct Pending {
     /* device-parsed pictures: raw bitstream in the arena instead of a blob */
     bool dev = false;
     int nest_ref = -1;                 /* pending index of the governing I picture, -1: the stream's nest_keep */
-    uint64_t dev_blob = 0, dev_nest = 0;
+    uint64_t dev_blob = 0, dev_nest = 0, nest_ptr = 0;
     uint32_t flags = 0, unk_shift = 0;
 };
 
 struct Launch {
     int queue;                         /* 0: main HIP stream, 1: second stream (the other half of the clips) */
+    int level;
     uint32_t first_tile, ntiles;
     uint32_t items_cap, pair_cap;      /* LDS sizing of the launch: max over its pictures */
 };
@@ -131,12 +132,40 @@ struct HvqContext {
     uint8_t *host_arena = nullptr, *dev_arena = nullptr;
     size_t arena_cap = 0, arena_used = 0;
     size_t arena_uploaded = 0;         /* [0, arena_uploaded) is already on its way to dev_arena (early H2D of bitstreams) */
+    /* Two arenas: host_arena/dev_arena is the one being FILLED; the other belongs to the batch in flight (between
+     * hvq_flush_begin and hvq_flush_end) or is idle.  Uploads run on their own stream so that the next batch's
+     * bitstreams travel while this batch is parsed and reconstructed. */
+    uint8_t *host_arena_alt = nullptr, *dev_arena_alt = nullptr;
+    size_t arena_cap_alt = 0;
+    int arena_id = 0;                  /* which of the two the current one is */
+    bool arena_waited = false;         /* copy_stream already waits for the last batch that used the current arena */
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy = nullptr, ev_parse = nullptr, ev_arena_free[2] = { nullptr, nullptr };
     std::vector<Pending> pending;
+    /* batch in flight */
+    bool fl_active = false;
+    std::vector<Pending> fl_pending;
+    std::vector<size_t> fl_idx;        /* its GPU-parsed pictures (indices into fl_pending) */
+    std::vector<uint64_t> fl_nest_pairs;
+    uint8_t *fl_host = nullptr, *fl_dev = nullptr;
+    int fl_arena_id = 0;
+    int fl_nq = 1;
+    HvqParseResult *pr_host = nullptr; /* pinned */
+    size_t pr_host_cap = 0;
+    uint64_t *timing_dev = nullptr;
+    /* pinned staging of the table uploads, one set per arena id: an H2D from pageable memory would block the caller
+     * until the stream has drained (the parse kernel!), which is exactly what hvq_flush_begin must not do */
+    struct Pinned { uint8_t *p = nullptr; size_t cap = 0; } pin[2][4];   /* [arena id][parse jobs, tiles, jobs, nest pairs] */
+    std::vector<HvqJob> jobs_host;     /* the tables are built here, then copied into the pinned staging */
+    std::vector<HvqTileRef> tiles_host;
+    std::vector<uint64_t> pairs_host;
+    std::vector<HvqParseJob> pjobs_host;
     /* last flushed batch (kept resident for hvq_replay) */
     HvqJob *jobs_dev = nullptr;
     HvqTileRef *tiles_dev = nullptr;
     size_t jobs_cap = 0, tiles_cap = 0;
     std::vector<Launch> launches;
+    std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
     HvqStats stats{};
     double parse_seconds = 0;
     uint8_t *rgb_dev = nullptr;        /* scratch of the display epilogue */
@@ -163,12 +192,44 @@ static int arena_reserve(HvqContext *c, size_t need)
     HIPCHK(hipMalloc((void **)&nd, ncap));
     if (c->arena_used) memcpy(nh, c->host_arena, c->arena_used);
     if (c->host_arena) {
+        HIPCHK(hipStreamSynchronize(c->copy_stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipHostFree(c->host_arena));
         HIPCHK(hipFree(c->dev_arena));
     }
     c->host_arena = nh; c->dev_arena = nd; c->arena_cap = ncap;
     c->arena_uploaded = 0;             /* the new device arena holds nothing yet */
+    return HVQ_OK;
+}
+
+/* queue the H2D of [arena_uploaded, upto) of the arena being filled on the copy stream */
+static int arena_upload(HvqContext *c, size_t upto)
+{
+    if (upto <= c->arena_uploaded) return HVQ_OK;
+    if (!c->arena_waited) {            /* the batch that used this arena two flushes ago may still be reconstructing */
+        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_arena_free[c->arena_id], 0));
+        c->arena_waited = true;
+    }
+    HIPCHK(hipMemcpyAsync(c->dev_arena + c->arena_uploaded, c->host_arena + c->arena_uploaded, upto - c->arena_uploaded,
+                          hipMemcpyHostToDevice, c->copy_stream));
+    c->arena_uploaded = upto;
+    return HVQ_OK;
+}
+
+static int flush_end(HvqContext *c);
+
+/* copy `bytes` into pinned staging buffer [id][which] and queue its upload to `dst` on the compute stream */
+static int staged_upload(HvqContext *c, int id, int which, void *dst, const void *src, size_t bytes)
+{
+    HvqContext::Pinned &b = c->pin[id][which];
+    if (bytes > b.cap) {
+        if (b.p) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
+        const size_t ncap = align_up(bytes * 2, 4096);
+        HIPCHK(hipHostMalloc((void **)&b.p, ncap, hipHostMallocDefault));
+        b.cap = ncap;
+    }
+    memcpy(b.p, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyHostToDevice, c->stream));
     return HVQ_OK;
 }
 
@@ -186,6 +247,11 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_parse, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_arena_free[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_arena_free[1], hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -198,6 +264,8 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)flush_end(c);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->streams) {
         if (s.parser) hvq_parser_destroy(s.parser);
@@ -210,6 +278,14 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->np_dev) (void)hipFree(c->np_dev);
     if (c->host_arena) (void)hipHostFree(c->host_arena);
     if (c->dev_arena) (void)hipFree(c->dev_arena);
+    if (c->host_arena_alt) (void)hipHostFree(c->host_arena_alt);
+    if (c->dev_arena_alt) (void)hipFree(c->dev_arena_alt);
+    if (c->pr_host) (void)hipHostFree(c->pr_host);
+    for (auto &set : c->pin) for (auto &b : set) if (b.p) (void)hipHostFree(b.p);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->ev_parse) (void)hipEventDestroy(c->ev_parse);
+    for (auto e : c->ev_arena_free) if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tiles_dev) (void)hipFree(c->tiles_dev);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
@@ -250,6 +326,7 @@ HVQ_EXPORT int hvq_stream_close(HvqContext *c, int sid)
     if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
     for (auto &p : c->pending)
         if (p.stream == sid) return fail(HVQ_E_STATE, "stream %d has queued pictures; flush first", sid);
+    { int rc = flush_end(c); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     Stream &s = c->streams[sid];
     hvq_parser_destroy(s.parser); s.parser = nullptr;
@@ -510,19 +587,20 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
             for (auto &t : pool) t.join();
         }
         if (early) {
-            const size_t b0 = offs[(size_t)lo], b1 = hi < n ? offs[(size_t)hi] : c->arena_used;
-            HIPCHK(hipMemcpyAsync(c->dev_arena + b0, c->host_arena + b0, b1 - b0, hipMemcpyHostToDevice, c->stream));
-            c->arena_uploaded = b1;
+            int rcu = arena_upload(c, hi < n ? offs[(size_t)hi] : c->arena_used);
+            if (rcu) return rcu;
         }
         lo = hi;
     }
     return HVQ_OK;
 }
 
-/* parse every device-parsed picture of the pending batch in one launch; fills dev_blob, dev_nest, the LDS sizes and the flags */
-static int device_parse(HvqContext *c)
+/* GPU-parsed pictures of the pending batch: lay their blobs out, queue the parse kernel and the read-back of its
+ * results on the compute stream (which already waits for the bitstreams' H2D).  Nothing here waits for the GPU. */
+static int device_parse_launch(HvqContext *c)
 {
-    std::vector<size_t> idx;
+    std::vector<size_t> &idx = c->fl_idx;
+    idx.clear();
     size_t need = 0;
     uint32_t rowbuf = 0;
     for (size_t i = 0; i < c->pending.size(); ++i) {
@@ -546,13 +624,18 @@ static int device_parse(HvqContext *c)
         HIPCHK(hipMalloc((void **)&c->pr_dev, c->pj_cap * sizeof(HvqParseResult)));
         HIPCHK(hipMalloc((void **)&c->np_dev, c->pj_cap * 2 * sizeof(uint64_t)));
     }
-    std::vector<HvqParseJob> jobs(idx.size());
+    if (idx.size() > c->pr_host_cap) {
+        if (c->pr_host) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->pr_host)); }
+        c->pr_host_cap = idx.size() * 2;
+        HIPCHK(hipHostMalloc((void **)&c->pr_host, c->pr_host_cap * sizeof(HvqParseResult), hipHostMallocDefault));
+    }
+    std::vector<HvqParseJob> &jobs = c->pjobs_host;
+    jobs.assign(idx.size(), HvqParseJob{});
     size_t off = 0;
     for (size_t k = 0; k < idx.size(); ++k) {
         Pending &p = c->pending[idx[k]];
         const Stream &s = c->streams[(size_t)p.stream];
         HvqParseJob &j = jobs[k];
-        memset(&j, 0, sizeof j);
         p.dev_blob = (uint64_t)(uintptr_t)(c->gp_dev + off);             off += s.blob_cap;
         j.scratch = (uint64_t)(uintptr_t)(c->gp_dev + off);              off += s.scratch_bytes;
         p.dev_nest = (uint64_t)(uintptr_t)(c->gp_dev + off);             off += align_up(GP_ALIGN16(HVQ_NESTP_BYTES), 256);
@@ -567,53 +650,62 @@ static int device_parse(HvqContext *c)
         j.h_samp = s.layout.wshift ? 2 : 1; j.v_samp = s.layout.hshift ? 2 : 1;
         j.is15 = (s.layout.flags & HVQ_F_IS15) ? 1 : 0;
     }
-    HIPCHK(hipMemcpyAsync(c->pj_dev, jobs.data(), jobs.size() * sizeof(HvqParseJob), hipMemcpyHostToDevice, c->stream));
+    { int rcu = staged_upload(c, c->arena_id, 0, c->pj_dev, jobs.data(), jobs.size() * sizeof(HvqParseJob)); if (rcu) return rcu; }
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     /* HVQM4_AMD_PARSE_TIMING=1: per-phase times of the parse kernel (development aid, prints to stderr) */
     static const bool want_timing = getenv("HVQM4_AMD_PARSE_TIMING") != nullptr;
-    uint64_t *timing_dev = nullptr;
+    c->timing_dev = nullptr;
     if (want_timing) {
-        HIPCHK(hipMalloc((void **)&timing_dev, jobs.size() * 16 * sizeof(uint64_t)));
-        HIPCHK(hipMemsetAsync(timing_dev, 0, jobs.size() * 16 * sizeof(uint64_t), c->stream));
+        HIPCHK(hipMalloc((void **)&c->timing_dev, jobs.size() * 16 * sizeof(uint64_t)));
+        HIPCHK(hipMemsetAsync(c->timing_dev, 0, jobs.size() * 16 * sizeof(uint64_t), c->stream));
     }
-    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, timing_dev, c->stream));
+    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, c->timing_dev, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
-    std::vector<HvqParseResult> res(idx.size());
-    HIPCHK(hipMemcpyAsync(res.data(), c->pr_dev, res.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(c->pr_host, c->pr_dev, idx.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->ev_parse, c->stream));
+    return HVQ_OK;
+}
+
+/* wait for the parse results of the batch in flight and take them over */
+static int device_parse_finish(HvqContext *c)
+{
+    const std::vector<size_t> &idx = c->fl_idx;
+    if (idx.empty()) return HVQ_OK;
+    HIPCHK(hipEventSynchronize(c->ev_parse));
+    const HvqParseResult *res = c->pr_host;
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->gpu_parse_ms = ms;
-    if (timing_dev) {
-        std::vector<uint64_t> tm(jobs.size() * 16);
-        HIPCHK(hipMemcpy(tm.data(), timing_dev, tm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIPCHK(hipFree(timing_dev));
+    if (c->timing_dev) {
+        std::vector<uint64_t> tm(idx.size() * 16);
+        HIPCHK(hipMemcpy(tm.data(), c->timing_dev, tm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipFree(c->timing_dev)); c->timing_dev = nullptr;
         static const char *names[3][7] = {
             { "setup+trees", "", "chains kinds/DC", "nest+run sums", "scan+entries", "chains coefficients", "merge words" },
             { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains coefficients/MV", "merge words" },
             { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains coefficients/MV", "merge words" } };
         double sum[3][7] = {}; size_t cnt[3] = {}; uint64_t t_min = ~0ull, t_max = 0;
-        for (size_t k = 0; k < jobs.size(); ++k) {
+        for (size_t k = 0; k < idx.size(); ++k) {
             const uint64_t *t = &tm[16 * k];
-            const int kind = (int)c->pending[idx[k]].kind;
+            const int kind = (int)c->fl_pending[idx[k]].kind;
             uint64_t prev = t[0];
             for (int ph = 1; ph <= 7; ++ph) { if (!t[ph]) continue; sum[kind][ph - 1] += (double)(t[ph] - prev) * 0.01; prev = t[ph]; }
             cnt[kind]++; t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[7]);
         }
         uint64_t s_max = 0, d_min = ~0ull, d_max = 0;
-        for (size_t k = 0; k < jobs.size(); ++k) {
+        for (size_t k = 0; k < idx.size(); ++k) {
             const uint64_t *t = &tm[16 * k];
             s_max = std::max(s_max, t[0]); d_min = std::min(d_min, t[7] - t[0]); d_max = std::max(d_max, t[7] - t[0]);
         }
-        fprintf(stderr, "hvqm4_amd parse occupancy: %d workgroups per CU (runtime query)\n", hvq_parse_occupancy(rowbuf));
+        fprintf(stderr, "hvqm4_amd parse occupancy: %d workgroups per CU (runtime query)\n", hvq_parse_occupancy(256));
         fprintf(stderr, "hvqm4_amd parse timing: %zu pictures, kernel %.3f ms, first start -> last end %.3f ms, last start +%.3f ms, "
                 "per picture %.3f .. %.3f ms\n",
-                jobs.size(), ms, (double)(t_max - t_min) * 1e-5, (double)(s_max - t_min) * 1e-5, (double)d_min * 1e-5, (double)d_max * 1e-5);
+                idx.size(), ms, (double)(t_max - t_min) * 1e-5, (double)(s_max - t_min) * 1e-5, (double)d_min * 1e-5, (double)d_max * 1e-5);
         {   /* finer split of the P/B phases */
             double d[8] = {}; size_t n = 0;
-            for (size_t k = 0; k < jobs.size(); ++k) {
+            for (size_t k = 0; k < idx.size(); ++k) {
                 const uint64_t *t = &tm[16 * k];
-                if (c->pending[idx[k]].kind == HVQ_PIC_I || !t[12]) continue;
+                if (c->fl_pending[idx[k]].kind == HVQ_PIC_I || !t[12]) continue;
                 d[0] += (double)(t[12] - t[2]); d[1] += (double)(t[13] - t[12]); d[2] += (double)(t[3] - t[13]);
                 d[3] += (double)(t[8] - t[4]); d[4] += (double)(t[9] - t[8]); d[5] += (double)(t[10] - t[9]);
                 d[6] += (double)(t[11] - t[10]); d[7] += (double)(t[5] - t[11]);
@@ -631,7 +723,7 @@ static int device_parse(HvqContext *c)
         }
     }
     for (size_t k = 0; k < idx.size(); ++k) {
-        Pending &p = c->pending[idx[k]];
+        Pending &p = c->fl_pending[idx[k]];
         if (res[k].status)
             return fail(res[k].status & GP_ST_OVERFLOW ? HVQ_E_OVERFLOW : HVQ_E_ARG,
                         "GPU parse failed (status %u) for stream %d picture %d", res[k].status, p.stream, p.ordinal);
@@ -661,27 +753,116 @@ static int run_launches(HvqContext *c)
     return HVQ_OK;
 }
 
-HVQ_EXPORT int hvq_flush(HvqContext *c)
+/* tile table of the batch in flight: one launch per dependency level (and queue), tiles dealt so that a picture stays
+ * on one XCD.  Needs nothing from the GPU, so it is built and uploaded while the parse kernel runs. */
+static int build_tiles(HvqContext *c)
+{
+    std::vector<HvqTileRef> &tiles = c->tiles_host;
+    tiles.clear();
+    c->fl_launches.clear();
+    int max_level = 0;
+    for (auto &p : c->fl_pending) max_level = std::max(max_level, p.level);
+    /* Two queues: clips are independent, so the dependency levels of the even and of the odd streams form two
+     * chains that run on two HIP streams -- while one chain drains a level the other keeps the CUs busy. */
+    const char *qenv = getenv("HVQM4_AMD_QUEUES");
+    /* measured +1.5 % on the bench workload; off by default so that per-kernel profiler durations stay comparable */
+    const int nq = (qenv && atoi(qenv) >= 2) ? 2 : 1;
+    for (int lvl = 0; lvl <= max_level; ++lvl)
+      for (int qi = 0; qi < nq; ++qi) {
+        std::vector<HvqTileRef> bins[8];
+        int nb = 0;
+        for (size_t i = 0; i < c->fl_pending.size(); ++i) {
+            const Pending &p = c->fl_pending[i];
+            if (p.level != lvl || (nq == 2 && (p.stream & 1) != qi)) continue;
+            auto &bin = bins[nb++ & 7];
+            for (uint32_t t = 0; t < p.ntiles; ++t) bin.push_back(HvqTileRef{ (uint32_t)i, t });
+        }
+        if (!nb) continue;
+        Launch L{ qi, lvl, (uint32_t)tiles.size(), 0, 0, 0 };
+        if (nb < 8) {
+            /* too few pictures to give every XCD its own: plain order, no padding */
+            for (int x = 0; x < nb; ++x) tiles.insert(tiles.end(), bins[x].begin(), bins[x].end());
+        } else {
+            /* blockIdx % 8 selects the XCD: entry 8k+x comes from bin x; ragged tails are padded
+             * with {0xFFFFFFFF,0} entries that exit at once */
+            size_t longest = 0;
+            for (auto &b : bins) longest = std::max(longest, b.size());
+            for (size_t k = 0; k < longest; ++k)
+                for (int x = 0; x < 8; ++x)
+                    tiles.push_back(k < bins[x].size() ? bins[x][k] : HvqTileRef{ 0xFFFFFFFFu, 0u });
+        }
+        L.ntiles = (uint32_t)tiles.size() - L.first_tile;
+        c->fl_launches.push_back(L);
+      }
+    c->fl_nq = nq;
+    if (tiles.size() > c->tiles_cap) {
+        if (c->tiles_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tiles_dev)); }
+        c->tiles_cap = tiles.size() * 2;
+        HIPCHK(hipMalloc((void **)&c->tiles_dev, c->tiles_cap * sizeof(HvqTileRef)));
+    }
+    return staged_upload(c, c->fl_arena_id, 1, c->tiles_dev, tiles.data(), tiles.size() * sizeof(HvqTileRef));
+}
+
+/* First half of a flush: everything that can be queued without waiting for the GPU.  The pending batch becomes the
+ * batch in flight; the caller may queue the NEXT batch (hvq_submit_*) before hvq_flush_end -- its bitstreams are copied
+ * and uploaded (other arena, copy stream) while this batch is being parsed. */
+HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
 {
     if (!c) return fail(HVQ_E_ARG, "null context");
-    if (c->pending.empty()) return HVQ_OK;
     HIPCHK(hipSetDevice(c->device));
-    /* 1. descriptors -> HBM (one copy) */
-    if (c->arena_used > c->arena_uploaded)
-        HIPCHK(hipMemcpyAsync(c->dev_arena + c->arena_uploaded, c->host_arena + c->arena_uploaded,
-                              c->arena_used - c->arena_uploaded, hipMemcpyHostToDevice, c->stream));
-    c->arena_uploaded = 0;
+    { int rc = flush_end(c); if (rc) return rc; }            /* at most one batch in flight */
+    if (c->pending.empty()) return HVQ_OK;
+    HIPCHK(hipEventSynchronize(c->ev_arena_free[c->arena_id]));   /* the pinned staging of this arena id is free again */
+    /* 1. descriptors / bitstreams -> HBM; the compute stream waits for the copy stream */
+    { int rc = arena_upload(c, c->arena_used); if (rc) return rc; }
+    HIPCHK(hipEventRecord(c->ev_copy, c->copy_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
     /* 1b. streams parsed on the GPU: bitstreams -> blobs, one launch */
-    { int rc = device_parse(c); if (rc) { c->pending.clear(); c->arena_used = 0; c->arena_uploaded = 0; for (auto &s : c->streams) s.nest_src = -1; return rc; } }
-    /* 2. job + tile tables, level by level, tiles dealt so that a picture stays on one XCD */
-    int max_level = 0;
-    for (auto &p : c->pending) max_level = std::max(max_level, p.level);
-    std::vector<HvqJob> jobs(c->pending.size());
-    std::vector<HvqTileRef> tiles;
-    c->launches.clear();
+    int rc = device_parse_launch(c);
+    /* the nest a GPU-parsed P/B picture uses: its batch's governing I picture, else the stream's kept one; the last I
+     * picture of every stream is committed to the other kept slot at the end of the batch */
+    c->fl_nest_pairs.clear();
+    for (auto &p : c->pending)
+        if (p.dev) {
+            const Stream &s = c->streams[(size_t)p.stream];
+            p.nest_ptr = p.nest_ref >= 0 ? c->pending[(size_t)p.nest_ref].dev_nest : (uint64_t)(uintptr_t)s.nest_keep_ptr(s.nest_cur);
+        }
+    for (auto &s : c->streams)
+        if (s.open && s.nest_src >= 0) {
+            c->fl_nest_pairs.push_back(c->pending[(size_t)s.nest_src].dev_nest);
+            c->fl_nest_pairs.push_back((uint64_t)(uintptr_t)s.nest_keep_ptr(s.nest_cur ^ 1));   /* replays of this batch keep reading [nest_cur] */
+            s.nest_cur ^= 1;
+            s.nest_src = -1;
+        }
+    /* the batch is in flight: levels restart from zero for whatever is queued next, which goes to the other arena */
+    c->fl_pending.swap(c->pending);
+    c->pending.clear();
+    for (auto &s : c->streams)
+        for (auto &sl : s.slots) { sl.w_level = -1; sl.r_level = -1; }
+    c->fl_host = c->host_arena; c->fl_dev = c->dev_arena; c->fl_arena_id = c->arena_id;
+    std::swap(c->host_arena, c->host_arena_alt);
+    std::swap(c->dev_arena, c->dev_arena_alt);
+    std::swap(c->arena_cap, c->arena_cap_alt);
+    c->arena_id ^= 1;
+    c->arena_used = 0; c->arena_uploaded = 0; c->arena_waited = false;
+    c->fl_active = true;
+    if (!rc) rc = build_tiles(c);
+    if (rc) { c->fl_active = false; c->fl_pending.clear(); c->fl_idx.clear(); return rc; }
+    return HVQ_OK;
+}
+
+/* Second half: take the parse results, build the job and tile tables, launch the reconstruction. */
+static int flush_end(HvqContext *c)
+{
+    if (!c->fl_active) return HVQ_OK;
+    c->fl_active = false;
+    { int rc = device_parse_finish(c); if (rc) { c->fl_pending.clear(); c->fl_idx.clear(); return rc; } }
+    /* 2. job table (the tile table went up at begin) */
+    std::vector<HvqJob> &jobs = c->jobs_host;
+    jobs.assign(c->fl_pending.size(), HvqJob{});
     HvqStats st{};
-    for (size_t i = 0; i < c->pending.size(); ++i) {
-        const Pending &p = c->pending[i];
+    for (size_t i = 0; i < c->fl_pending.size(); ++i) {
+        const Pending &p = c->fl_pending[i];
         const Stream &s = c->streams[(size_t)p.stream];
         HvqJob &j = jobs[i];
         memset(&j, 0, sizeof j);
@@ -692,8 +873,8 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
             if (p.kind == HVQ_PIC_I) hdev.mv_off = 0;
             hdev.nest_off = 1;
         }
-        const HvqPicHeader *hd = p.dev ? &hdev : (const HvqPicHeader *)(c->host_arena + p.blob_off);
-        const uint64_t blob = p.dev ? p.dev_blob : (uint64_t)(uintptr_t)(c->dev_arena + p.blob_off);
+        const HvqPicHeader *hd = p.dev ? &hdev : (const HvqPicHeader *)(c->fl_host + p.blob_off);
+        const uint64_t blob = p.dev ? p.dev_blob : (uint64_t)(uintptr_t)(c->fl_dev + p.blob_off);
         const uint64_t dst = (uint64_t)(uintptr_t)s.slot_ptr(p.dst);
         j.ref0 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref0);
         j.ref1 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref1);
@@ -701,7 +882,7 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         j.mv = blob + hd->mv_off;
         j.wave_base = blob + hd->wave_base_off;
         j.nest = hd->nest_off ? blob + hd->nest_off : 0;
-        if (p.dev) j.nest = p.nest_ref >= 0 ? c->pending[(size_t)p.nest_ref].dev_nest : (uint64_t)(uintptr_t)s.nest_keep_ptr(s.nest_cur);
+        if (p.dev) j.nest = p.nest_ptr;
         j.slot_bytes = s.slot_bytes;
         j.flags = hd->flags; j.width = hd->width; j.height = hd->height;
         j.pic_kind = hd->pic_kind; j.unk_shift = hd->unk_shift;
@@ -723,43 +904,19 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         st.flags_or |= hd->flags;
         st.gpu_parsed += p.dev ? 1u : 0u;
     }
-    /* Two queues: clips are independent, so the dependency levels of the even and of the odd streams form two
-     * chains that run on two HIP streams -- while one chain drains a level the other keeps the CUs busy. */
-    const char *qenv = getenv("HVQM4_AMD_QUEUES");
-    /* measured +1.5 % on the bench workload; off by default so that per-kernel profiler durations stay comparable */
-    const int nq = (qenv && atoi(qenv) >= 2) ? 2 : 1;
-    for (int lvl = 0; lvl <= max_level; ++lvl)
-      for (int qi = 0; qi < nq; ++qi) {
-        std::vector<HvqTileRef> bins[8];
-        int nb = 0;
+    /* LDS sizes of the launches (their tile ranges were dealt at begin): accumulators are 16 dwords per queued block,
+     * rows padded to 32 entries (LDS banks); pairs above the cap take the kernel's serial fallback */
+    for (auto &L : c->fl_launches) {
         uint32_t mi = 0, mp = 0;
-        for (size_t i = 0; i < c->pending.size(); ++i) {
-            const Pending &p = c->pending[i];
-            if (p.level != lvl || (nq == 2 && (p.stream & 1) != qi)) continue;
+        for (const Pending &p : c->fl_pending) {
+            if (p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
             mi = std::max(mi, p.max_items); mp = std::max(mp, p.max_pairs);
-            auto &bin = bins[nb++ & 7];
-            for (uint32_t t = 0; t < p.ntiles; ++t) bin.push_back(HvqTileRef{ (uint32_t)i, t });
         }
-        if (!nb) continue;
-        /* accumulators: 16 dwords per queued block, rows padded to 32 entries (LDS banks); pairs above the cap
-         * take the kernel's serial fallback */
-        Launch L{ qi, (uint32_t)tiles.size(), 0, std::max(32u, (mi + 31u) & ~31u), std::min(1024u, (mp + 63u) & ~63u) };
-        if (nb < 8) {
-            /* too few pictures to give every XCD its own: plain order, no padding */
-            for (int x = 0; x < nb; ++x) tiles.insert(tiles.end(), bins[x].begin(), bins[x].end());
-        } else {
-            /* blockIdx % 8 selects the XCD: entry 8k+x comes from bin x; ragged tails are padded
-             * with {0xFFFFFFFF,0} entries that exit at once */
-            size_t longest = 0;
-            for (auto &b : bins) longest = std::max(longest, b.size());
-            for (size_t k = 0; k < longest; ++k)
-                for (int x = 0; x < 8; ++x)
-                    tiles.push_back(k < bins[x].size() ? bins[x][k] : HvqTileRef{ 0xFFFFFFFFu, 0u });
-        }
-        L.ntiles = (uint32_t)tiles.size() - L.first_tile;
-        c->launches.push_back(L);
+        L.items_cap = std::max(32u, (mi + 31u) & ~31u);
+        L.pair_cap = std::min(1024u, (mp + 63u) & ~63u);
         st.workgroups += L.ntiles;
-      }
+    }
+    c->launches = c->fl_launches;
     st.launches = (uint32_t)c->launches.size();
     st.parse_seconds = c->parse_seconds;
     st.gpu_parse_ms = st.gpu_parsed ? c->gpu_parse_ms : 0.0;
@@ -768,44 +925,39 @@ HVQ_EXPORT int hvq_flush(HvqContext *c)
         c->jobs_cap = jobs.size() * 2;
         HIPCHK(hipMalloc((void **)&c->jobs_dev, c->jobs_cap * sizeof(HvqJob)));
     }
-    if (tiles.size() > c->tiles_cap) {
-        if (c->tiles_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tiles_dev)); }
-        c->tiles_cap = tiles.size() * 2;
-        HIPCHK(hipMalloc((void **)&c->tiles_dev, c->tiles_cap * sizeof(HvqTileRef)));
-    }
-    /* pageable sources: hipMemcpyAsync stages them before returning, so the vectors may die */
-    HIPCHK(hipMemcpyAsync(c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->tiles_dev, tiles.data(), tiles.size() * sizeof(HvqTileRef), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    /* stream-ordered after whatever still reads the previous table */
+    { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return rcu; }
     /* 3. one launch per level */
     { int rc = run_launches(c); if (rc) return rc; }
-    {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
-        std::vector<uint64_t> pairs;
-        for (auto &s : c->streams)
-            if (s.open && s.nest_src >= 0) {
-                pairs.push_back(c->pending[(size_t)s.nest_src].dev_nest);
-                pairs.push_back((uint64_t)(uintptr_t)s.nest_keep_ptr(s.nest_cur ^ 1));   /* replays of this batch keep reading [nest_cur] */
-                s.nest_cur ^= 1;
-                s.nest_src = -1;
-            }
-        if (!pairs.empty()) {
-            HIPCHK(hipMemcpyAsync(c->np_dev, pairs.data(), pairs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hvq_launch_nest_commit(c->np_dev, (uint32_t)(pairs.size() / 2), c->stream));
-        }
+    if (!c->fl_nest_pairs.empty()) {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
+        { int rcu = staged_upload(c, c->fl_arena_id, 3, c->np_dev, c->fl_nest_pairs.data(), c->fl_nest_pairs.size() * sizeof(uint64_t)); if (rcu) return rcu; }
+        HIPCHK(hvq_launch_nest_commit(c->np_dev, (uint32_t)(c->fl_nest_pairs.size() / 2), c->stream));
     }
+    HIPCHK(hipEventRecord(c->ev_arena_free[c->fl_arena_id], c->stream));    /* this batch's arena may be refilled after this */
     c->stats = st;
-    /* the batch is in flight: levels restart from zero for whatever is queued next */
-    for (auto &s : c->streams)
-        for (auto &sl : s.slots) { sl.w_level = -1; sl.r_level = -1; }
-    c->pending.clear();
-    c->arena_used = 0;      /* blobs stay valid in dev_arena until the next flush overwrites them */
+    c->fl_pending.clear();
+    c->fl_idx.clear();
     return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_flush_end(HvqContext *c)
+{
+    if (!c) return fail(HVQ_E_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    return flush_end(c);
+}
+
+HVQ_EXPORT int hvq_flush(HvqContext *c)
+{
+    int rc = hvq_flush_begin(c);
+    return rc ? rc : hvq_flush_end(c);
 }
 
 HVQ_EXPORT int hvq_sync(HvqContext *c)
 {
     if (!c) return fail(HVQ_E_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
+    { int rc = flush_end(c); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     return HVQ_OK;
 }
@@ -813,6 +965,7 @@ HVQ_EXPORT int hvq_sync(HvqContext *c)
 HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
 {
     if (!c || reps < 0) return fail(HVQ_E_ARG, "bad arguments");
+    { int rc = flush_end(c); if (rc) return rc; }
     if (c->launches.empty()) return fail(HVQ_E_STATE, "nothing flushed yet");
     if (!c->pending.empty()) return fail(HVQ_E_STATE, "pictures queued since the last flush");
     HIPCHK(hipSetDevice(c->device));
@@ -832,6 +985,7 @@ HVQ_EXPORT int hvq_read_picture(HvqContext *c, int sid, int ordinal, void *dst, 
     Stream &s = c->streams[sid];
     if (ordinal < 0 || ordinal >= s.npics) return fail(HVQ_E_ARG, "bad picture ordinal %d", ordinal);
     if (cap < s.pic_bytes) return fail(HVQ_E_ARG, "destination too small");
+    { int rc = flush_end(c); if (rc) return rc; }
     for (auto &p : c->pending)
         if (p.stream == sid && p.ordinal == ordinal) return fail(HVQ_E_STATE, "picture %d is queued but not flushed", ordinal);
     int slot = s.pic_slot[(size_t)ordinal];
@@ -881,6 +1035,7 @@ HVQ_EXPORT int hvq_read_picture_rgb(HvqContext *c, int sid, int ordinal, void *d
     const size_t need = (size_t)s.w * s.h * 3;
     if (cap < need) return fail(HVQ_E_ARG, "destination too small");
     if (s.pic_bytes != (uint32_t)(s.w * s.h * 3 / 2)) return fail(HVQ_E_GEOMETRY, "RGB epilogue needs 4:2:0");
+    { int rc = flush_end(c); if (rc) return rc; }
     for (auto &p : c->pending)
         if (p.stream == sid && p.ordinal == ordinal) return fail(HVQ_E_STATE, "picture %d is queued but not flushed", ordinal);
     int slot = s.pic_slot[(size_t)ordinal];
@@ -898,6 +1053,7 @@ HVQ_EXPORT int hvq_rgb_bench(HvqContext *c, int reps, float *gpu_ms, uint64_t *b
 {
     if (!c || reps < 1) return fail(HVQ_E_ARG, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
+    { int rc = flush_end(c); if (rc) return rc; }
     std::vector<RgbJob> jobs;
     uint64_t bytes = 0;
     for (auto &s : c->streams) {
@@ -918,6 +1074,7 @@ HVQ_EXPORT int hvq_rgb_bench(HvqContext *c, int reps, float *gpu_ms, uint64_t *b
 HVQ_EXPORT int hvq_get_stats(HvqContext *c, HvqStats *out)
 {
     if (!c || !out) return fail(HVQ_E_ARG, "bad arguments");
+    { int rc = flush_end(c); if (rc) return rc; }
     *out = c->stats;
     out->parse_seconds = c->parse_seconds;
     return HVQ_OK;

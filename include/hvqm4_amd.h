@@ -79,6 +79,14 @@ int  hvq_submit_many_device(HvqContext *ctx, int n, const int *streams, const in
 
 /* Upload queued descriptors, group queued pictures into dependency levels, launch. Async. */
 int  hvq_flush(HvqContext *ctx);
+
+/* The same in two halves, for streaming.  hvq_flush_begin queues what needs no answer from the GPU (uploads, the
+ * entropy-parse kernel) and returns; the queued batch is now "in flight" and the caller may already submit the NEXT
+ * batch -- its bitstreams are copied and uploaded (second arena, copy stream) while this one is parsed.
+ * hvq_flush_end takes the parse results, builds the launch tables and launches the reconstruction.  One batch can be
+ * in flight; every call that needs its pictures (sync, read, replay, stats, close) ends it implicitly. */
+int  hvq_flush_begin(HvqContext *ctx);
+int  hvq_flush_end(HvqContext *ctx);
 int  hvq_sync(HvqContext *ctx);
 
 /* Re-run the launches of the last flush `reps` times (descriptors already resident in HBM).

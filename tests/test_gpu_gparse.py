@@ -130,3 +130,42 @@ def test_large_and_extreme_geometries(gpu_ctx, w, h, samp):
     for gpu_parse in (False, True):
         got = batch.decode_clip(gpu_ctx, clip.data, gpu_parse=gpu_parse)
         assert np.array_equal(got, want), ("gpu parse" if gpu_parse else "host parse")
+
+
+@pytest.mark.parametrize("gpu_parse", [False, True], ids=["host_parse", "gpu_parse"])
+def test_pipelined_batches_begin_submit_next_end(gpu_ctx, gpu_parse):
+    """streaming use: the next batch is submitted (copied, uploaded) while the batch in flight is parsed --
+    hvq_flush_begin / hvq_submit_* / hvq_flush_end; two arenas alternate"""
+    from hvqm4_amd.container import parse_header, video_pictures
+    from oracle import bridge
+    cases = [clips.get(c) for c in (clips.SMALL[14], clips.SMALL[3], clips.SMALL[15])]      # 3 GOPs / 1 GOP / 1 GOP
+    hdrs = [parse_header(cl.data) for cl in cases]
+    pics = [list(video_pictures(cl.data)) for cl in cases]
+    sids = [gpu_ctx.open_stream(h.width, h.height, h.h_samp, h.v_samp, h.is15, len(p) + 3) for h, p in zip(hdrs, pics)]
+    step = 3                                                     # pictures per stream per batch
+    nb = max((len(p) + step - 1) // step for p in pics)
+
+    def submit(b):
+        a_s, a_t, a_p = [], [], []
+        for sid, p in zip(sids, pics):
+            for ft, _d, pic in p[b * step:(b + 1) * step]:
+                a_s.append(sid); a_t.append(ft); a_p.append(bytes(pic))
+        if not a_p:
+            return
+        if gpu_parse:
+            gpu_ctx.submit_many_device(a_s, a_t, a_p)
+        else:
+            gpu_ctx.submit_many(a_s, a_t, a_p, 2)
+
+    submit(0)
+    gpu_ctx.flush_begin()
+    for b in range(1, nb):
+        submit(b)                                               # while batch b-1 is in flight
+        gpu_ctx.flush_end()
+        gpu_ctx.flush_begin()
+    gpu_ctx.flush_end()
+    for sid, cl in zip(sids, cases):
+        want = bridge.oracle_decode(cl.data, cl.n_pictures)
+        for k in range(cl.n_pictures):
+            assert np.array_equal(gpu_ctx.read_picture(sid, k), want[k]), (cl.width, k)
+        gpu_ctx.close_stream(sid)
