@@ -36,6 +36,10 @@
 typedef uint32_t u32;
 typedef int32_t i32;
 typedef uint64_t __attribute__((aligned(1))) u64u;
+/* Everything in HBM is addressed through global-address-space pointers.  A generic pointer becomes flat_load /
+ * flat_store, which count on the LDS counter as well: every s_waitcnt for an LDS access would then also wait for all
+ * outstanding HBM loads of the wave. */
+#define GLB __attribute__((address_space(1)))
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -85,13 +89,13 @@ __device__ __forceinline__ i32 clampi(i32 v, i32 lo, i32 hi) { return min(max(v,
  * source sample inside the reference picture buffer. */
 struct McRows { uint64_t q[5]; };
 
-__device__ __forceinline__ McRows mc_load(const uint8_t *ref, i32 a, i32 stride, int hy, i32 amax8)
+__device__ __forceinline__ McRows mc_load(const GLB uint8_t *ref, i32 a, i32 stride, int hy, i32 amax8)
 {
     McRows r;
 #pragma unroll
-    for (int y = 0; y < 4; ++y) r.q[y] = *(const u64u *)(ref + clampi(a + y * stride, 0, amax8));
+    for (int y = 0; y < 4; ++y) r.q[y] = *(const GLB u64u *)(ref + clampi(a + y * stride, 0, amax8));
     r.q[4] = 0;
-    if (hy) r.q[4] = *(const u64u *)(ref + clampi(a + 4 * stride, 0, amax8));   /* 5th row only for vertical half samples */
+    if (hy) r.q[4] = *(const GLB u64u *)(ref + clampi(a + 4 * stride, 0, amax8));   /* 5th row only for vertical half samples */
     return r;
 }
 
@@ -128,7 +132,7 @@ __device__ __forceinline__ Blk mc_filter(const McRows &rows, int hx, int hy)
     return o;
 }
 
-__device__ __forceinline__ Blk mc_block(const uint8_t *ref, i32 a, i32 stride, int hx, int hy, i32 amax8)
+__device__ __forceinline__ Blk mc_block(const GLB uint8_t *ref, i32 a, i32 stride, int hx, int hy, i32 amax8)
 {
     return mc_filter(mc_load(ref, a, stride, hy, amax8), hx, hy);
 }
@@ -219,7 +223,7 @@ __device__ __forceinline__ void gather_nest(u32 d, bool landscape, const uint8_t
 
 /* nest gather for one basis, MC residual: the nest is a 70x38 window of the reference LUMA plane
  * (h4m:1865-1868, 734-765); each basis row (4 samples at stride 1 or 2) is one unaligned 8-byte load */
-__device__ __forceinline__ void gather_window(u32 d, bool landscape, const uint8_t *ref, i32 origin, i32 lw, i32 slot,
+__device__ __forceinline__ void gather_window(u32 d, bool landscape, const GLB uint8_t *ref, i32 origin, i32 lw, i32 slot,
                                               u32 e[16], u32 &lo, u32 &hi)
 {
     i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
@@ -230,7 +234,7 @@ __device__ __forceinline__ void gather_window(u32 d, bool landscape, const uint8
     const u32 sel = x2 ? 0x06040200u : 0x03020100u;                 /* stride 2: bytes 0,2,4,6 */
     uint64_t q[4];
 #pragma unroll
-    for (int y = 0; y < 4; ++y) q[y] = *(const u64u *)(ref + clampi(origin + o + y * ys, 0, slot - 8));
+    for (int y = 0; y < 4; ++y) q[y] = *(const GLB u64u *)(ref + clampi(origin + o + y * ys, 0, slot - 8));
     lo = 255; hi = 0;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
@@ -384,11 +388,11 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
     const bool big = flags & HVQ_F_BIG_AOT;
-    const uint8_t *map = (const uint8_t *)R->map;
-    const u32 *__restrict__ pool = (const u32 *)J->pool;
-    const u32 *__restrict__ mvs = (const u32 *)J->mv;
+    const GLB uint8_t *map = (const GLB uint8_t *)R->map;
+    const GLB u32 *__restrict__ pool = (const GLB u32 *)J->pool;
+    const GLB u32 *__restrict__ mvs = (const GLB u32 *)J->mv;
     const i32 plane_off = (i32)R->plane_off;
-    uint8_t *plane = (uint8_t *)R->dst;
+    GLB uint8_t *plane = (GLB uint8_t *)R->dst;
     const i32 slot = (i32)J->slot_bytes;
     const i32 mcb_w = (i32)J->mcb_w;
     const i32 lw = J->width;
@@ -398,14 +402,14 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const bool valid = b < nblocks;
     i32 bx, by;
     block_coords(valid ? b : 0u, hb, rhb, bx, by);
-    const uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
+    const GLB uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
     /* independent loads first: own entry, four neighbours, vector, wave payload base */
-    const u32 e16 = *(const uint16_t *)ent;
-    const u32 nt = *(const uint16_t *)(ent - 2 * mstride), nbt = *(const uint16_t *)(ent + 2 * mstride);
-    const u32 nl = *(const uint16_t *)(ent - 2), nr = *(const uint16_t *)(ent + 2);
+    const u32 e16 = *(const GLB uint16_t *)ent;
+    const u32 nt = *(const GLB uint16_t *)(ent - 2 * mstride), nbt = *(const GLB uint16_t *)(ent + 2 * mstride);
+    const u32 nl = *(const GLB uint16_t *)(ent - 2), nr = *(const GLB uint16_t *)(ent + 2);
     u32 mvw = 0;
     if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
-    const u32 wbase = ((const u32 *)J->wave_base)[tile * HVQ_NW + (u32)wave];
+    const u32 wbase = ((const GLB u32 *)J->wave_base)[tile * HVQ_NW + (u32)wave];
 
     const i32 V = e16 & 0xFF;
     const u32 T = valid ? (e16 >> 8) : 0u;
@@ -426,12 +430,12 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 
     if (HVQ_ABL != 4 && HVQ_ABL != 5 && valid && cls != 1) {
         Blk o;
-        const u32 *__restrict__ pay = pool + off;
+        const GLB u32 *__restrict__ pay = pool + off;
         const bool needs_mc = inter && (cls == 2 || (T & 0x10u) || kind == 0);
         if (needs_mc) {
             /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
             const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-            const uint8_t *ref = (const uint8_t *)((((T >> 5) & 3u) == 1u) ? J->ref0 : J->ref1);
+            const GLB uint8_t *ref = (const GLB uint8_t *)((((T >> 5) & 3u) == 1u) ? J->ref0 : J->ref1);
             const i32 pdx = rx >> ws, pdy = ry >> hs;
             const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
             const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
@@ -481,7 +485,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         }
     }
     if (nI) {
-        const u32 *src = (const u32 *)J->nest;                /* already nibble-packed by the host */
+        const GLB u32 *src = (const GLB u32 *)J->nest;                /* already nibble-packed by the host */
         for (int i = tid; i < (HVQ_NESTP_BYTES + 3) / 4; i += HVQ_WG) ((u32 *)s_nest)[i] = src[i];
     }
     if (total) __syncthreads();                                                /* barrier 2: queue + nest staged */
@@ -490,7 +494,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         const bool has_item = (u32)tid < total;
         const bool item_mc = has_item && (u32)tid >= nI;
         u32 owner = 0, q16 = 0, p0 = 0, p1 = 0;
-        const u32 *__restrict__ qpay = pool;
+        const GLB u32 *__restrict__ qpay = pool;
         if (has_item) {
             const u32 item = s_item0[tid];
             owner = item & 1023u;
@@ -512,7 +516,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
                 } else {
                     const u32 t16 = s_item1[it], mv = s_item2[it];
                     const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
-                    const uint8_t *ref = (const uint8_t *)(((t16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
+                    const GLB uint8_t *ref = (const GLB uint8_t *)(((t16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
                     const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
                     gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
                 }
@@ -530,10 +534,10 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             for (int i = 0; i < 16; ++i) acc[i] = 0;
             const bool intra_item = (u32)tid < nI;
             const u32 n = intra_item ? (I_luma ? (q16 >> 8) : ((q16 >> 8) & 0xFu)) : ((q16 >> 8) & 0xFu) - 1u;
-            const u32 *bases = qpay + (intra_item ? 0 : 2);
+            const GLB u32 *bases = qpay + (intra_item ? 0 : 2);
             const u32 mv = s_item2[tid];
             const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
-            const uint8_t *ref = (const uint8_t *)(((q16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
+            const GLB uint8_t *ref = (const GLB uint8_t *)(((q16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
             const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
             for (u32 k = 0; k < n; ++k) {
                 const u32 d = bases[k];
@@ -578,13 +582,14 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         if (gb < nblocks) {
             i32 gx, gy;
             block_coords(gb, hb, rhb, gx, gy);
-            const uint4 v = *(const uint4 *)&s_out[rr][4 * g];
-            *(uint4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = *(const u32x4 *)&s_out[rr][4 * g];
+            *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
         }
     } else if (valid) {
-        uint8_t *dst = plane + (size_t)(by * 4) * pw + bx * 4;
+        GLB uint8_t *dst = plane + (size_t)(by * 4) * pw + bx * 4;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) *(u32 *)(dst + (size_t)y * pw) = s_out[y][tid];
+        for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[y][tid];
     }
 }
 
