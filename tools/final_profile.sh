@@ -6,6 +6,7 @@ T=${1:-final}
 O=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python -m pytest tests -m gpu -x -q > $O/${T}_gpu_tests.log 2>&1 || { tail -20 $O/${T}_gpu_tests.log; exit 1; }
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/${T}_smoke.log 2>&1 || { tail -5 $O/${T}_smoke.log; exit 1; }
 timeout -k 10 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err || { tail -5 $O/${T}_bench.err; exit 1; }
 timeout -k 10 400 python bench.py --preset natural > $O/${T}_bench_natural.json 2> $O/${T}_bench_natural.err || exit 1
 cd /tmp && export TMPDIR=/tmp
