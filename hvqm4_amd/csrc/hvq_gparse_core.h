@@ -51,7 +51,12 @@
 #define GP_ST(lvalue, value) do { (lvalue) = (value); } while (0)
 
 #define GP_LUT_BITS 8
-#define GP_MAX_OVF_ITER 65536
+/* caps of the overflow-symbol loops (the reference has none: h4m:654-677 loop for as long as the stream says).  A
+ * signed-overflow value (DC delta, MC-residual scalar) is a handful of symbols in any real stream; a run count is at
+ * most the number of macroblocks, 255 per symbol.  The caps are the same in hvq_parse.c, so malformed streams still
+ * give identical blobs, and they bound a picture's decode time whatever the stream contains. */
+#define GP_SOVF_CAP 256
+#define GP_UOVF_CAP(nmb) ((int)((nmb) / 255u) + 16)
 #define GP_ALIGN16(x) (((x) + 15u) & ~15u)
 
 /* status bits of HvqParseResult.status */
@@ -249,15 +254,15 @@ GP_FN int32_t gsym_sovf(const GCode *c, GBits *b, int32_t lo, int32_t hi)      /
     uint32_t total = 0;
     int32_t v;
     int guard = 0;
-    do { v = gsym(c, b); total += (uint32_t)v; } while ((v <= lo || v >= hi) && ++guard < GP_MAX_OVF_ITER);
+    do { v = gsym(c, b); total += (uint32_t)v; } while ((v <= lo || v >= hi) && ++guard < GP_SOVF_CAP);
     return (int32_t)total;
 }
 
-GP_FN int32_t gsym_uovf(const GCode *c, GBits *b)                               /* h4m:667-677 */
+GP_FN int32_t gsym_uovf(const GCode *c, GBits *b, int cap)                      /* h4m:667-677 */
 {
     int32_t total = 0, v;
     int guard = 0;
-    do { v = gsym(c, b); total += v; } while (v >= 0xFF && ++guard < GP_MAX_OVF_ITER);
+    do { v = gsym(c, b); total += v; } while (v >= 0xFF && ++guard < cap);
     return total;
 }
 
@@ -897,8 +902,9 @@ GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
     if (g->status) return;
     GBits b = g->mtype;
     const GCode *c = &codes[GC_MCB];
+    const int cap = GP_UOVF_CAP((uint32_t)g->mw * (uint32_t)g->mh);
     uint32_t value = 0, count = 0;
-    if (b.live) { value = gb_take(&b, 2); count = (uint32_t)gsym_uovf(c, &b); }
+    if (b.live) { value = gb_take(&b, 2); count = (uint32_t)gsym_uovf(c, &b, cap); }
     const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
     for (uint32_t m = 0; m < n; ++m) {
         if (count == 0) {
@@ -906,7 +912,7 @@ GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
             const uint32_t v = value & 3u;
             /* step table { {1,2,0,2}, {2,0,1,0} } of hvq_parse.c pb_pass1 */
             value = bit ? (v == 0 ? 2u : (v == 2 ? 1u : 0u)) : (v == 0 ? 1u : (v == 2 ? 0u : 2u));
-            count = (uint32_t)gsym_uovf(c, &b);
+            count = (uint32_t)gsym_uovf(c, &b, cap);
         }
         --count;
         GP_ST(g->mbtype[m], (uint8_t)value);
@@ -922,14 +928,15 @@ GP_FN void gp_mbprocs(GPic *g, const GCode *codes)
     if (g->status) return;
     GBits b = g->mproc;
     const GCode *c = &codes[GC_MCB];
+    const int cap = GP_UOVF_CAP((uint32_t)g->mw * (uint32_t)g->mh);
     uint32_t value = 0, count = 0;
-    if (b.live) { value = gb_take(&b, 1); count = (uint32_t)gsym_uovf(c, &b); }
+    if (b.live) { value = gb_take(&b, 1); count = (uint32_t)gsym_uovf(c, &b, cap); }
     const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
     for (uint32_t m = 0; m < n; ++m) {
         if (count == 0) {
             if (b.idx > b.nd + 2u) break;
             value ^= 1u;
-            count = (uint32_t)gsym_uovf(c, &b);
+            count = (uint32_t)gsym_uovf(c, &b, cap);
         }
         --count;
         GP_ST(g->procseq[m], (uint8_t)value);

@@ -17,7 +17,9 @@
 #include <string.h>
 
 #define LUT_BITS 10
-#define MAX_OVF_ITER 65536
+/* caps of the overflow-symbol loops, identical in hvq_gparse_core.h (see there) */
+#define SOVF_CAP 256
+#define UOVF_CAP(nmb) ((int)((nmb) / 255u) + 16)
 
 /* ------------------------------------------------------------------ bit reader */
 typedef struct {
@@ -131,15 +133,15 @@ static int32_t sym_sovf(const Code *c, BitRd *b, int32_t lo, int32_t hi)       /
     uint32_t total = 0;
     int32_t v;
     int guard = 0;
-    do { v = sym(c, b); total += (uint32_t)v; } while ((v <= lo || v >= hi) && ++guard < MAX_OVF_ITER);
+    do { v = sym(c, b); total += (uint32_t)v; } while ((v <= lo || v >= hi) && ++guard < SOVF_CAP);
     return (int32_t)total;
 }
 
-static int32_t sym_uovf(const Code *c, BitRd *b)                               /* h4m:667-677 */
+static int32_t sym_uovf(const Code *c, BitRd *b, int cap)                      /* h4m:667-677 */
 {
     int32_t total = 0, v;
     int guard = 0;
-    do { v = sym(c, b); total += v; } while (v >= 0xFF && ++guard < MAX_OVF_ITER);
+    do { v = sym(c, b); total += v; } while (v >= 0xFF && ++guard < cap);
     return total;
 }
 
@@ -573,9 +575,10 @@ static void pb_kinds(HvqParser *p, uint8_t *blob, int mx, int my, uint32_t proc,
 static void pb_pass1(HvqParser *p, uint8_t *blob, int is_P)                      /* h4m:1545-1622, 1649-1668, 1742-1776 */
 {
     static const uint32_t step[2][4] = { { 1, 2, 0, 2 }, { 2, 0, 1, 0 } };
+    const int cap = UOVF_CAP((uint32_t)(p->w / 8) * (uint32_t)(p->h / 8));
     RunLen type = { 0, 0 }, proc = { 0, 0 };
-    if (p->mproc.live) { proc.value = br_take(&p->mproc, 1); proc.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mproc); }
-    if (p->mtype.live) { type.value = br_take(&p->mtype, 2); type.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mtype); }
+    if (p->mproc.live) { proc.value = br_take(&p->mproc, 1); proc.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mproc, cap); }
+    if (p->mtype.live) { type.value = br_take(&p->mtype, 2); type.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mtype, cap); }
     uint32_t rl[2] = { 0, 0 };
     uint32_t pbdc[3] = { 0x7F, 0x7F, 0x7F };
     int mw = p->w / 8, mh = p->h / 8;
@@ -583,7 +586,7 @@ static void pb_pass1(HvqParser *p, uint8_t *blob, int is_P)                     
         for (int mx = 0; mx < mw; ++mx) {
             if (type.count == 0) {
                 type.value = step[br_take(&p->mtype, 1)][type.value & 3];
-                type.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mtype);
+                type.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mtype, cap);
             }
             --type.count;
             if (type.value == 0) {
@@ -599,7 +602,7 @@ static void pb_pass1(HvqParser *p, uint8_t *blob, int is_P)                     
             } else {
                 if (is_P && type.value >= 2) p->flags |= HVQ_F_SELF_REF;
                 pbdc[0] = pbdc[1] = pbdc[2] = 0x7F;
-                if (proc.count == 0) { proc.value ^= 1; proc.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mproc); }
+                if (proc.count == 0) { proc.value ^= 1; proc.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mproc, cap); }
                 --proc.count;
                 pb_kinds(p, blob, mx, my, proc.value, type.value, rl);
             }

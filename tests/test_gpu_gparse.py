@@ -169,3 +169,36 @@ def test_pipelined_batches_begin_submit_next_end(gpu_ctx, gpu_parse):
         for k in range(cl.n_pictures):
             assert np.array_equal(gpu_ctx.read_picture(sid, k), want[k]), (cl.width, k)
         gpu_ctx.close_stream(sid)
+
+
+def test_pathological_trees_cannot_stall_the_gpu_parser(gpu_ctx):
+    """A one-leaf DC tree whose only value lies outside the overflow window makes every DC read spin until its cap
+    (the reference would never return).  Full-size pictures of that kind, of zeros and of ones must come back
+    quickly -- the caps bound a picture's decode time whatever the stream says."""
+    import struct
+    import time
+    from hvqm4_amd.container import parse_header, video_pictures
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    clip = make_clip(SynthConfig(width=640, height=480, gop="IPB", seed=77))
+    hdr = parse_header(clip.data)
+    variants = []
+    for ft, _d, pic in video_pictures(clip.data):
+        p = bytearray(pic)
+        data = 8 + (0x40 if ft == 0x10 else 0x44)
+        off = data + struct.unpack_from(">I", p, 8 + 4 * 4)[0] + 4          # section 4 = DC buffer of the luma plane
+        p[0] = 0                                                             # dc_shift 0: window is (-128, 127)
+        p[off:off + 2] = b"\x3f\x80"                                         # tree = single leaf 0x7F
+        variants.append((ft, bytes(p)))
+        variants.append((ft, bytes(p[:0x60]) + bytes(len(p) - 0x60)))        # all zero after the header
+        variants.append((ft, bytes(p[:0x60]) + b"\xff" * (len(p) - 0x60)))   # all ones
+    t0 = time.time()
+    for ft, data in variants:
+        sid = gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, 4)
+        try:
+            gpu_ctx.submit_many_device([sid], [ft], [data])
+            gpu_ctx.flush()
+            gpu_ctx.sync()
+        except Exception:
+            pass
+        gpu_ctx.close_stream(sid)
+    assert time.time() - t0 < 20.0
