@@ -237,6 +237,29 @@ def main():
     except Exception as e:      # never let the optional epilogue measurement break the headline number
         out["rgb_epilogue"] = {"error": str(e)}
 
+    # the SDK boundary itself (PCIe-inclusive, never `value`): one stream, one synchronous call per picture -- upload
+    # of the caller's reference pictures, host parse, launch, download of the decoded picture
+    if rank == 0 and world == 1:
+        try:
+            from hvqm4_amd import sdk
+            pl = sdk.Player(args.width, args.height, 2, 2, True)
+            seq = pics[0]
+            for ft, _d, pic in seq:                                  # warm-up pass
+                pl.decode(ft, bytes(pic))
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                for ft, _d, pic in seq:
+                    pl.decode(ft, bytes(pic))
+            dt = (time.perf_counter() - t0) / (reps * len(seq))
+            pl.close()
+            out["sdk_path"] = {"value": round(args.width * args.height / dt / 1e6, 1), "unit": "Mpixels/s",
+                               "ms_per_picture": round(dt * 1e3, 3),
+                               "what": "HVQM4DecodeIpic/Ppic/Bpic through the C ABI with host picture buffers, one "
+                                       "synchronous picture at a time (PCIe both ways inside the call)"}
+        except Exception as e:
+            out["sdk_path"] = {"error": str(e)}
+
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(clips[0], args.cpu_seconds)
     if rank == 0:
