@@ -577,7 +577,8 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
         int hi = lo;
         size_t bytes = 0;
         while (hi < n && bytes < chunk_bytes) { bytes += align_up(lens[hi] + 16, 256); ++hi; }
-        const int nt = bytes >= ((size_t)4 << 20) ? 4 : 1;
+        static const int copy_threads = getenv("HVQM4_AMD_COPY_THREADS") ? std::max(1, atoi(getenv("HVQM4_AMD_COPY_THREADS"))) : 4;
+        const int nt = bytes >= ((size_t)4 << 20) ? copy_threads : 1;
         if (nt == 1) copy_range(lo, hi);
         else {
             std::vector<std::thread> pool;
