@@ -305,7 +305,7 @@ typedef struct {
     int32_t dc_lo, dc_hi;
     uint8_t res[8];              /* h0 h1 v0 v1 0 0 (h4m:2023-2026; indexed by reference 0..2 like hvq_parse.c) */
     uint32_t flags, status;
-    uint32_t max_items, max_pairs, pool_dwords, total, nest_off;
+    uint32_t max_items, max_pairs, pool_dwords, total;
     uint64_t fx_off[3];          /* byte offset of the fixed-length sections (basis words, literal blocks) */
     uint32_t nchain[3];          /* entries in clist per plane */
     uint32_t ncoded, ntype0;     /* entries of cmb / t0 */
@@ -318,7 +318,6 @@ typedef struct {
 #define GP_PART 4096
 #define GP_PART2 512
 #define GP_MISC 992
-#define GP_MAX_THREADS 480
 #define GP_EP(plane, which, tid) (1024 + ((plane) * 2 + (which)) * 512 + (tid))
 
 GP_FN uint32_t gp_be32(const GPic *g, uint64_t off)
@@ -392,7 +391,7 @@ GP_FN void gp_setup(GPic *g, const HvqParseJob *job)
     g->cmb = (GP_G uint32_t *)s;         s += GP_ALIGN16(4u * nmb + 16u);
     g->t0 = (GP_G uint32_t *)s;          s += GP_ALIGN16(4u * nmb + 16u);
     g->part = (GP_G uint32_t *)s;
-    g->flags = 0; g->status = 0; g->max_items = 0; g->max_pairs = 0; g->pool_dwords = 0; g->total = 0; g->nest_off = 0;
+    g->flags = 0; g->status = 0; g->max_items = 0; g->max_pairs = 0; g->pool_dwords = 0; g->total = 0;
     if (g->cap < g->fixed_bytes || g->len < 8 + 0x44 + 4) g->status |= GP_ST_BADARG;
 }
 

@@ -158,7 +158,6 @@ struct HvqContext {
     struct Pinned { uint8_t *p = nullptr; size_t cap = 0; } pin[2][4];   /* [arena id][parse jobs, tiles, jobs, nest pairs] */
     std::vector<HvqJob> jobs_host;     /* the tables are built here, then copied into the pinned staging */
     std::vector<HvqTileRef> tiles_host;
-    std::vector<uint64_t> pairs_host;
     std::vector<HvqParseJob> pjobs_host;
     /* last flushed batch (kept resident for hvq_replay) */
     HvqJob *jobs_dev = nullptr;
