@@ -584,7 +584,10 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             block_coords(gb, hb, rhb, gx, gy);
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = *(const u32x4 *)&s_out[rr][4 * g];
-            *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
+            /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors
+             * in L2 (+1 % on MC-dominated streams, neutral on the dense one; profiles/r01j_ab_nontemporal.txt) */
+            if (J->pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
+            else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
         }
     } else if (valid) {
         GLB uint8_t *dst = plane + (size_t)(by * 4) * pw + bx * 4;
