@@ -217,6 +217,14 @@ static int arena_upload(HvqContext *c, size_t upto)
 
 static int flush_end(HvqContext *c);
 
+/* HVQM4_AMD_FLUSH_TIMING=1: host-side timeline of the flush halves on stderr (development aid) */
+static bool flush_timing() { static const bool on = getenv("HVQM4_AMD_FLUSH_TIMING") != nullptr; return on; }
+static double now_ms()
+{
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 /* copy `bytes` into pinned staging buffer [id][which] and queue its upload to `dst` on the compute stream */
 static int staged_upload(HvqContext *c, int id, int which, void *dst, const void *src, size_t bytes)
 {
@@ -812,6 +820,7 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
     HIPCHK(hipSetDevice(c->device));
     { int rc = flush_end(c); if (rc) return rc; }            /* at most one batch in flight */
     if (c->pending.empty()) return HVQ_OK;
+    const double tb0 = now_ms();
     HIPCHK(hipEventSynchronize(c->ev_arena_free[c->arena_id]));   /* the pinned staging of this arena id is free again */
     /* 1. descriptors / bitstreams -> HBM; the compute stream waits for the copy stream */
     { int rc = arena_upload(c, c->arena_used); if (rc) return rc; }
@@ -848,6 +857,7 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
     c->fl_active = true;
     if (!rc) rc = build_tiles(c);
     if (rc) { c->fl_active = false; c->fl_pending.clear(); c->fl_idx.clear(); return rc; }
+    if (flush_timing()) fprintf(stderr, "flush_begin %.3f -> %.3f ms\n", tb0, now_ms());
     return HVQ_OK;
 }
 
@@ -856,7 +866,9 @@ static int flush_end(HvqContext *c)
 {
     if (!c->fl_active) return HVQ_OK;
     c->fl_active = false;
+    const double te0 = now_ms();
     { int rc = device_parse_finish(c); if (rc) { c->fl_pending.clear(); c->fl_idx.clear(); return rc; } }
+    const double te1 = now_ms();
     /* 2. job table (the tile table went up at begin) */
     std::vector<HvqJob> &jobs = c->jobs_host;
     jobs.assign(c->fl_pending.size(), HvqJob{});
@@ -937,6 +949,7 @@ static int flush_end(HvqContext *c)
     c->stats = st;
     c->fl_pending.clear();
     c->fl_idx.clear();
+    if (flush_timing()) fprintf(stderr, "flush_end   %.3f: parse results at %.3f, launches queued %.3f ms (parse kernel %.3f ms)\n", te0, te1, now_ms(), c->gpu_parse_ms);
     return HVQ_OK;
 }
 
