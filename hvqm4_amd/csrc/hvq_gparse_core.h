@@ -95,7 +95,7 @@ typedef struct HvqParseResult {   /* what the host needs back to size and order 
  * instead of one per 4.  (Keeping look-ahead dwords in registers does not work: the compiler's register copies of a
  * freshly requested dword make it wait for the load on the spot.) */
 #define GP_BLK 32
-#define GP_SLOTS 14
+#define GP_SLOTS 18           /* 14 bitstream cursors + 4 list readers (GList) */
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 __shared__ uint32_t gp_stage[GP_SLOTS * GP_BLK];
@@ -161,20 +161,28 @@ GP_FN uint32_t gb_take(GBits *b, int n)        /* n <= 32 */
     return v;
 }
 
-/* sequential reader of a byte array in HBM (macroblock types / tags), four bytes per load, one load ahead; the array
- * must be readable up to 8 bytes past its last element */
+/* sequential reader of a u32 array in HBM (work lists written by the parallel phases), staged through LDS exactly like
+ * the bitstream: one coalesced load per GP_BLK entries instead of a dependent load per entry */
 typedef struct {
     const GP_G uint32_t *p;
-    uint32_t cur, nxt, i;
-} GBytes;
+    uint32_t n, idx, base, slot;
+} GList;
 
-GP_FN void gby_init(GBytes *b, const GP_G uint8_t *a) { b->p = (const GP_G uint32_t *)a; b->cur = b->p[0]; b->nxt = b->p[1]; b->i = 0; }
+GP_FN void gl_init(GList *l, const GP_G uint32_t *p, uint32_t n, uint32_t slot) { l->p = p; l->n = n; l->idx = 0; l->base = ~0u; l->slot = slot; }
 
-GP_FN uint32_t gby_next(GBytes *b)
+GP_FN uint32_t gl_next(GList *l)
 {
-    const uint32_t v = (b->cur >> (8u * (b->i & 3u))) & 0xFFu;
-    if ((++b->i & 3u) == 0) { b->cur = b->nxt; b->nxt = b->p[(b->i >> 2) + 1]; }
-    return v;
+    const uint32_t blk = l->idx & ~(uint32_t)(GP_BLK - 1);
+    if (blk != l->base) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        const int lane = GP_LANE();
+        if (lane < GP_BLK) gp_stage[l->slot * GP_BLK + (uint32_t)lane] = blk + (uint32_t)lane < l->n ? l->p[blk + (uint32_t)lane] : 0u;
+#else
+        for (uint32_t k = 0; k < GP_BLK; ++k) gp_stage[l->slot * GP_BLK + k] = blk + k < l->n ? l->p[blk + k] : 0u;
+#endif
+        l->base = blk;
+    }
+    return gp_stage[l->slot * GP_BLK + (l->idx++ & (GP_BLK - 1))];
 }
 
 /* ------------------------------------------------------------------ prefix trees (h4m:385-394, 604-651) */
@@ -806,12 +814,11 @@ GP_FN void gp_payload(GPic *g, const GCode *codes, int i)
     GBits bt = g->bt[i];
     const GCode *c_bt = &codes[GC_BT];
     GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
-    const GP_G uint32_t *ents = g->clist + g->pl[i].blk_first;
     const uint32_t n = g->nchain[i];
-    uint32_t next = n ? ents[0] : 0u;
+    GList ents;
+    gl_init(&ents, g->clist + g->pl[i].blk_first, n, i == 0 ? 14u : 15u);
     for (uint32_t e = 0; e < n; ++e) {
-        const uint32_t ent = next;
-        if (e + 1 < n) next = ents[e + 1];                              /* requested one entry ahead */
+        const uint32_t ent = gl_next(&ents);
         const uint32_t nb = (ent >> 22) & 0xFFu;
         GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu) + ((ent >> 30) == GP_MODE_PREDI ? 2u : 0u);
         uint32_t run = 0;
@@ -829,12 +836,11 @@ GP_FN void gp_predi_params(GPic *g, const GCode *codes, int i)
     const int32_t lo = g->dc_lo, hi = g->dc_hi;
     const int sh_dc = g->dc_shift & 31, sh_unk = g->unk_shift & 31;
     GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
-    const GP_G uint32_t *ents = g->clist + g->pl[i].blk_first;
     const uint32_t n = g->nchain[i];
-    uint32_t next = n ? ents[0] : 0u;
+    GList ents;
+    gl_init(&ents, g->clist + g->pl[i].blk_first, n, 16u);
     for (uint32_t e = 0; e < n; ++e) {
-        const uint32_t ent = next;
-        if (e + 1 < n) next = ents[e + 1];
+        const uint32_t ent = gl_next(&ents);
         if ((ent >> 30) != GP_MODE_PREDI) continue;
         GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
         const int32_t s1 = gsym_sovf(c_dc, &dc, lo, hi);
@@ -1078,10 +1084,10 @@ GP_FN void gp_pbdc(GPic *g, const GCode *codes, int i)
     GP_G uint8_t *dv = (GP_G uint8_t *)g->pinfo + g->pl[i].blk_first;
     const uint32_t n = g->ntype0;
     uint32_t pbdc = 0x7F, prev = ~0u, at = 0;
-    uint32_t next = n ? g->t0[0] : 0u;
+    GList t0;
+    gl_init(&t0, g->t0, n, i == 0 ? 14u : 15u);
     for (uint32_t r = 0; r < n; ++r) {
-        const uint32_t m = next;
-        if (r + 1 < n) next = g->t0[r + 1];
+        const uint32_t m = gl_next(&t0);
         if (m != prev + 1u) pbdc = 0x7F;                                /* a non-intra macroblock in between resets */
         prev = m;
         for (int j = 0; j < nblk; ++j) {
@@ -1119,12 +1125,13 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp)
     GP_G int16_t *mvs = (GP_G int16_t *)(g->blob + g->mv_off);
     int cur_ref = -1;
     int32_t acc = 0;
-    uint32_t fl = 0, m = 0;
-    GBytes types;
-    gby_init(&types, g->mbtype);
+    uint32_t fl = 0, m = 0, w4 = 0;
+    GList types;                                                         /* the type bytes, four per entry */
+    gl_init(&types, (const GP_G uint32_t *)g->mbtype, ((uint32_t)g->mw * (uint32_t)g->mh + 3u) / 4u, 17u);
     for (int my = 0; my < g->mh; ++my)
         for (int mx = 0; mx < g->mw; ++mx, ++m) {
-            const int t = (int)gby_next(&types);
+            if ((m & 3u) == 0) w4 = gl_next(&types);
+            const int t = (int)((w4 >> (8u * (m & 3u))) & 0xFFu);
             if (t == 0) continue;
             const int r = t - 1;
             if (r != cur_ref) { cur_ref = r; acc = 0; }
