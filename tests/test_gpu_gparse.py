@@ -202,3 +202,39 @@ def test_pathological_trees_cannot_stall_the_gpu_parser(gpu_ctx):
             pass
         gpu_ctx.close_stream(sid)
     assert time.time() - t0 < 20.0
+
+
+def test_reading_a_picture_of_the_batch_in_flight_ends_it(gpu_ctx):
+    from hvqm4_amd.container import parse_header, video_pictures
+    from oracle import bridge
+    cl = clips.get(clips.SMALL[3])
+    hdr = parse_header(cl.data)
+    pics = list(video_pictures(cl.data))
+    sid = gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, len(pics) + 3)
+    gpu_ctx.submit_many_device([sid] * len(pics), [p[0] for p in pics], [bytes(p[2]) for p in pics])
+    gpu_ctx.flush_begin()                                  # no flush_end: read_picture has to finish the batch itself
+    want = bridge.oracle_decode(cl.data, cl.n_pictures)
+    for k in range(cl.n_pictures):
+        assert np.array_equal(gpu_ctx.read_picture(sid, k), want[k])
+    gpu_ctx.close_stream(sid)
+
+
+def test_a_rejected_picture_fails_the_flush_and_leaves_the_context_usable(gpu_ctx):
+    """a prefix tree that nests deeper than 255 levels is rejected by the device parser (GP_ST_BADTREE): hvq_flush_end
+    reports it, and the next batch decodes normally"""
+    import struct
+    from hvqm4_amd._lib import HvqError
+    from hvqm4_amd.container import parse_header, video_pictures
+    cl = clips.get(clips.SMALL[3])
+    hdr = parse_header(cl.data)
+    ft, _d, pic = next(iter(video_pictures(cl.data)))
+    bad = bytearray(pic)
+    off = 8 + 0x40 + struct.unpack_from(">I", bad, 8)[0] + 4          # section 0 carries the block-kind tree
+    bad[off:off + 64] = b"\xff" * 64                                   # 512 inner nodes in a row
+    sid = gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, 4)
+    gpu_ctx.submit_many_device([sid], [ft], [bytes(bad)])
+    gpu_ctx.flush_begin()
+    with pytest.raises(HvqError):
+        gpu_ctx.flush_end()
+    gpu_ctx.close_stream(sid)
+    test_nest_of_the_last_I_picture_survives_flushes(gpu_ctx, 2)
