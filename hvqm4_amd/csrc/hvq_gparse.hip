@@ -11,8 +11,8 @@
  *   P/B picture  : 2 chains (macroblock types; proc runs) | inter ranks, tags, lists of coded / intra macroblocks (all, 5
  *                  steps) | 5 chains (kinds Y, kinds UV, DC Y, DC U, DC V: symbols only) | kinds and DC values placed in
  *                  the maps (all) | run sums (all) | run scan, header (thread 0) |
- *                  payload entries, fixed-length offsets, compaction (all) | 4 waves: coefficient symbols Y; U, V; MV x, y;
- *                  DC-buffer scalars of the MC-residual blocks Y, U, V | basis words merged in, literal blocks copied (all)
+ *                  payload entries, fixed-length offsets, compaction (all) | 4 waves: coefficient symbols Y; U, V + DC-buffer
+ *                  scalars of the MC-residual blocks Y; MV x + scalars U, V; MV y | basis words merged in, literal blocks copied (all)
  * A chain runs wave-uniform (all lanes compute the same values, so its cursors and counters live in scalar registers
  * and its logic runs on the scalar unit); the four waves of a workgroup run different
  * chains at the same time and 8 workgroups share a CU, so the serial bit-level work of thousands of pictures overlaps.
@@ -127,12 +127,17 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         gp_emit_compact(&g, tid, GPW);
         __syncthreads();
         GP_STAMP(5);
+        /* balanced by measured chain lengths: Y coefficients | U, V coefficients + Y scalars | MV x + U, V scalars | MV y */
         if (wave == 0) gp_payload(&g, codes, 0);
-        else if (wave == 1) { gp_payload(&g, codes, 1); gp_payload(&g, codes, 2); }
+        else if (wave == 1) { gp_payload(&g, codes, 1); gp_payload(&g, codes, 2); gp_predi_params(&g, codes, 0); }
         else if (wave == 2) {
-            const uint32_t fx = gp_mvs(&g, codes, 0), fy = gp_mvs(&g, codes, 1);
-            GP_ST(g.part[GP_MISC + 13], fx | fy);
-        } else { gp_predi_params(&g, codes, 0); gp_predi_params(&g, codes, 1); gp_predi_params(&g, codes, 2); }
+            const uint32_t fx = gp_mvs(&g, codes, 0);
+            GP_ST(g.part[GP_MISC + 13], fx);
+            gp_predi_params(&g, codes, 1); gp_predi_params(&g, codes, 2);
+        } else {
+            const uint32_t fy = gp_mvs(&g, codes, 1);
+            GP_ST(g.part[GP_MISC + 14], fy);
+        }
     }
     __syncthreads();
     GP_STAMP(6);

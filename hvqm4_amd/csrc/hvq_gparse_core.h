@@ -95,7 +95,7 @@ typedef struct HvqParseResult {   /* what the host needs back to size and order 
  * instead of one per 4.  (Keeping look-ahead dwords in registers does not work: the compiler's register copies of a
  * freshly requested dword make it wait for the load on the spot.) */
 #define GP_BLK 32
-#define GP_SLOTS 18           /* 14 bitstream cursors + 4 list readers (GList) */
+#define GP_SLOTS 19           /* 14 bitstream cursors + 5 list readers (GList) */
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 __shared__ uint32_t gp_stage[GP_SLOTS * GP_BLK];
@@ -838,7 +838,7 @@ GP_FN void gp_predi_params(GPic *g, const GCode *codes, int i)
     GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
     const uint32_t n = g->nchain[i];
     GList ents;
-    gl_init(&ents, g->clist + g->pl[i].blk_first, n, 16u);
+    gl_init(&ents, g->clist + g->pl[i].blk_first, n, i == 0 ? 16u : 17u);   /* Y on one wave, U and V on another */
     for (uint32_t e = 0; e < n; ++e) {
         const uint32_t ent = gl_next(&ents);
         if ((ent >> 30) != GP_MODE_PREDI) continue;
@@ -1127,7 +1127,7 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp)
     int32_t acc = 0;
     uint32_t fl = 0, m = 0, w4 = 0;
     GList types;                                                         /* the type bytes, four per entry */
-    gl_init(&types, (const GP_G uint32_t *)g->mbtype, ((uint32_t)g->mw * (uint32_t)g->mh + 3u) / 4u, 17u);
+    gl_init(&types, (const GP_G uint32_t *)g->mbtype, ((uint32_t)g->mw * (uint32_t)g->mh + 3u) / 4u, comp ? 18u : 17u);
     for (int my = 0; my < g->mh; ++my)
         for (int mx = 0; mx < g->mw; ++mx, ++m) {
             if ((m & 3u) == 0) w4 = gl_next(&types);
