@@ -700,11 +700,16 @@ static int device_parse_finish(HvqContext *c)
             for (int ph = 1; ph <= 7; ++ph) { if (!t[ph]) continue; sum[kind][ph - 1] += (double)(t[ph] - prev) * 0.01; prev = t[ph]; }
             cnt[kind]++; t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[7]);
         }
-        uint64_t s_max = 0, d_min = ~0ull, d_max = 0;
+        uint64_t s_max = 0, d_min = ~0ull, d_max = 0, k_max[3] = { 0, 0, 0 }, k_end[3] = { 0, 0, 0 };
         for (size_t k = 0; k < idx.size(); ++k) {
             const uint64_t *t = &tm[16 * k];
+            const int kind = (int)c->fl_pending[idx[k]].kind;
             s_max = std::max(s_max, t[0]); d_min = std::min(d_min, t[7] - t[0]); d_max = std::max(d_max, t[7] - t[0]);
+            k_max[kind] = std::max(k_max[kind], t[7] - t[0]); k_end[kind] = std::max(k_end[kind], t[7] - t_min);
         }
+        fprintf(stderr, "hvqm4_amd parse: slowest picture / last end per kind: I %.3f / %.3f  P %.3f / %.3f  B %.3f / %.3f ms\n",
+                (double)k_max[0] * 1e-5, (double)k_end[0] * 1e-5, (double)k_max[1] * 1e-5, (double)k_end[1] * 1e-5,
+                (double)k_max[2] * 1e-5, (double)k_end[2] * 1e-5);
         fprintf(stderr, "hvqm4_amd parse occupancy: %d workgroups per CU (runtime query)\n", hvq_parse_occupancy(256));
         fprintf(stderr, "hvqm4_amd parse timing: %zu pictures, kernel %.3f ms, first start -> last end %.3f ms, last start +%.3f ms, "
                 "per picture %.3f .. %.3f ms\n",
