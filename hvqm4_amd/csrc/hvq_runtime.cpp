@@ -778,7 +778,8 @@ static int build_tiles(HvqContext *c)
     /* Two queues: clips are independent, so the dependency levels of the even and of the odd streams form two
      * chains that run on two HIP streams -- while one chain drains a level the other keeps the CUs busy. */
     const char *qenv = getenv("HVQM4_AMD_QUEUES");
-    /* measured +1.5 % on the bench workload; off by default so that per-kernel profiler durations stay comparable */
+    /* measured +2.1 % on the bench workload (profiles/r01m_ab_two_queues.txt); off by default: with overlapping
+     * launches the per-kernel durations a profiler reports no longer add up to the elapsed time the roofline uses */
     const int nq = (qenv && atoi(qenv) >= 2) ? 2 : 1;
     for (int lvl = 0; lvl <= max_level; ++lvl)
       for (int qi = 0; qi < nq; ++qi) {
