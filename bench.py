@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--preset", default="dense", choices=["dense", "realistic", "flat", "natural"])
     ap.add_argument("--nslots", type=int, default=6)
     ap.add_argument("--no-gpu-parse", action="store_true", help="skip the GPU-entropy-parse end-to-end leg")
+    ap.add_argument("--no-sdk", action="store_true", help="skip the SDK-boundary (PCIe-inclusive) leg")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--parse-threads", type=int, default=0, help="host parse threads for the end-to-end pass (0 = all cores, max 64)")
@@ -244,7 +245,7 @@ def main():
 
     # the SDK boundary itself (PCIe-inclusive, never `value`): one stream, one synchronous call per picture -- upload
     # of the caller's reference pictures, host parse, launch, download of the decoded picture
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_sdk:
         try:
             from hvqm4_amd import sdk
             pl = sdk.Player(args.width, args.height, 2, 2, True)
