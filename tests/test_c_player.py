@@ -14,12 +14,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "native", "_build", "h4m_player")
 
 
+BIN_BATCH = os.path.join(ROOT, "tests", "native", "_build", "h4m_batch")
+
+
 def build():
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     lib = os.path.join(ROOT, "hvqm4_amd")
-    subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "h4m_player.c"), "-L" + lib, "-lhvqm4_amd",
-                    "-Wl,-rpath," + lib, "-o", BIN], check=True)
+    for src, out in (("h4m_player.c", BIN), ("h4m_batch.c", BIN_BATCH)):
+        subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", src), "-L" + lib, "-lhvqm4_amd",
+                        "-Wl,-rpath," + lib, "-o", out], check=True)
 
 
 def fnv1a(b: bytes) -> int:
@@ -65,3 +69,23 @@ def test_c_player_decodes_the_golden_clips_like_the_reference(tmp_path):
             assert hashlib.sha256(got[k].tobytes()).hexdigest() == ent["picture_sha256"][k], (name, k)   # the REFERENCE's output
         done += 1
     assert done >= 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parser", ["gpu", "host"])
+def test_c_batch_example_streams_the_golden_clip(parser):
+    """examples/h4m_batch.c: N streams of one clip through the batched C API (GPU or host entropy parse), streamed with
+    hvq_flush_begin / hvq_flush_end; every stream's last picture must be the oracle's"""
+    from oracle import bridge
+    build()
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
+    ent = man["clips"]["gop64x48_15"]
+    path = os.path.join(ROOT, "tests", "golden", ent["file"])
+    r = subprocess.run([BIN_BATCH, path, "5", parser], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    data = open(path, "rb").read()
+    want = bridge.oracle_decode(data, len(ent["frame_types"]))
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 5
+    for l in lines:
+        assert int(l.split()[-1], 16) == fnv1a(want[-1].tobytes())
