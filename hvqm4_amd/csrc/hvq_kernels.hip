@@ -638,8 +638,9 @@ __device__ __forceinline__ void rgb4(u32 y4, u32 u2, u32 v2, u32 out[3])
     }
 }
 
-/* WIDE: one lane = 16 samples of a row (16-byte Y load, 8-byte U/V loads, three 16-byte stores; a wave writes
- * 3 KB contiguous).  Needs width % 16 == 0; otherwise 4 samples per lane. */
+/* WIDE: one lane = 16 samples of TWO rows that share their chroma (two 16-byte Y loads, one 8-byte U and V load, six
+ * 16-byte stores; the chroma products are computed once for the 2x2 samples they serve).  Needs width % 16 == 0 and an
+ * even height (4:2:0 has both); otherwise 4 samples of one row per lane. */
 template <bool WIDE>
 __global__ __launch_bounds__(256)
 void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
@@ -651,23 +652,29 @@ void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
     constexpr int S = WIDE ? 16 : 4;
     const int qw = w / S;                                    /* lanes per row */
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= qw * h) return;
-    const int y = idx / qw, xq = idx - y * qw;
+    if (idx >= qw * (WIDE ? h / 2 : h)) return;
+    const int yr = idx / qw, xq = idx - yr * qw;
+    const int y = WIDE ? 2 * yr : yr;
     const uint8_t *yp = yuv + (size_t)y * w + S * xq;
     const uint8_t *up = yuv + (size_t)w * h + (size_t)(y >> 1) * (w >> 1) + (S / 2) * xq;
     const uint8_t *vp = up + (size_t)(w >> 1) * (h >> 1);
     u32 *dst = (u32 *)(rgb + ((size_t)y * w + S * xq) * 3);
     if (WIDE) {
-        const uint4 y16 = *(const uint4 *)yp;
+        const uint4 ya = *(const uint4 *)yp, yb = *(const uint4 *)(yp + w);
         const uint2 u8 = *(const uint2 *)up, v8 = *(const uint2 *)vp;
-        const u32 ys[4] = { y16.x, y16.y, y16.z, y16.w };
         const u32 us[4] = { u8.x & 0xFFFFu, u8.x >> 16, u8.y & 0xFFFFu, u8.y >> 16 };
         const u32 vs[4] = { v8.x & 0xFFFFu, v8.x >> 16, v8.y & 0xFFFFu, v8.y >> 16 };
-        u32 o[12];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rgb4(ys[q], us[q], vs[q], o + 3 * q);
+        for (int row = 0; row < 2; ++row) {
+            const uint4 y16 = row ? yb : ya;
+            const u32 ys[4] = { y16.x, y16.y, y16.z, y16.w };
+            u32 o[12];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) ((uint4 *)dst)[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            for (int q = 0; q < 4; ++q) rgb4(ys[q], us[q], vs[q], o + 3 * q);     /* the chroma terms are common subexpressions of the two rows */
+            u32 *d = dst + row * (3 * w / 4);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ((uint4 *)d)[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        }
     } else {
         u32 o[3];
         rgb4(*(const u32 *)yp, *(const uint16_t *)up, *(const uint16_t *)vp, o);
@@ -681,7 +688,7 @@ extern "C" hipError_t hvq_launch_rgb(const void *jobs_dev, int njobs, int max_la
 {
     if (njobs <= 0) return hipSuccess;
     if (wide)
-        hipLaunchKernelGGL(hvq_yuv420_rgb_kernel<true>, dim3((max_lanes / 4 + 255) / 256, njobs), dim3(256), 0, stream,
+        hipLaunchKernelGGL(hvq_yuv420_rgb_kernel<true>, dim3((max_lanes / 8 + 255) / 256, njobs), dim3(256), 0, stream,
                            (const HvqRgbJob *)jobs_dev);
     else
         hipLaunchKernelGGL(hvq_yuv420_rgb_kernel<false>, dim3((max_lanes + 255) / 256, njobs), dim3(256), 0, stream,
