@@ -17,8 +17,9 @@
  * and its logic runs on the scalar unit); the four waves of a workgroup run different
  * chains at the same time and 8 workgroups share a CU, so the serial bit-level work of thousands of pictures overlaps.
  *
- * LDS per workgroup: the picture state (cursors, geometry), six prefix trees with 9-bit tables (2.5 KB each) and
- * the DC chains' row buffers: ~17 KB.
+ * LDS per workgroup: the picture state (cursors, geometry), six prefix trees (8-bit table whose entries hold the leaf
+ * value, child and leaf tables: 2.5 KB each), 19 staging slots of 128 B (bitstream blocks and work lists) and the DC
+ * chains' row buffers: 19.4 KB, 8 workgroups per CU.  At most 80 SGPRs: more costs a wave slot per SIMD on gfx950.
  */
 #include <hip/hip_runtime.h>
 
