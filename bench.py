@@ -2,23 +2,34 @@
 """bench.py -- HVQM4 picture-reconstruction throughput on MI355X.
 
 Metric (BASELINE.json): decoded Mpixels/s (bit-exact YUV) and % of the HBM roofline.
-Workload at every N (weak scaling, one rank per GPU, no collective on the data path): the per-GPU
-share of SURVEY.md's config C5 -- 128 concurrent 640x480 HVQM4 1.5 streams, GOP I P B B P B B ...
-(16 pictures), descriptors pre-parsed and resident in HBM.  One "step" = every stream decodes one
-full GOP (128 * 16 = 2048 pictures) through the batched path (hvq_replay): the launches of the
-dependency levels, nothing skipped.  `value` = luma pixels decoded by all ranks / max-over-ranks time.
+
+Workloads, weak scaling, one rank per GPU, no collective on the data path:
+  c5 (default)  the per-GPU share of config C5: 128 concurrent 640x480 HVQM4 1.5 streams, GOP I P B B P B B ...
+                (16 pictures), descriptors pre-parsed and resident in HBM.  One step = every stream decodes one GOP
+                (128 * 16 = 2048 pictures) through the batched path (hvq_replay): the launches of the dependency
+                levels, nothing skipped.
+  c4            config C4: 64 clips = 32 x 320x240 + 32 x 640x480, HVQM4 1.3 and 1.5 alternating, seeds 0..63,
+                four 16-picture GOPs each, clip i -> rank i mod N.  One step = every clip of the rank decoded once.
+`value` = luma pixels decoded by all ranks / max-over-ranks time.
+
+`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself, before
+anything touches a GPU, and forwards rank 0's line; under torchrun it runs as one of the ranks.
 
 Extra objects on the JSON line:
-  roofline      algorithmic bytes (1.5 B/px written + 1.5 B/px read for P/B)
-                per launch / average launch duration from HIP events on the launch stream, vs 8 TB/s
-  cpu_baseline  the reference decoder (oracle/_ref, kind "reference") or this repo's scalar
-                restatement (kind "port") timed on one host core over a bounded sample
+  roofline      algorithmic bytes (1.5 B/px written + 1.5 B/px read for P/B) per launch /
+                average launch duration from HIP events on the launch stream, vs 8 TB/s; `traffic` = HBM bytes per
+                launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json), calibrated as
+                MI355X_MICROARCH.md prescribes
+  cpu_baseline  the reference decoder (oracle/_ref, kind "reference") or this repo's scalar restatement (kind "port")
+                on the host cores: one core on C1, C2, C3 and one process per clip over all cores on a C4 sample
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,64 +38,178 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+GOP16 = "IPBBPBBPBBPBBPBB"
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=128, help="concurrent streams per GPU")
+    ap.add_argument("--workload", default="c5", choices=["c5", "c4"])
+    ap.add_argument("--streams", type=int, default=128, help="c5: concurrent streams per GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--gop", default="IPBBPBBPBBPBBPBB")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic clips per GPU (replicated over the streams)")
+    ap.add_argument("--gop", default=GOP16)
+    ap.add_argument("--distinct", type=int, default=8, help="c5: distinct synthetic clips per GPU (replicated over the streams)")
     ap.add_argument("--preset", default="dense", choices=["dense", "realistic", "flat", "natural"])
     ap.add_argument("--nslots", type=int, default=6)
     ap.add_argument("--no-gpu-parse", action="store_true", help="skip the GPU-entropy-parse end-to-end leg")
     ap.add_argument("--no-sdk", action="store_true", help="skip the SDK-boundary (PCIe-inclusive) leg")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget in seconds (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--parse-threads", type=int, default=0, help="host parse threads for the end-to-end pass (0 = all cores, max 64)")
     ap.add_argument("--mv-bits", default="0,1,2", help="vector residual-bit choices of the synthetic P/B pictures (reach = 16 << bits samples)")
-    args = ap.parse_args()
+    ap.add_argument("--gen-workers", type=int, default=0, help="processes that generate the synthetic clips (0 = cores / ranks)")
+    return ap.parse_args(argv)
 
-    from hvqm4_amd.distrib import Group
+
+# ---------------------------------------------------------------------------------------------- rank launcher
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int, argv, child=None) -> int:
+    """Parent of a self-started multi-rank run.  Imports neither torch nor the HIP library and makes no GPU call: it
+    starts one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, waits, forwards rank 0's stdout (the
+    JSON line) and returns non-zero when any child failed (the others are then terminated)."""
+    import tempfile
+    port = free_port()
+    cmd = child or [sys.executable, os.path.abspath(__file__)]
+    out0 = tempfile.TemporaryFile()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if os.environ.get("HVQM4_BENCH_SHARE_GPU"):
+            env.setdefault("HVQM4_DIST_BACKEND", "gloo")     # RCCL refuses two ranks on one device
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=out0 if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        while rc == 0 and any(p.poll() is None for p in procs):
+            time.sleep(0.1)
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    rc = p.returncode
+                    print(f"bench.py: rank {r} exited with code {rc}", file=sys.stderr)
+                    break
+        for r, p in enumerate(procs):
+            if rc == 0 and p.poll() not in (None, 0):
+                rc = p.returncode
+                print(f"bench.py: rank {r} exited with code {rc}", file=sys.stderr)
+    finally:
+        for p in procs:                               # a failed rank leaves the others at a barrier: end exactly those
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if rc == 0:
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode(errors="replace"))
+        sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------- workloads
+def c4_clip_config(i: int, preset: str = "dense", gops: int = 4, mv_bits=(0, 1, 2)):
+    """Clip i of config C4 (seed i).  Sizes alternate per group of 8 and versions per clip and group of 16, so that every
+    rank of an i mod N sharding (N = 1, 2, 4, 8) decodes the same mix of both sizes and both versions."""
+    from hvqm4_amd.synth import SynthConfig
+    small = (i // 8) % 2 == 0
+    v13 = ((i // 16) + i) % 2 == 0
+    return SynthConfig(width=320 if small else 640, height=240 if small else 480, version="1.3" if v13 else "1.5",
+                       gop=GOP16, n_gops=1, repeat_gops=gops, seed=i, preset=preset, mv_res_bits=tuple(mv_bits))
+
+
+def _make(cfg):
+    from hvqm4_amd.synth import make_clip
+    return make_clip(cfg)
+
+
+def gen_clips(cfgs, workers: int):
+    """synthetic clips, generated by a process pool (pure Python + numpy; no GPU or HIP call happens in the children)"""
+    if workers <= 1 or len(cfgs) <= 1:
+        return [_make(c) for c in cfgs]
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(workers, len(cfgs))) as pool:
+        return pool.map(_make, cfgs, chunksize=1)
+
+
+def host_cores() -> int:
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+# ---------------------------------------------------------------------------------------------- one rank
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    from hvqm4_amd.distrib import Group, shard
     grp = Group()                       # torch.distributed (nccl = RCCL) only when WORLD_SIZE > 1
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
-    if world != args.gpus and world > 1:
-        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+    if world != args.gpus:
+        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; running {world} rank(s)", file=sys.stderr)
 
     import numpy as np
     from hvqm4_amd import batch
+    from hvqm4_amd._lib import HVQ_E_STATE, HvqError
     from hvqm4_amd.container import video_pictures
-    from hvqm4_amd.synth import SynthConfig, make_clip
+    from hvqm4_amd.synth import SynthConfig
 
-    # ---- synthetic inputs (fixed seeds; clip i of rank r has seed 1000 + r*distinct + i) ----
+    mv_bits = tuple(int(x) for x in args.mv_bits.split(","))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    workers = args.gen_workers or max(1, host_cores() // max(1, local_world))
+
+    # ---- synthetic inputs (fixed seeds) ----
     t0 = time.time()
-    clips = [make_clip(SynthConfig(width=args.width, height=args.height, version="1.5", gop=args.gop,
-                                   seed=1000 + rank * args.distinct + i, preset=args.preset,
-                                   mv_res_bits=tuple(int(x) for x in args.mv_bits.split(","))))
-             for i in range(args.distinct)]
+    if args.workload == "c5":
+        # clip i of rank r has seed 1000 + r*distinct + i; stream s replays clip s mod distinct
+        cfgs = [SynthConfig(width=args.width, height=args.height, version="1.5", gop=args.gop,
+                            seed=1000 + rank * args.distinct + i, preset=args.preset, mv_res_bits=mv_bits)
+                for i in range(args.distinct)]
+        stream_clip = [s % args.distinct for s in range(args.streams)]
+        what = (f"C5 share: {args.streams} concurrent {args.width}x{args.height} HVQM4 1.5 streams per GPU, GOP {args.gop}, "
+                f"{args.preset} synthetic streams, descriptors resident in HBM")
+    else:
+        mine = shard(64, rank, world)
+        cfgs = [c4_clip_config(i, args.preset, 4, mv_bits) for i in mine]
+        stream_clip = list(range(len(cfgs)))
+        what = (f"C4: 64 clips (32 x 320x240 + 32 x 640x480, HVQM4 1.3/1.5 alternating, seeds 0..63, 4 x 16-picture GOPs), "
+                f"clip i -> rank i mod {world}, {args.preset} synthetic streams, descriptors resident in HBM")
+    clips = gen_clips(cfgs, workers)
     gen_s = time.time() - t0
     pics = [list(video_pictures(c.data)) for c in clips]
-    n_pic = len(args.gop)
+
+    # CPU baseline first: the host is otherwise idle, and its worker processes start before this process touches the GPU
+    cpu_base = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        c3 = clips[0] if (args.workload == "c5" and (args.width, args.height, args.gop) == (640, 480, GOP16)) else None
+        cpu_base = cpu_baseline(args.cpu_seconds, c3, args.preset)
 
     # one rank per GPU; HVQM4_BENCH_SHARE_GPU=1 lets several ranks share device 0 (rehearsal on a 1-GPU box only)
-    ctx = batch.Context(0 if os.environ.get("HVQM4_BENCH_SHARE_GPU") else local_rank)
-    sids = []
-    for s in range(args.streams):
-        sids.append(ctx.open_stream(args.width, args.height, 2, 2, True, args.nslots))
+    device = 0 if os.environ.get("HVQM4_BENCH_SHARE_GPU") else local_rank
+    ctx = batch.Context(device)
+    sids = [ctx.open_stream(clips[ci].width, clips[ci].height, 2, 2, clips[ci].version == "1.5", args.nslots)
+            for ci in stream_clip]
     # decode-order interleave: picture k of every stream, then k+1 ... (the order a player would submit).
-    # This first pass is also the END-TO-END measurement: host entropy parse (thread pool) + descriptor upload
-    # + all launches, from bitstreams in host memory to pictures in HBM.
-    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(args.parse_threads or allowed, 64))
-    a_sid, a_ft, a_pic = [], [], []
-    for k in range(n_pic):
+    # This first pass is also the END-TO-END measurement with the host parser: entropy parse (thread pool) +
+    # descriptor upload + all launches, from bitstreams in host memory to pictures in HBM.
+    threads = max(1, min(args.parse_threads or host_cores(), 64))
+    a_sid, a_ft, a_pic, a_stream = [], [], [], []
+    for k in range(max(len(p) for p in pics)):
         for s, sid in enumerate(sids):
-            ft, _d, pic = pics[s % args.distinct][k]
-            a_sid.append(sid); a_ft.append(ft); a_pic.append(pic)
+            seq = pics[stream_clip[s]]
+            if k < len(seq):
+                ft, _d, pic = seq[k]
+                a_sid.append(sid); a_ft.append(ft); a_pic.append(pic); a_stream.append(s)
     ctx.sync()
     t0 = time.perf_counter()
     ctx.submit_many(a_sid, a_ft, a_pic, threads)
@@ -94,21 +219,29 @@ def main():
     t_e2e = time.perf_counter() - t0
     st = ctx.stats()
 
-    # ---- parity spot-check against the CPU oracle on what is still resident ----
-    verified = None
+    # ---- parity check against the CPU oracle on what is still resident ----
+    # every stream keeps its last min(nslots, pictures) pictures; the first `distinct` streams (c4: every 4th clip) are checked
+    verified = expected = None
     if not args.no_verify:
         from oracle import bridge
-        verified = 0
-        for i in range(min(args.distinct, args.streams)):
-            want = bridge.oracle_decode(clips[i].data, n_pic)
-            for k in range(n_pic):
+        verified = expected = 0
+        check = list(range(min(args.distinct, len(sids)))) if args.workload == "c5" else list(range(0, len(sids), 4))
+        for s in check:
+            clip, seq = clips[stream_clip[s]], pics[stream_clip[s]]
+            want = bridge.oracle_decode(clip.data, len(seq))
+            expected += min(args.nslots, len(seq))
+            for k in range(len(seq)):
                 try:
-                    got = ctx.read_picture(sids[i], k)
-                except Exception:
+                    got = ctx.read_picture(sids[s], k)
+                except HvqError as e:
+                    if e.code != HVQ_E_STATE:
+                        raise
                     continue        # slot already reused by a later picture
                 if not np.array_equal(got, want[k]):
-                    raise SystemExit(f"PARITY FAILURE: stream {i} picture {k} differs from the oracle")
+                    raise SystemExit(f"PARITY FAILURE: stream {s} picture {k} differs from the oracle")
                 verified += 1
+        if verified != expected:
+            raise SystemExit(f"PARITY CHECK INCOMPLETE: {verified} pictures compared, {expected} expected to be resident")
 
     def barrier():
         ctx.sync()
@@ -122,17 +255,20 @@ def main():
     barrier()
     wall = grp.max(time.perf_counter() - t0)
 
-    # ---- end to end with the entropy parse ON THE GPU: raw bitstreams in host memory ->
-    # H2D -> parse kernel -> reconstruction launches.  Second pass of a fresh context = steady state (buffers sized).
+    # ---- end to end with the entropy parse ON THE GPU, on EVERY rank at once: raw bitstreams in
+    # host memory -> H2D -> parse kernel -> reconstruction launches; host copy threads, pinned arenas and PCIe of all
+    # ranks contend as they would in production.  Second pass of a fresh context = steady state (buffers sized).
     gpu_e2e = None
-    if rank == 0 and world == 1 and not args.no_gpu_parse:
-        ctx2 = batch.Context(local_rank)
-        sids2 = [ctx2.open_stream(args.width, args.height, 2, 2, True, args.nslots) for _ in range(args.streams)]
-        a_sid2 = [sids2[sids.index(x)] for x in a_sid]
+    if not args.no_gpu_parse:
+        ctx2 = batch.Context(device)
+        sids2 = [ctx2.open_stream(clips[ci].width, clips[ci].height, 2, 2, clips[ci].version == "1.5", args.nslots)
+                 for ci in stream_clip]
+        a_sid2 = [sids2[s] for s in a_stream]
         a_raw = [bytes(p) for p in a_pic]
         t_pass, parse_ms = [], []
+        t_split = []
         for _ in range(3):
-            ctx2.sync()
+            barrier(); ctx2.sync()
             t0 = time.perf_counter()
             ctx2.submit_many_device(a_sid2, a_ft, a_raw)
             t1 = time.perf_counter()
@@ -146,7 +282,7 @@ def main():
         # batch n is parsed.  Steady-state period = time between the completions of consecutive hvq_flush_end calls,
         # after two warm-up batches (the second arena and its staging are allocated on first use).
         nwarm, nbatch = 2, 8
-        ctx2.sync()
+        barrier(); ctx2.sync()
         ctx2.submit_many_device(a_sid2, a_ft, a_raw)
         ctx2.flush_begin()
         t_calls = [0.0, 0.0, 0.0]
@@ -168,33 +304,50 @@ def main():
         t_pipe = (t_end[-1] - t_end[nwarm]) / (len(t_end) - 1 - nwarm)
         t_calls = [round(x / (nbatch - 1) * 1e3, 2) for x in t_calls]
         parse_ms_streaming = ctx2.stats().gpu_parse_ms
-        nbatch = nwarm + nbatch
-        n_done = 3 + nbatch
+        n_done = 3 + nwarm + nbatch
         ok = 0
-        for i in range(min(4, args.streams)):
-            for k in range(n_pic):
+        n_seq = [len(pics[stream_clip[s]]) for s in range(len(sids))]
+        for s in range(min(4, len(sids))):
+            for k in range(n_seq[s]):
                 try:
-                    a = ctx.read_picture(sids[i], k); b = ctx2.read_picture(sids2[i], k + (n_done - 1) * n_pic)
-                except Exception:
+                    a = ctx.read_picture(sids[s], k); b = ctx2.read_picture(sids2[s], k + (n_done - 1) * n_seq[s])
+                except HvqError as e:
+                    if e.code != HVQ_E_STATE:
+                        raise
                     continue
                 if not np.array_equal(a, b):
-                    raise SystemExit(f"PARITY FAILURE: GPU-parsed stream {i} picture {k} differs from the host-parsed one")
+                    raise SystemExit(f"PARITY FAILURE: GPU-parsed stream {s} picture {k} differs from the host-parsed one")
                 ok += 1
-        gpu_e2e = {"value": round(int(st.luma_pixels) / min(t_pass[1:]) / 1e6, 1), "unit": "Mpixels/s",
-                   "streaming_value": round(int(st.luma_pixels) / t_pipe / 1e6, 1), "streaming_ms_per_batch": round(t_pipe * 1e3, 2), "streaming_submit_end_begin_ms": t_calls, "streaming_parse_kernel_ms": round(parse_ms_streaming, 3),
-                   "parse_kernel_ms": round(min(parse_ms[1:]), 3), "pass_ms": [round(t * 1e3, 2) for t in t_pass], "submit_flush_sync_ms": t_split,
-                   "host_copy_threads": 4, "pictures_checked_against_host_parsed": ok,
+        if ok != sum(min(args.nslots, n_seq[s]) for s in range(min(4, len(sids)))):
+            raise SystemExit(f"PARITY CHECK INCOMPLETE on the GPU-parsed streams: {ok} pictures compared")
+        px = int(st.luma_pixels)
+        one = px / min(t_pass[1:]) / 1e6
+        stream_v = px / t_pipe / 1e6
+        gpu_e2e = {"value": round(grp.sum(one), 1), "unit": "Mpixels/s",
+                   "streaming_value": round(grp.sum(stream_v), 1),
+                   "streaming_value_min_rank": round(-grp.max(-stream_v), 1),
+                   "streaming_value_max_rank": round(grp.max(stream_v), 1),
+                   "ranks": world,
+                   "streaming_ms_per_batch": round(t_pipe * 1e3, 2), "streaming_submit_end_begin_ms": t_calls,
+                   "streaming_parse_kernel_ms": round(parse_ms_streaming, 3),
+                   "parse_kernel_ms": round(min(parse_ms[1:]), 3), "pass_ms": [round(t * 1e3, 2) for t in t_pass],
+                   "submit_flush_sync_ms": t_split,
+                   "host_copy_threads": int(os.environ.get("HVQM4_AMD_COPY_THREADS", "4")),
+                   "pictures_checked_against_host_parsed": ok,
                    "what": "raw bitstreams in host memory -> H2D -> entropy parse kernel (one workgroup per picture) -> "
-                           "reconstruction launches -> pictures in HBM; no host entropy parse.  value: one batch start to finish; "
-                           "streaming_value: steady-state period of hvq_flush_begin / submit next / hvq_flush_end (next batch "
-                           "copied and uploaded while this one is parsed), 8 batches after 2 warm-up batches"}
+                           "reconstruction launches -> pictures in HBM; no host entropy parse; all ranks at once (sum over ranks, "
+                           "per-rank min and max of the streaming rate; the per-rank detail fields are rank 0's).  value: one "
+                           "batch start to finish; streaming_value: steady-state period of hvq_flush_begin / submit next / "
+                           "hvq_flush_end (next batch copied and uploaded while this one is parsed), 8 batches after 2 warm-up batches"}
         ctx2.close()
 
     px_step = int(st.luma_pixels)
-    value = px_step * args.steps * world / wall / 1e6
+    total_px = grp.sum(float(px_step))
+    value = total_px * args.steps / wall / 1e6
     launches = int(st.launches)
     avg_launch_s = gpu_ms * 1e-3 / (args.steps * launches)
     achieved = st.algorithmic_bytes / launches / avg_launch_s / 1e9
+    traffic = pmc_traffic(args)
 
     out = {
         "metric": "decoded Mpixels/s (bit-exact YUV)",
@@ -205,20 +358,24 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(wall * 1e3 / args.steps, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if args.workload == "c5" else "strong",
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": f"C5 share: {args.streams} concurrent {args.width}x{args.height} HVQM4 1.5 streams per GPU, "
-                        f"GOP {args.gop}, {args.preset} synthetic streams, descriptors resident in HBM",
-            "streams_per_gpu": args.streams, "pictures_per_step": int(st.pictures),
-            "distinct_clips_per_gpu": args.distinct, "launches_per_step": launches,
-            "workgroups_per_step": int(st.workgroups), "nslots": args.nslots, "sharding": "one clip per stream, streams split across GPUs, no collective",
+            "workload": what,
+            "streams_per_gpu": len(sids), "pictures_per_step": int(st.pictures),
+            "distinct_clips_per_gpu": len(clips), "launches_per_step": launches,
+            "workgroups_per_step": int(st.workgroups), "nslots": args.nslots,
+            "sharding": "one clip per stream, streams split across GPUs, no collective",
+            "clip_generation_s": round(gen_s, 1),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args),
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+            "traffic_over_algorithmic": traffic["over_algorithmic"] if traffic else None,
+            "traffic_source": traffic["source"] if traffic else None,
             "kernel": "hvq_recon_kernel", "algorithmic_bytes_per_launch": int(st.algorithmic_bytes // launches),
             "avg_launch_us": round(avg_launch_s * 1e6, 2),
             "descriptor_bytes_per_launch": int(st.descriptor_bytes // launches),
@@ -227,8 +384,8 @@ def main():
         "end_to_end_gpu_parse": gpu_e2e,
         "end_to_end": {"value": round(px_step / t_e2e / 1e6, 1), "unit": "Mpixels/s", "parse_threads": threads,
                        "parse_only_mpix_s": round(px_step / t_parse / 1e6, 1),
-                       "what": "first pass: host entropy parse + descriptor H2D + kernels, bitstreams in host memory -> pictures in HBM"},
-        "verified_pictures": verified,
+                       "what": "rank 0, first pass: host entropy parse + descriptor H2D + kernels, bitstreams in host memory -> pictures in HBM"},
+        "verified_pictures": verified, "verified_pictures_expected": expected,
         "flags_or": int(st.flags_or),
     }
 
@@ -246,10 +403,26 @@ def main():
     # the SDK boundary itself (PCIe-inclusive, never `value`): one stream, one synchronous call per picture -- upload
     # of the caller's reference pictures, host parse, launch, download of the decoded picture
     if rank == 0 and world == 1 and not args.no_sdk:
-        try:
-            from hvqm4_amd import sdk
-            pl = sdk.Player(args.width, args.height, 2, 2, True)
-            seq = pics[0]
+        out["sdk_path"] = sdk_leg(clips[0], pics[0])
+
+    if cpu_base is not None:
+        out["cpu_baseline"] = cpu_base
+    if rank == 0:
+        grp.emit(json.dumps(out))
+    ctx.close()
+    grp.close()
+
+
+def sdk_leg(clip, seq):
+    try:
+        from hvqm4_amd import sdk
+        res = {}
+        for name, env in (("default", None), ("trusted_pictures", "1")):
+            if env is None:
+                os.environ.pop("HVQM4_AMD_TRUST_PICTURES", None)
+            else:
+                os.environ["HVQM4_AMD_TRUST_PICTURES"] = env
+            pl = sdk.Player(clip.width, clip.height, 2, 2, clip.version == "1.5")
             for ft, _d, pic in seq:                                  # warm-up pass
                 pl.decode(ft, bytes(pic))
             t0 = time.perf_counter()
@@ -259,49 +432,91 @@ def main():
                     pl.decode(ft, bytes(pic))
             dt = (time.perf_counter() - t0) / (reps * len(seq))
             pl.close()
-            out["sdk_path"] = {"value": round(args.width * args.height / dt / 1e6, 1), "unit": "Mpixels/s",
-                               "ms_per_picture": round(dt * 1e3, 3),
-                               "what": "HVQM4DecodeIpic/Ppic/Bpic through the C ABI with host picture buffers, one "
-                                       "synchronous picture at a time (PCIe both ways inside the call)"}
-        except Exception as e:
-            out["sdk_path"] = {"error": str(e)}
-
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(clips[0], args.cpu_seconds)
-    if rank == 0:
-        grp.emit(json.dumps(out))
-    ctx.close()
-    grp.close()
+            res[name] = {"value": round(clip.width * clip.height / dt / 1e6, 1), "ms_per_picture": round(dt * 1e3, 3)}
+        os.environ.pop("HVQM4_AMD_TRUST_PICTURES", None)
+        return {"value": res["default"]["value"], "unit": "Mpixels/s", "ms_per_picture": res["default"]["ms_per_picture"],
+                "trusted_pictures": res["trusted_pictures"],
+                "what": "HVQM4DecodeIpic/Ppic/Bpic through the C ABI with host picture buffers, one synchronous picture at a "
+                        "time (PCIe both ways inside the call); trusted_pictures: HVQM4_AMD_TRUST_PICTURES=1 skips the upload "
+                        "of `past`/`future` when they are the buffers this library last wrote for the same SeqObj"}
+    except Exception as e:
+        return {"error": str(e)}
 
 
 def pmc_traffic(args):
-    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes of this same
-    default workload (tools/pmc_passes.sh -> tools/pmc_traffic.py -> profiles/*_pmc_traffic.json); None for
-    any other workload."""
-    default = (args.streams, args.width, args.height, args.gop, args.preset, args.distinct, args.mv_bits) == \
-              (128, 640, 480, "IPBBPBBPBBPBBPBB", "dense", 8, "0,1,2")
+    """HBM bytes per launch of hvq_recon_kernel from the committed rocprofv3 --pmc passes of this same default workload
+    (tools/pmc_passes.sh -> tools/pmc_traffic.py -> profiles/*_pmc_traffic.json, read side calibrated by
+    tools/ubench/pmc_calib.hip as MI355X_MICROARCH.md prescribes); None for any other workload.  PMC counters cannot be
+    collected from inside the timed process, so this is evidence from a separate run of the same command."""
+    default = (args.workload, args.streams, args.width, args.height, args.gop, args.preset, args.distinct, args.mv_bits) == \
+              ("c5", 128, 640, 480, GOP16, "dense", 8, "0,1,2")
     if not default:
         return None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None
-    return int(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+    j = json.load(open(files[-1]))
+    hbm = j.get("hbm_bytes_per_launch_calibrated", j.get("hbm_bytes_per_launch"))
+    return {"hbm_bytes_per_launch": int(hbm), "over_algorithmic": j.get("over_algorithmic"),
+            "source": "profiles/" + os.path.basename(files[-1]) + (" (calibrated)" if "hbm_bytes_per_launch_calibrated" in j else " (raw counters)")}
 
 
-def cpu_baseline(clip, budget_s: float):
-    """One host core, decode calls only, same clip as stream 0 of the GPU run."""
+def _time_clip_worker(job):
+    data, reps = job
     from oracle import bridge
-    if bridge.have_ref():
-        kind, timer = "reference", bridge.ref_time
-    else:
-        kind, timer = "port", bridge.oracle_time
-    t, px = timer(clip.data, 1)
-    reps = max(1, int(budget_s / max(t, 1e-6)))
-    t, px = timer(clip.data, reps)
-    return {"value": round(px / t / 1e6, 1), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-            "sample": f"{reps} passes over one {clip.width}x{clip.height} {len(clip.kinds)}-picture clip "
-                      f"(decode calls only, {t:.1f} s)"}
+    timer = bridge.ref_time if bridge.have_ref() else bridge.oracle_time
+    return timer(data, reps)
+
+
+def cpu_baseline(budget_s: float, c3_clip, preset: str):
+    """The reference decoder on the host cores (decode calls only): one core on C1 (one 320x240 1.3 I picture),
+    C2 (320x240 1.5, I pictures only) and C3 (640x480 1.5, I P B B ...), plus one process per clip over all cores on a
+    sample of the C4 clip set.  `value` is the C3 figure (the configuration `metric` is quoted on)."""
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    from oracle import bridge
+    have_ref = bridge.have_ref()
+    kind, timer = ("reference", bridge.ref_time) if have_ref else ("port", bridge.oracle_time)
+    per = max(0.5, budget_s / 5.0)
+
+    def one_core(clip):
+        t, px = timer(clip.data, 1)
+        reps = max(1, int(per / max(t, 1e-6)))
+        t, px = timer(clip.data, reps)
+        return {"value": round(px / t / 1e6, 1), "unit": "Mpixels/s", "cores": 1,
+                "sample": f"{reps} passes over one {clip.width}x{clip.height} HVQM4 {clip.version} clip of {len(clip.kinds)} "
+                          f"picture(s) (decode calls only, {t:.1f} s)"}
+
+    c1 = make_clip(SynthConfig(width=320, height=240, version="1.3", gop="I", seed=1, preset=preset))
+    c2 = make_clip(SynthConfig(width=320, height=240, version="1.5", gop="I", n_gops=16, seed=2, preset=preset))
+    c3 = c3_clip or make_clip(SynthConfig(width=640, height=480, version="1.5", gop=GOP16, seed=1000, preset=preset))
+    res = {"C1": one_core(c1), "C2": one_core(c2), "C3": one_core(c3)}
+    # all cores: C4 clips 0..15 (8 x 320x240 + 8 x 640x480, both versions), one GOP each, one process per clip
+    cores = host_cores()
+    cfgs = [c4_clip_config(i, preset, 1) for i in range(16)]
+    sample = gen_clips(cfgs, cores)
+    t1, _ = timer(sample[-1].data, 1)
+    reps = max(1, int(2.0 * per / max(t1 * max(1.0, 16.0 / cores), 1e-6)))
+    import multiprocessing as mp
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(min(cores, 16)) as pool:
+        t_start = time.perf_counter()
+        r = pool.map(_time_clip_worker, [(c.data, reps) for c in sample], chunksize=1)
+        t_all = time.perf_counter() - t_start
+    px_all = sum(px for _t, px in r)
+    res["all_cores_C4"] = {"value": round(px_all / t_all / 1e6, 1), "unit": "Mpixels/s", "cores": min(cores, 16), "nproc": cores,
+                           "sample": f"C4 clips 0..15 (8 x 320x240 + 8 x 640x480, HVQM4 1.3/1.5 alternating, one 16-picture GOP each), "
+                                     f"{reps} passes per clip, one process per clip over {min(cores, 16)} processes "
+                                     f"(wall time of the pool map {t_all:.1f} s, process start-up {t_start - t0:.1f} s excluded)"}
+    info = {}
+    try:
+        info = json.load(open(os.path.join(ROOT, "oracle", "_ref" if have_ref else ".", "build_info.json")))
+    except Exception:
+        pass
+    fast = bridge.ref_fast_flags() if have_ref else None
+    return {"value": res["C3"]["value"], "unit": "Mpixels/s", "cores": 1, "kind": kind, "sample": "C3: " + res["C3"]["sample"],
+            "configs": res, "compiler": info.get("compiler"), "flags": info.get("flags_v3" if fast else "flags"),
+            "note": info.get("note", "CPU restatement built by oracle/Makefile")}
 
 
 if __name__ == "__main__":

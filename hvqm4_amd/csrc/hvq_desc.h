@@ -116,10 +116,10 @@ HVQ_HD static inline uint32_t hvq_payload_dwords(uint32_t type, int is_pb, int i
     return kind == 6u ? ((inter && (type & 0x10u)) ? 0u : 4u) : (inter ? n_inter : n_intra);
 }
 
-/* one reconstruction job = one picture of one stream (device-visible).  The runtime copies the
- * geometry out of the blob header so that a workgroup reaches its map with two dependent loads
- * (tile table -> job -> map) instead of three. */
-typedef struct HvqPlaneRec {       /* everything a tile of this plane needs, ready to use (32 bytes) */
+/* one reconstruction job = one picture of one stream (device-visible): what the runtime knows about the picture.
+ * hvq_tilegen_kernel expands it, together with the blob's wave_base[] (which only the device has when the picture was
+ * parsed there), into one self-contained HvqTileRec per workgroup. */
+typedef struct HvqPlaneRec {       /* per-plane part (32 bytes) */
     uint64_t map;                  /* device address of the plane's map (entry [-1][-1], i.e. incl. border) */
     uint64_t dst;                  /* device address of the plane inside the destination picture */
     uint32_t plane_off;            /* byte offset of the plane inside a picture buffer (reference reads) */
@@ -141,7 +141,9 @@ typedef struct HvqJob {
     uint16_t width, height;
     uint8_t  pic_kind, unk_shift, pad0[2];
     uint32_t mcb_w;
-    uint32_t pad1[3];
+    uint32_t pool_dwords;          /* payload pool size: end of the last tile's payload */
+    uint32_t total_tiles;
+    uint32_t pad1;
     HvqPlaneRec plane[3];
     uint32_t pad2[8];
 } HvqJob;
@@ -154,10 +156,40 @@ _Static_assert(sizeof(HvqPlaneRec) == 32, "HvqPlaneRec must be 32 bytes");
 _Static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
 #endif
 
-/* one workgroup = one tile */
+/* one workgroup = one tile: the host deals {job, tile} pairs into launch order (XCD-aware) ... */
 typedef struct HvqTileRef {
-    uint32_t job;
+    uint32_t job;                  /* 0xFFFFFFFF: padding entry of the XCD-dealt table */
     uint32_t tile;
 } HvqTileRef;
+
+/* ... and the device turns each into everything its workgroup needs, ready to use: ONE 128-byte scalar load
+ * replaces the tile table -> job -> plane record -> wave_base chain of dependent loads (each ~700 cycles under load). */
+#define HVQ_TR_KIND_SHIFT   16     /* flags: HVQ_F_* in the low 16 bits, then picture kind, unk_shift, plane */
+#define HVQ_TR_UNK_SHIFT    20
+#define HVQ_TR_PLANE_SHIFT  28
+typedef struct HvqTileRec {
+    uint64_t map;                  /* plane map, entry [-1][-1] */
+    uint64_t dst;                  /* plane inside the destination picture */
+    uint64_t pool;                 /* first payload dword OF THE TILE */
+    uint64_t mv;
+    uint64_t nest;
+    uint64_t ref0, ref1;
+    uint32_t b0;                   /* first block of the tile inside its plane */
+    uint32_t nblocks;              /* blocks of the plane */
+    uint32_t pool_dwords;          /* payload dwords of the tile */
+    uint32_t wrel[3];              /* payload offset of the tile's 64-block runs 1..3 relative to run 0 */
+    uint32_t plane_off, slot_bytes;
+    uint32_t flags;
+    uint16_t hb, vb, pw, lw, mcb_w;   /* hb == 0: padding entry, the workgroup exits */
+    uint8_t  ws, hs;
+    float    rhb;                  /* 1 / hb */
+    uint32_t pad[5];
+} HvqTileRec;
+
+#if defined(__cplusplus)
+static_assert(sizeof(HvqTileRec) == 128, "HvqTileRec must be 128 bytes");
+#else
+_Static_assert(sizeof(HvqTileRec) == 128, "HvqTileRec must be 128 bytes");
+#endif
 
 #endif

@@ -336,80 +336,175 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 
 #define HVQ_NW (HVQ_WG / 64)
 
-/*
- * Workgroup = tile of 256 consecutive blocks of one plane.
- *   phase A   every lane owns one block: descriptors are fetched with independent loads (own map
- *             entry, four neighbours, macroblock vector); cheap kinds (flat, weighted-DC, literal,
- *             plain MC) and the MC part of MC-residual blocks are reconstructed at once into the LDS
- *             tile; AOT blocks are queued
- *             (intra items first, then MC-residual items; entries carry what the owner fetched) and
- *             every basis of every queued block becomes one (item, basis) pair.
- *   phase B1  one lane per PAIR: nest gather, min/max, gain, 16 products -> ds_add into the item's
- *             accumulators.  The serial per-block basis loop of the reference (h4m:782-788) becomes one
- *             parallel step; lane utilisation is independent of how basis counts are distributed.
- *   phase B2  one lane per queued block: accumulators -> samples (h4m:1367-1376 / 1385-1419).
- *   phase C   the finished tile leaves LDS as 16-byte row segments: one store instruction of a wave
- *             writes four complete 256-byte runs of the destination plane (full lines, written once).
+/* Diagnostic build only (-DHVQ_STAMPS, tools/variant.sh): s_memtime stamps of wave phases into a buffer of their own
+ * (64 x u64 per workgroup: [wave][16]); the shipped kernel executes no stamp.  VM = also wait for the wave's
+ * outstanding vector-memory operations first (exposes load latency at that point). */
+#ifdef HVQ_STAMPS
+static unsigned long long *g_stamps = nullptr;
+extern "C" __attribute__((visibility("default"))) void hvq_set_stamps(unsigned long long *p) { g_stamps = p; }
+#define HVQ_STAMP_ARG , unsigned long long *stamps
+#define STAMP(i, VM) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+        if (VM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+        if (stamps && (threadIdx.x & 63) == 0) stamps[(size_t)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + (i)] = t_; } while (0)
+#else
+#define HVQ_STAMP_ARG
+#define STAMP(i, VM) do { } while (0)
+#endif
+
+/* ------------------------------------------------------------------------------------------------------
+ * Tile records.  The host deals {job, tile} pairs into launch order; this kernel expands each into the
+ * self-contained 128-byte record its workgroup reads with one scalar load (hvq_desc.h).  It runs once per
+ * flush (after the entropy parse, whose wave_base[] only the device has for GPU-parsed pictures).
  */
-__global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
-void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles, u32 items_cap, u32 pair_cap)
+__global__ __launch_bounds__(256)
+void hvq_tilegen_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles, HvqTileRec *__restrict__ recs, u32 n)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];   /* accumulators [16][items_cap] + pair list [pair_cap] */
-    __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];   /* nest packed two 4-bit values per byte */
-    __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];   /* [sample row][block] packed dwords */
-    i32 *s_acc = (i32 *)s_dyn;             /* AOT accumulators, [sample][queued block]: lanes of one ds_add hit
-                                              consecutive banks (a [block][16] layout is a 32-way conflict) */
-    u32 *s_pair = (u32 *)(s_dyn + 64u * items_cap);   /* item | pool index of the basis << 9 */
-    __shared__ u32 s_item0[HVQ_WG];    /* owner lane | payload offset << 10 */
-    __shared__ u32 s_item1[HVQ_WG];    /* map entry {value, type} */
-    __shared__ u32 s_item2[HVQ_WG];    /* macroblock vector */
-    __shared__ u32 s_cnt[HVQ_NW][3];
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const HvqTileRef ref = tiles[i];
+    HvqTileRec r;
+    __builtin_memset(&r, 0, sizeof r);
+    if (ref.job != 0xFFFFFFFFu) {
+        const HvqJob *J = jobs + ref.job;
+        const u32 tile = ref.tile;
+        const int p = (tile >= J->plane[1].tile_first) + (tile >= J->plane[2].tile_first);
+        const HvqPlaneRec P = J->plane[p];
+        const u32 *wb = (const u32 *)J->wave_base + (size_t)tile * HVQ_NW;
+        const u32 w0 = wb[0];
+        const u32 wend = tile + 1 < J->total_tiles ? wb[HVQ_NW] : J->pool_dwords;
+        r.map = P.map; r.dst = P.dst;
+        r.pool = J->pool + 4ull * w0;
+        r.mv = J->mv; r.nest = J->nest; r.ref0 = J->ref0; r.ref1 = J->ref1;
+        r.b0 = (tile - P.tile_first) * HVQ_TILE_BLOCKS;
+        r.nblocks = (u32)P.hb * P.vb;
+        r.pool_dwords = wend - w0;
+        r.wrel[0] = wb[1] - w0; r.wrel[1] = wb[2] - w0; r.wrel[2] = wb[3] - w0;
+        r.plane_off = P.plane_off; r.slot_bytes = J->slot_bytes;
+        r.flags = (J->flags & 0xFFFFu) | ((u32)J->pic_kind << HVQ_TR_KIND_SHIFT) | ((u32)J->unk_shift << HVQ_TR_UNK_SHIFT) |
+                  ((u32)p << HVQ_TR_PLANE_SHIFT);
+        r.hb = P.hb; r.vb = P.vb; r.pw = P.pw; r.lw = J->width; r.mcb_w = (uint16_t)J->mcb_w;
+        r.ws = P.ws; r.hs = P.hs;
+        r.rhb = 1.0f / (float)P.hb;
+    }
+    recs[i] = r;
+}
+
+extern "C" hipError_t hvq_launch_tilegen(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, HvqTileRec *recs_dev, uint32_t n,
+                                         hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(hvq_tilegen_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, jobs_dev, tiles_dev, recs_dev, n);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------------------
+ * Reconstruction.
+ *
+ * Workgroup = tile of 256 consecutive blocks of one plane; wave = 64 of them; lane = one block.
+ * What bounds this kernel is the depth of its chain of dependent memory round trips (each ~1.7k cycles under load,
+ * profiles/r02a_stamps.txt), so it is built as three levels with everything inside a level issued at once:
+ *   level 0   one scalar load of the tile record;
+ *   level 1   own map entry + four neighbours + macroblock vector per lane, and -- cooperatively -- the tile's whole
+ *             payload (contiguous in the pool) and the nest into LDS;
+ *   level 2   the gathers that depend on them: motion-compensation source rows, MC-residual window rows.
+ * After the one barrier that publishes payload and nest, every wave works on its own 64 blocks without meeting the
+ * others again:
+ *   cheap kinds (flat, weighted DC, literal, plain MC) are reconstructed by the owning lane into the LDS tile;
+ *   AOT blocks are queued PER WAVE, at most HVQ_CHUNK at a time, counting-sorted by (class, number of bases) with one
+ *   returning LDS add per item; every (item, basis) pair becomes one lane's work (the serial basis loop of h4m:782-788
+ *   turns into one parallel step), laid out basis-major -- pair (k, r) of the r-th item in sorted order sits at
+ *   seg[k] + r -- so that the 64 lanes of one ds_add hit 64 different items = consecutive banks: no same-address
+ *   serialisation and no bank conflict (item-major order made the 1..15 lanes of one item add to the same 16 words);
+ *   the item's lane then turns the accumulators into samples (h4m:1367-1376 / 1385-1419);
+ *   the wave's 64 blocks leave LDS as 16-byte row segments: one store instruction writes four complete 256-byte runs.
+ * LDS traffic inside a wave needs no barrier: a wave's LDS instructions execute in order.
+ */
+#define HVQ_POOL_LDS 640            /* payload dwords of a tile staged in LDS; larger tiles read the pool from HBM */
+#define HVQ_CHUNK    32             /* queued blocks accumulated at a time per wave */
+#define HVQ_PAIRWIN  128            /* (item, basis) pairs listed at a time per wave */
+
+struct WaveLds {
+    i32 acc[16 * HVQ_CHUNK];        /* [sample][item slot] */
+    u32 pair[HVQ_PAIRWIN];          /* item slot | payload index of the basis << 5 */
+    u32 hist[32];                   /* items per (class, bases) bin; then pair segment starts per (class, basis k) */
+    u32 item[HVQ_CHUNK];            /* owner lane | map entry {value, type} << 8 */
+    u32 imv[HVQ_CHUNK];             /* the owner's macroblock vector */
+    u32 ioff[HVQ_CHUNK];            /* the owner's payload index */
+};
+
+/* compiler-level ordering of LDS accesses between lanes of ONE wave (the hardware executes them in order) */
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
+void hvq_recon_kernel(const HvqTileRec *__restrict__ recs HVQ_STAMP_ARG)
+{
+    __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];                  /* [sample row][block] packed dwords */
+    __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 16];  /* nest, two 4-bit values per byte */
+    __shared__ __attribute__((aligned(16))) u32 s_pool[HVQ_POOL_LDS];
+    __shared__ __attribute__((aligned(16))) WaveLds s_w[HVQ_NW];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const u32 job_id = __builtin_amdgcn_readfirstlane(tiles[blockIdx.x].job);
-    const u32 tile = __builtin_amdgcn_readfirstlane(tiles[blockIdx.x].tile);
-    if (job_id == 0xFFFFFFFFu) return;            /* padding entry of the XCD-dealt tile table (uniform exit) */
-    const HvqJob *__restrict__ J = jobs + job_id;
-    /* plane of the tile, then ONE 32-byte record with everything per-plane (absolute pointers, geometry) */
-    const int p = (tile >= J->plane[1].tile_first) + (tile >= J->plane[2].tile_first);
-    const HvqPlaneRec *__restrict__ R = &J->plane[p];
-    const i32 hb = R->hb, vb = R->vb;
-    const float rhb = 1.0f / (float)hb;
-    const u32 nblocks = (u32)hb * (u32)vb;
-    const u32 b0 = (tile - R->tile_first) * HVQ_TILE_BLOCKS;
-    const i32 ws = R->ws, hs = R->hs;
-    const i32 pw = R->pw;
-    const u32 flags = J->flags;
-    const bool is_pb = J->pic_kind != HVQ_PIC_I;
-    const bool I_luma = !is_pb && p == 0;
-    const i32 unk = J->unk_shift;
-    const i32 mstride = hb + 2;
+    STAMP(0, 0);
+    /* ---- level 0: the tile record ---- */
+    const HvqTileRec *__restrict__ R = recs + blockIdx.x;
+    const i32 hb = R->hb;
+    if (hb == 0) return;                                  /* padding entry of the XCD-dealt table (uniform exit) */
+    const u32 flags = R->flags;
+    const u32 pic_kind = (flags >> HVQ_TR_KIND_SHIFT) & 3u;
+    const i32 unk = (i32)((flags >> HVQ_TR_UNK_SHIFT) & 31u);
+    const int plane_id = (int)(flags >> HVQ_TR_PLANE_SHIFT);
+    const bool is_pb = pic_kind != HVQ_PIC_I;
+    const bool I_luma = !is_pb && plane_id == 0;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
     const bool big = flags & HVQ_F_BIG_AOT;
+    const float rhb = R->rhb;
+    const u32 nblocks = R->nblocks;
+    const u32 b0 = R->b0;
+    const i32 ws = R->ws, hs = R->hs;
+    const i32 pw = R->pw;
+    const i32 mstride = hb + 2;
     const GLB uint8_t *map = (const GLB uint8_t *)R->map;
-    const GLB u32 *__restrict__ pool = (const GLB u32 *)J->pool;
-    const GLB u32 *__restrict__ mvs = (const GLB u32 *)J->mv;
+    const GLB u32 *__restrict__ gpool = (const GLB u32 *)R->pool;
+    const GLB u32 *__restrict__ mvs = (const GLB u32 *)R->mv;
+    const GLB u32 *__restrict__ gnest = (const GLB u32 *)R->nest;
+    const GLB uint8_t *ref0 = (const GLB uint8_t *)R->ref0, *ref1 = (const GLB uint8_t *)R->ref1;
     const i32 plane_off = (i32)R->plane_off;
     GLB uint8_t *plane = (GLB uint8_t *)R->dst;
-    const i32 slot = (i32)J->slot_bytes;
-    const i32 mcb_w = (i32)J->mcb_w;
-    const i32 lw = J->width;
+    const i32 slot = (i32)R->slot_bytes;
+    const i32 mcb_w = (i32)R->mcb_w;
+    const i32 lw = R->lw;
+    const u32 pool_dwords = R->pool_dwords;
+    const bool pool_lds = pool_dwords <= HVQ_POOL_LDS;
+    const bool need_nest = (flags & HVQ_F_HAS_NEST) && gnest;
+    STAMP(1, 0);
 
-    /* ---- phase A: own block ---- */
+    /* ---- level 1: own descriptors per lane; payload and nest for the workgroup ---- */
     const u32 b = b0 + (u32)tid;
     const bool valid = b < nblocks;
     i32 bx, by;
     block_coords(valid ? b : 0u, hb, rhb, bx, by);
     const GLB uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
-    /* independent loads first: own entry, four neighbours, vector, wave payload base */
     const u32 e16 = *(const GLB uint16_t *)ent;
     const u32 nt = *(const GLB uint16_t *)(ent - 2 * mstride), nbt = *(const GLB uint16_t *)(ent + 2 * mstride);
     const u32 nl = *(const GLB uint16_t *)(ent - 2), nr = *(const GLB uint16_t *)(ent + 2);
     u32 mvw = 0;
     if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
-    const u32 wbase = ((const GLB u32 *)J->wave_base)[tile * HVQ_NW + (u32)wave];
+    u32 pq[(HVQ_POOL_LDS + HVQ_WG - 1) / HVQ_WG];
+    if (pool_lds) {
+#pragma unroll
+        for (int j = 0; j < (HVQ_POOL_LDS + HVQ_WG - 1) / HVQ_WG; ++j) {
+            pq[j] = 0;
+            if ((u32)tid + HVQ_WG * j < pool_dwords) pq[j] = gpool[tid + HVQ_WG * j];
+        }
+    }
+    u32 nq0 = 0, nq1 = 0;
+    if (need_nest) {
+        nq0 = gnest[tid];
+        if (tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4) nq1 = gnest[tid + HVQ_WG];
+    }
 
     const i32 V = e16 & 0xFF;
     const u32 T = valid ? (e16 >> 8) : 0u;
@@ -422,26 +517,39 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const bool c2 = valid && inter && !(T & 0x10u) && aot_kind;
     const int cls = c1 ? 1 : c2 ? 2 : 0;
     const u32 nb = c1 ? kind : c2 ? kind - 1u : 0u;
-    /* payload offset / pair slot: prefix sums over the wave, skipped when the wave carries no payload at all */
-    u32 off = wbase, pincl = 0;
-    if (__ballot(npay != 0)) { off += wave_incl_scan(npay) - npay; pincl = wave_incl_scan(nb); }
-    const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
-    if (lane == 63) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = pincl; }
+    /* payload index inside the tile: the wave's base from the record + prefix sum over the wave */
+    u32 off = wave == 0 ? 0u : wave == 1 ? R->wrel[0] : wave == 2 ? R->wrel[1] : R->wrel[2];
+    if (__ballot(npay != 0)) off += wave_incl_scan(npay) - npay;
+    STAMP(2, 1);
 
-    if (HVQ_ABL != 4 && HVQ_ABL != 5 && valid && cls != 1) {
+    if (pool_lds) {
+#pragma unroll
+        for (int j = 0; j < (HVQ_POOL_LDS + HVQ_WG - 1) / HVQ_WG; ++j)
+            if (tid + HVQ_WG * j < HVQ_POOL_LDS) s_pool[tid + HVQ_WG * j] = pq[j];
+    }
+    if (need_nest) {
+        ((u32 *)s_nest)[tid] = nq0;
+        if (tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
+    }
+    __syncthreads();                                    /* the only workgroup barrier: payload + nest published */
+    STAMP(3, 0);
+
+    /* ---- level 2a: motion-compensation rows of the own block go out first ... ---- */
+    const bool needs_mc = valid && inter && (cls == 2 || (T & 0x10u) || kind == 0);
+    McRows rows;
+    int hx = 0, hy = 0;
+    if (needs_mc) {
+        const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+        const GLB uint8_t *ref = (((T >> 5) & 3u) == 1u) ? ref0 : ref1;
+        const i32 pdx = rx >> ws, pdy = ry >> hs;
+        hx = is15 ? (pdx & 1) : (rx & 1); hy = is15 ? (pdy & 1) : (ry & 1);              /* h4m:1337-1343 */
+        const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+        rows = mc_load(ref, a, pw, hy, slot - 8);
+    }
+    /* ---- ... while the kinds that need nothing else are finished ---- */
+    if (valid && !needs_mc && cls == 0) {
         Blk o;
-        const GLB u32 *__restrict__ pay = pool + off;
-        const bool needs_mc = inter && (cls == 2 || (T & 0x10u) || kind == 0);
-        if (needs_mc) {
-            /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
-            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-            const GLB uint8_t *ref = (const GLB uint8_t *)((((T >> 5) & 3u) == 1u) ? J->ref0 : J->ref1);
-            const i32 pdx = rx >> ws, pdy = ry >> hs;
-            const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
-            const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
-            if (HVQ_ABL == 2) { o.r[0] = o.r[1] = o.r[2] = o.r[3] = (u32)(a + hx + hy); }
-            else o = mc_block(ref, a, pw, hx, hy, slot - 8);
-        } else if (!inter && kind == 0) {
+        if (!inter && kind == 0) {
             /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
              * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
             i32 Tt = (nt & 0x7700u) ? V : (i32)(nt & 0xFF);
@@ -454,127 +562,140 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             /* flat DC (h4m:281-286) or literal (h4m:543-549) */
             const u32 v = (u32)V * 0x01010101u;
             o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
-            if (kind == 6) { o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3]; }
+            if (kind == 6) {
+                if (pool_lds) { o.r[0] = s_pool[off]; o.r[1] = s_pool[off + 1]; o.r[2] = s_pool[off + 2]; o.r[3] = s_pool[off + 3]; }
+                else { o.r[0] = gpool[off]; o.r[1] = gpool[off + 1]; o.r[2] = gpool[off + 2]; o.r[3] = gpool[off + 3]; }
+            }
         }
 #pragma unroll
         for (int y = 0; y < 4; ++y) s_out[y][tid] = o.r[y];
     }
-
-    __syncthreads();                                                           /* barrier 1: queue counts */
-    u32 nI = 0, nP = 0, myI = 0, myP = 0, npairs = 0, pbefore = 0;
+    STAMP(4, 0);
+    if (needs_mc) {
+        const Blk o = mc_filter(rows, hx, hy);          /* plain MC, and the MC part of MC-residual blocks */
 #pragma unroll
-    for (int w = 0; w < HVQ_NW; ++w) {
-        const u32 ci = s_cnt[w][0], cp = s_cnt[w][1], cb = s_cnt[w][2];
-        if (w < wave) { myI += ci; myP += cp; pbefore += cb; }
-        nI += ci; nP += cp; npairs += cb;
+        for (int y = 0; y < 4; ++y) s_out[y][tid] = o.r[y];
     }
-    const u32 total = (HVQ_ABL == 1 || HVQ_ABL == 4) ? 0u : nI + nP;
-    const bool parallel = npairs <= pair_cap && total <= items_cap;
-    if (total && parallel && (u32)tid < items_cap) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s_acc[i * items_cap + tid] = 0;
-    }
-    if (cls) {
-        const u32 slotq = cls == 1 ? myI + lanes_below(m1) : nI + myP + lanes_below(m2);
-        s_item0[slotq] = (u32)tid | (off << 10);
-        s_item1[slotq] = e16;
-        s_item2[slotq] = mvw;
-        if (parallel) {
-            const u32 pstart = pbefore + pincl - nb, bidx = off + (cls == 2 ? 2u : 0u);
-            for (u32 k = 0; k < nb; ++k) s_pair[pstart + k] = slotq | ((bidx + k) << 9);
-        }
-    }
-    if (nI) {
-        const GLB u32 *src = (const GLB u32 *)J->nest;                /* already nibble-packed by the host */
-        for (int i = tid; i < (HVQ_NESTP_BYTES + 3) / 4; i += HVQ_WG) ((u32 *)s_nest)[i] = src[i];
-    }
-    if (total) __syncthreads();                                                /* barrier 2: queue + nest staged */
+    STAMP(5, 0);
 
-    if (total) {
-        const bool has_item = (u32)tid < total;
-        const bool item_mc = has_item && (u32)tid >= nI;
-        u32 owner = 0, q16 = 0, p0 = 0, p1 = 0;
-        const GLB u32 *__restrict__ qpay = pool;
-        if (has_item) {
-            const u32 item = s_item0[tid];
-            owner = item & 1023u;
-            qpay = pool + (item >> 10);
-            q16 = s_item1[tid];
-        }
-        if (item_mc) { p0 = qpay[0]; p1 = qpay[1]; }          /* in flight while phase B1 runs */
-
-        u32 r[16];
-        if (parallel) {
-            /* ---- phase B1: one lane per (item, basis) pair ---- */
-            for (u32 pi = (u32)tid; pi < npairs; pi += HVQ_WG) {
-                const u32 pr = s_pair[pi];
-                const u32 it = pr & 511u;
-                const u32 d = pool[pr >> 9];
-                u32 e[16], lo, hi;
-                if (it < nI) {
-                    gather_nest(d, landscape, s_nest, e, lo, hi);
-                } else {
-                    const u32 t16 = s_item1[it], mv = s_item2[it];
-                    const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
-                    const GLB uint8_t *ref = (const GLB uint8_t *)(((t16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
-                    const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
-                    gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
-                }
-                basis_scatter(basis_gain(d, lo, hi, big), e, big, s_acc + it, items_cap);
-            }
-            __syncthreads();                                                   /* barrier 3: accumulators complete */
-            if (has_item) {
+    /* ---- AOT blocks of this wave, HVQ_CHUNK at a time ---- */
+    const unsigned long long imask = __ballot(cls != 0);
+    const u32 nitems = (u32)__popcll(imask);
+    if (nitems) {
+        WaveLds &W = s_w[wave];
+        const u32 idx = lanes_below(imask);
+        for (u32 c0 = 0; c0 < nitems; c0 += HVQ_CHUNK) {
+            const bool act = cls != 0 && idx - c0 < (u32)HVQ_CHUNK;
+            const u32 nchunk = min(nitems - c0, (u32)HVQ_CHUNK);
+            /* counting sort by (class, bases descending): bin = class-2 flag * 16 + 15 - min(bases, 15) */
+            if (lane < 32) W.hist[lane] = 0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) r[i] = (u32)s_acc[i * items_cap + tid];
-            }
-        } else if (has_item) {
-            /* serial fallback for tiles whose queue exceeds the launch's LDS sizing (pathological streams) */
-            i32 acc[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0;
-            const bool intra_item = (u32)tid < nI;
-            const u32 n = intra_item ? (I_luma ? (q16 >> 8) : ((q16 >> 8) & 0xFu)) : ((q16 >> 8) & 0xFu) - 1u;
-            const GLB u32 *bases = qpay + (intra_item ? 0 : 2);
-            const u32 mv = s_item2[tid];
-            const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
-            const GLB uint8_t *ref = (const GLB uint8_t *)(((q16 >> 13) & 3u) == 1u ? J->ref0 : J->ref1);
-            const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
-            for (u32 k = 0; k < n; ++k) {
-                const u32 d = bases[k];
-                u32 e[16], lo, hi;
-                if (intra_item) gather_nest(d, landscape, s_nest, e, lo, hi);
-                else gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
-                const i32 g = basis_gain(d, lo, hi, big);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] += big ? (i32)((u32)g * e[i]) : __mul24(g, (i32)e[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = (u32)acc[i];
-        }
-
-        /* ---- phase B2: one lane per queued block ---- */
-        if (has_item) {
+            for (int j = 0; j < 16 * HVQ_CHUNK / 64; ++j) W.acc[lane + 64 * j] = 0;
+            WAVE_SYNC();
+            const u32 bin = (cls == 2 ? 16u : 0u) + 15u - min(nb, 15u);
+            u32 rank = 0;
+            if (act) rank = __hip_atomic_fetch_add(&W.hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            WAVE_SYNC();
+            const u32 hcount = W.hist[lane & 31];
+            WAVE_SYNC();
+            const u32 hincl = wave_incl_scan(lane < 32 ? hcount : 0u);
+            const u32 hexcl = hincl - (lane < 32 ? hcount : 0u);                  /* lane j < 32: items in bins below j */
+            const u32 n1 = (u32)__builtin_amdgcn_readlane((int)hexcl, 16);        /* class-1 items of the chunk */
+            /* items of class c with more than k bases: E[c*16 + 15 - k] - E[c*16]; lane c*16 + k holds it */
+            const int cbase = lane & 16, kk = lane & 15;
+            const u32 e_hi = (u32)__builtin_amdgcn_ds_bpermute(4 * (cbase + 15 - kk), (int)hexcl);
+            const u32 e_lo = (u32)__builtin_amdgcn_ds_bpermute(4 * cbase, (int)hexcl);
+            const u32 cnt = lane < 32 ? e_hi - e_lo : 0u;
+            /* pair segment starts: exclusive prefix of cnt over k inside each class (a DPP row = 16 lanes), class 2 after class 1 */
+            u32 segi = cnt;
+            segi += (u32)__builtin_amdgcn_update_dpp(0, (int)segi, 0x111, 0xF, 0xF, false);
+            segi += (u32)__builtin_amdgcn_update_dpp(0, (int)segi, 0x112, 0xF, 0xF, false);
+            segi += (u32)__builtin_amdgcn_update_dpp(0, (int)segi, 0x114, 0xF, 0xF, false);
+            segi += (u32)__builtin_amdgcn_update_dpp(0, (int)segi, 0x118, 0xF, 0xF, false);
+            const u32 P1 = (u32)__builtin_amdgcn_readlane((int)segi, 15), P2 = (u32)__builtin_amdgcn_readlane((int)segi, 31);
+            u32 npairs = P1 + P2;
+            /* slot in sorted order (every lane takes part in the cross-lane read: a disabled source lane would read as 0) */
+            const u32 slotq = (u32)__builtin_amdgcn_ds_bpermute(4 * (int)bin, (int)hexcl) + rank;
+            u32 pstart = 0;
             if (!big) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) r[i] <<= 4;
-            }
-            Blk o;
-            if (item_mc) {
-                Blk m;                                       /* the owner left the MC block in the tile */
-#pragma unroll
-                for (int y = 0; y < 4; ++y) m.r[y] = s_out[y][owner];
-                o = predi_finish(r, m, p0, p1, unk);
+                if (lane < 32) W.hist[lane] = segi - cnt + (lane >= 16 ? P1 : 0u);
             } else {
-                o = intra_finish(r, (i32)(q16 & 0xFF), unk);
+                /* more than 15 bases per block possible (I-luma type bytes > 15, never produced by real encoders): the
+                 * prefix property of the sorted order does not hold beyond k = 15, pairs are listed item-major */
+                const u32 nbm = act ? nb : 0u;
+                const u32 pin = wave_incl_scan(nbm);
+                pstart = pin - nbm;
+                npairs = (u32)__builtin_amdgcn_readlane((int)pin, 63);
             }
+            if (act) {
+                W.item[slotq] = (u32)lane | (e16 << 8);
+                W.imv[slotq] = mvw;
+                W.ioff[slotq] = off;
+            }
+            WAVE_SYNC();
+            const u32 rcls = slotq - (cls == 2 ? n1 : 0u);                        /* rank inside the class */
+            const u32 bidx = off + (cls == 2 ? 2u : 0u);
+            for (u32 w0 = 0; w0 < npairs; w0 += HVQ_PAIRWIN) {
+                if (act) {
+                    for (u32 k = 0; k < nb; ++k) {
+                        const u32 pos = (big ? pstart + k : W.hist[(cls == 2 ? 16u : 0u) + k] + rcls) - w0;
+                        if (pos < (u32)HVQ_PAIRWIN) W.pair[pos] = slotq | ((bidx + k) << 5);
+                    }
+                }
+                WAVE_SYNC();
+                const u32 wn = min(npairs - w0, (u32)HVQ_PAIRWIN);
+                /* ---- one lane per (item, basis) pair ---- */
+                for (u32 pi = (u32)lane; pi < wn; pi += 64) {
+                    const u32 pr = W.pair[pi];
+                    const u32 it = pr & 31u;
+                    const u32 d = pool_lds ? s_pool[pr >> 5] : gpool[pr >> 5];
+                    u32 e[16], lo, hi;
+                    if (it < n1) {
+                        gather_nest(d, landscape, s_nest, e, lo, hi);
+                    } else {
+                        const u32 t16 = W.item[it] >> 8, mv = W.imv[it];
+                        const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
+                        const GLB uint8_t *ref = ((t16 >> 13) & 3u) == 1u ? ref0 : ref1;
+                        const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
+                        gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
+                    }
+                    basis_scatter(basis_gain(d, lo, hi, big), e, big, W.acc + it, HVQ_CHUNK);
+                }
+                WAVE_SYNC();
+            }
+            /* ---- one lane per queued block: accumulators -> samples ---- */
+            if ((u32)lane < nchunk) {
+                const u32 info = W.item[lane];
+                const u32 owner = (u32)(wave * 64) + (info & 63u);
+                const u32 q16 = info >> 8;
+                u32 r[16];
 #pragma unroll
-            for (int y = 0; y < 4; ++y) s_out[y][owner] = o.r[y];
+                for (int i = 0; i < 16; ++i) r[i] = (u32)W.acc[i * HVQ_CHUNK + lane];
+                if (!big) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) r[i] <<= 4;
+                }
+                Blk o;
+                if ((u32)lane >= n1) {
+                    const u32 po = W.ioff[lane];
+                    const u32 p0 = pool_lds ? s_pool[po] : gpool[po], p1 = pool_lds ? s_pool[po + 1] : gpool[po + 1];
+                    Blk m;                                       /* the owner left the MC block in the tile */
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) m.r[y] = s_out[y][owner];
+                    o = predi_finish(r, m, p0, p1, unk);
+                } else {
+                    o = intra_finish(r, (i32)(q16 & 0xFF), unk);
+                }
+#pragma unroll
+                for (int y = 0; y < 4; ++y) s_out[y][owner] = o.r[y];
+            }
+            WAVE_SYNC();
         }
-        __syncthreads();                                                       /* barrier 4: tile complete in LDS */
     }
+    STAMP(6, 1);
+    WAVE_SYNC();
 
-    /* ---- phase C: tile -> HBM ---- */
-    if (HVQ_ABL == 3 || HVQ_ABL == 4) return;
+    /* ---- the wave's 64 blocks -> HBM ---- */
     if ((hb & 3) == 0) {
         /* lane (g, r): sample row r of blocks 4g..4g+3 = 16 contiguous bytes of the plane */
         const int g = wave * 16 + (lane & 15), rr = lane >> 4;
@@ -586,7 +707,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             const u32x4 v = *(const u32x4 *)&s_out[rr][4 * g];
             /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors
              * in L2 (+1 % on MC-dominated streams, neutral on the dense one; profiles/r01j_ab_nontemporal.txt) */
-            if (J->pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
+            if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
             else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
         }
     } else if (valid) {
@@ -594,14 +715,18 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 #pragma unroll
         for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[y][tid];
     }
+    STAMP(7, 0);
+    STAMP(8, 1);
 }
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
-                                       uint32_t items_cap, uint32_t pair_cap, hipStream_t stream)
+extern "C" hipError_t hvq_launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, hipStream_t stream)
 {
     if (ntiles == 0) return hipSuccess;
-    const uint32_t dyn = 64u * items_cap + 4u * pair_cap;
-    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), dyn, stream, jobs_dev, tiles_dev, items_cap, pair_cap);
+#ifdef HVQ_STAMPS
+    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), 0, stream, recs_dev, g_stamps);
+#else
+    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), 0, stream, recs_dev);
+#endif
     return hipGetLastError();
 }
 

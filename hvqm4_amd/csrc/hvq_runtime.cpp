@@ -40,9 +40,13 @@ extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t
 extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, uint32_t ntiles,
-                                       uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
+extern "C" hipError_t hvq_launch_tilegen(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, HvqTileRec *recs_dev, uint32_t n,
+                                         hipStream_t stream);
+extern "C" hipError_t hvq_launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, hipStream_t stream);
 
+#ifdef HVQ_STAMPS
+extern "C" void hvq_set_stamps(unsigned long long *p);
+#endif
 extern "C" hipError_t hvq_launch_rgb(const void *jobs_dev, int njobs, int max_lanes, int wide, hipStream_t stream);
 struct RgbJob { const uint8_t *yuv; uint8_t *rgb; int w, h; };
 
@@ -113,14 +117,13 @@ struct Pending {
     bool dev = false;
     int nest_ref = -1;                 /* pending index of the governing I picture, -1: the stream's nest_keep */
     uint64_t dev_blob = 0, dev_nest = 0, nest_ptr = 0;
-    uint32_t flags = 0, unk_shift = 0;
+    uint32_t flags = 0, unk_shift = 0, pool_dwords = 0;
 };
 
 struct Launch {
     int queue;                         /* 0: main HIP stream, 1: second stream (the other half of the clips) */
     int level;
     uint32_t first_tile, ntiles;
-    uint32_t items_cap, pair_cap;      /* LDS sizing of the launch: max over its pictures */
 };
 
 struct HvqContext {
@@ -162,6 +165,7 @@ struct HvqContext {
     /* last flushed batch (kept resident for hvq_replay) */
     HvqJob *jobs_dev = nullptr;
     HvqTileRef *tiles_dev = nullptr;
+    HvqTileRec *recs_dev = nullptr;    /* one self-contained record per workgroup, expanded on the device (hvq_tilegen_kernel) */
     size_t jobs_cap = 0, tiles_cap = 0;
     std::vector<Launch> launches;
     std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
@@ -295,6 +299,7 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tiles_dev) (void)hipFree(c->tiles_dev);
+    if (c->recs_dev) (void)hipFree(c->recs_dev);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
     if (c->rgb_jobs_dev) (void)hipFree(c->rgb_jobs_dev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -742,6 +747,7 @@ static int device_parse_finish(HvqContext *c)
                         "GPU parse failed (status %u) for stream %d picture %d", res[k].status, p.stream, p.ordinal);
         p.max_items = res[k].max_items; p.max_pairs = res[k].max_pairs;
         p.flags = res[k].flags;
+        p.pool_dwords = res[k].pool_dwords;
         p.blob_len = res[k].total_bytes;
     }
     return HVQ_OK;
@@ -757,8 +763,7 @@ static int run_launches(HvqContext *c)
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     for (auto &L : c->launches)
-        HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.items_cap, L.pair_cap,
-                                L.queue ? c->stream2 : c->stream));
+        HIPCHK(hvq_launch_recon(c->recs_dev + L.first_tile, L.ntiles, L.queue ? c->stream2 : c->stream));
     if (two) {
         HIPCHK(hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -792,7 +797,7 @@ static int build_tiles(HvqContext *c)
             for (uint32_t t = 0; t < p.ntiles; ++t) bin.push_back(HvqTileRef{ (uint32_t)i, t });
         }
         if (!nb) continue;
-        Launch L{ qi, lvl, (uint32_t)tiles.size(), 0, 0, 0 };
+        Launch L{ qi, lvl, (uint32_t)tiles.size(), 0 };
         if (nb < 8) {
             /* too few pictures to give every XCD its own: plain order, no padding */
             for (int x = 0; x < nb; ++x) tiles.insert(tiles.end(), bins[x].begin(), bins[x].end());
@@ -810,9 +815,10 @@ static int build_tiles(HvqContext *c)
       }
     c->fl_nq = nq;
     if (tiles.size() > c->tiles_cap) {
-        if (c->tiles_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tiles_dev)); }
+        if (c->tiles_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tiles_dev)); HIPCHK(hipFree(c->recs_dev)); }
         c->tiles_cap = tiles.size() * 2;
         HIPCHK(hipMalloc((void **)&c->tiles_dev, c->tiles_cap * sizeof(HvqTileRef)));
+        HIPCHK(hipMalloc((void **)&c->recs_dev, c->tiles_cap * sizeof(HvqTileRec)));
     }
     return staged_upload(c, c->fl_arena_id, 1, c->tiles_dev, tiles.data(), tiles.size() * sizeof(HvqTileRef));
 }
@@ -905,6 +911,8 @@ static int flush_end(HvqContext *c)
         j.flags = hd->flags; j.width = hd->width; j.height = hd->height;
         j.pic_kind = hd->pic_kind; j.unk_shift = hd->unk_shift;
         j.mcb_w = hd->mcb_w;
+        j.pool_dwords = p.dev ? p.pool_dwords : hd->pool_dwords;
+        j.total_tiles = hd->tile_first[3];
         for (int k = 0; k < 3; ++k) {
             HvqPlaneRec &r = j.plane[k];
             r.map = blob + hd->map_off[k];
@@ -922,18 +930,7 @@ static int flush_end(HvqContext *c)
         st.flags_or |= hd->flags;
         st.gpu_parsed += p.dev ? 1u : 0u;
     }
-    /* LDS sizes of the launches (their tile ranges were dealt at begin): accumulators are 16 dwords per queued block,
-     * rows padded to 32 entries (LDS banks); pairs above the cap take the kernel's serial fallback */
-    for (auto &L : c->fl_launches) {
-        uint32_t mi = 0, mp = 0;
-        for (const Pending &p : c->fl_pending) {
-            if (p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
-            mi = std::max(mi, p.max_items); mp = std::max(mp, p.max_pairs);
-        }
-        L.items_cap = std::max(32u, (mi + 31u) & ~31u);
-        L.pair_cap = std::min(1024u, (mp + 63u) & ~63u);
-        st.workgroups += L.ntiles;
-    }
+    for (auto &L : c->fl_launches) st.workgroups += L.ntiles;
     c->launches = c->fl_launches;
     st.launches = (uint32_t)c->launches.size();
     st.parse_seconds = c->parse_seconds;
@@ -945,7 +942,8 @@ static int flush_end(HvqContext *c)
     }
     /* stream-ordered after whatever still reads the previous table */
     { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return rcu; }
-    /* 3. one launch per level */
+    /* 3. {job, tile} pairs -> self-contained tile records (needs the parse kernel's wave_base[]), then one launch per level */
+    HIPCHK(hvq_launch_tilegen(c->jobs_dev, c->tiles_dev, c->recs_dev, (uint32_t)c->tiles_host.size(), c->stream));
     { int rc = run_launches(c); if (rc) return rc; }
     if (!c->fl_nest_pairs.empty()) {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
         { int rcu = staged_upload(c, c->fl_arena_id, 3, c->np_dev, c->fl_nest_pairs.data(), c->fl_nest_pairs.size() * sizeof(uint64_t)); if (rcu) return rcu; }
@@ -995,6 +993,40 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     if (gpu_ms) *gpu_ms = ms;
+#ifdef HVQ_STAMPS
+    if (getenv("HVQM4_AMD_STAMPS")) {
+        /* diagnostic build: one more pass with phase stamps, per-launch mean segment lengths on stderr */
+        static const char *seg[8] = { "tile record", "issue level-1 loads + classify", "level-1 loads land", "LDS staging + barrier",
+                                      "MC issue + cheap kinds", "MC rows land + filter", "AOT chunks", "store issue" };
+        static const int from[8] = { 0, 1, 1, 2, 3, 4, 5, 6 }, to[8] = { 1, 2, 2, 3, 4, 5, 6, 7 };
+        const int NS = 8, LAST = 8;
+        for (auto &L : c->launches) {
+            unsigned long long *d = nullptr;
+            const size_t n = (size_t)L.ntiles * 64;
+            HIPCHK(hipMalloc((void **)&d, n * 8));
+            HIPCHK(hipMemsetAsync(d, 0, n * 8, c->stream));
+            hvq_set_stamps(d);
+            HIPCHK(hvq_launch_recon(c->recs_dev + L.first_tile, L.ntiles, c->stream));
+            hvq_set_stamps(nullptr);
+            std::vector<unsigned long long> h(n);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipFree(d));
+            double sum[8] = {}, life = 0; size_t cnt[8] = {}, nw = 0;
+            for (size_t t = 0; t < L.ntiles; ++t)
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned long long *q = &h[t * 64 + w * 16];
+                    if (!q[LAST]) continue;
+                    for (int k = 0; k < NS; ++k)
+                        if (q[from[k]] && q[to[k]]) { sum[k] += (double)(q[to[k]] - q[from[k]]); cnt[k]++; }
+                    life += (double)(q[LAST] - q[0]); nw++;
+                }
+            fprintf(stderr, "stamps L%d q%d: %u tiles, %zu waves, mean wave lifetime %.0f cycles;", L.level, L.queue, L.ntiles, nw, nw ? life / nw : 0.0);
+            for (int k = 0; k < NS; ++k) fprintf(stderr, " %s %.0f |", seg[k], cnt[k] ? sum[k] / cnt[k] : 0.0);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return HVQ_OK;
 }
 

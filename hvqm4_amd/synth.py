@@ -60,6 +60,7 @@ class SynthConfig:
     version: str = "1.5"              # "1.3" | "1.5"
     gop: str = "IPBBPBB"              # decode-order picture kinds of one GOP
     n_gops: int = 1
+    repeat_gops: int = 1              # the n_gops generated GOP blocks are written this many times (long clips, cheaply)
     seed: int = 0
     preset: str = "dense"             # "dense"  | "realistic" | "flat" | "natural"
     dc_shifts: Sequence[int] = (0, 1, 2)
@@ -672,8 +673,11 @@ def make_clip(cfg: SynthConfig) -> SynthClip:
             max_frame = max(max_frame, len(payload))
             kinds.append(ft); cursors.append(cur); pictures.append(data)
         body += struct.pack(">IIIII", 0, len(frames), len(cfg.gop), 0, 0x01000000) + frames
+    if cfg.repeat_gops > 1:
+        body = body * cfg.repeat_gops
+        kinds = kinds * cfg.repeat_gops; cursors = cursors * cfg.repeat_gops; pictures = pictures * cfg.repeat_gops
     magic = (b"HVQM4 1.5" if cfg.version == "1.5" else b"HVQM4 1.3").ljust(16, b"\0")
-    hdr = magic + struct.pack(">IIIIIIIII", 0x44, len(body), cfg.n_gops, len(kinds), 0,
+    hdr = magic + struct.pack(">IIIIIIIII", 0x44, len(body), cfg.n_gops * cfg.repeat_gops, len(kinds), 0,
                               cfg.usec_per_frame, max_frame, 0, 0)
     samp = 1 if cfg.sampling == "444" else 2
     hdr += struct.pack(">HHBBBBBBBBI", cfg.width, cfg.height, samp, samp, 0, 0, 0, 0, 0, 0, 0)

@@ -58,9 +58,32 @@ def ref_decode(data: bytes, n_pictures: int, probe: bool = False):
     return out, pr
 
 
+REF_V3_SO = os.path.join(HERE, "_ref", "libh4mref_v3.so")
+_ref_fast = None
+
+
+def ref_fast_flags() -> Optional[str]:
+    """-march flag of the build ref_time uses on this host (None: the portable build)"""
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return None
+    ok = all(f" {k}" in flags for k in ("avx2", "bmi2", "fma"))
+    return "-march=x86-64-v3" if ok and os.path.exists(REF_V3_SO) else None
+
+
 def ref_time(data: bytes, reps: int) -> Tuple[float, int]:
+    """decode-call time of the reference over `reps` passes (the -march=x86-64-v3 build where the CPU allows it)"""
+    global _ref_fast
+    lib = ref()
+    if ref_fast_flags():
+        if _ref_fast is None:
+            _ref_fast = C.CDLL(REF_V3_SO)
+            _ref_fast.ref_time_clip.restype = C.c_double
+            _ref_fast.ref_time_clip.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
+        lib = _ref_fast
     px = C.c_uint64(0)
-    t = ref().ref_time_clip(data, len(data), reps, C.byref(px))
+    t = lib.ref_time_clip(data, len(data), reps, C.byref(px))
     return t, px.value
 
 
