@@ -156,6 +156,32 @@ _Static_assert(sizeof(HvqPlaneRec) == 32, "HvqPlaneRec must be 32 bytes");
 _Static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
 #endif
 
+/* Block classification by map type byte, one dword per (context, type): context 0 = I-picture luma (kind = whole byte,
+ * h4m:1093), 1 = I-picture chroma, 2 = P/B picture.  Filled by hvq_type_class() on the host, read by the kernel. */
+#define HVQ_TC_NPAY(c)   ((c) & 0xFFu)           /* payload dwords (hvq_payload_dwords) */
+#define HVQ_TC_NB(c)     (((c) >> 8) & 0xFFu)    /* AOT bases */
+#define HVQ_TC_CLS(c)    (((c) >> 16) & 3u)      /* 0 done by the owning lane, 1 intra AOT, 2 motion compensation + AOT residual */
+#define HVQ_TC_MC        (1u << 18)              /* motion compensated (plain, or the MC part of class 2) */
+#define HVQ_TC_WDC       (1u << 19)              /* weighted-DC intra predictor (intra kind 0) */
+#define HVQ_TC_LIT       (1u << 20)              /* literal block */
+HVQ_HD static inline uint32_t hvq_type_class(uint32_t type, int ctx)
+{
+    const int is_pb = ctx == 2, il = ctx == 0;
+    const uint32_t kind = il ? type : (type & 0xFu);
+    const int inter = is_pb && (type & 0x60u);
+    const int proc = (type & 0x10u) != 0;
+    const uint32_t npay = hvq_payload_dwords(type, is_pb, il);
+    const int aot = kind != 0u && kind != 6u;
+    const int c1 = !inter && aot && kind != 8u;
+    const int c2 = inter && !proc && aot;
+    const uint32_t nb = c1 ? kind : c2 ? kind - 1u : 0u;
+    uint32_t c = (npay & 0xFFu) | ((nb & 0xFFu) << 8) | ((uint32_t)(c1 ? 1 : c2 ? 2 : 0) << 16);
+    if (inter && (c2 || proc || kind == 0u)) c |= HVQ_TC_MC;
+    if (!inter && kind == 0u) c |= HVQ_TC_WDC;
+    if (kind == 6u && npay) c |= HVQ_TC_LIT;
+    return c;
+}
+
 /* one workgroup = one tile: the host deals {job, tile} pairs into launch order (XCD-aware) ... */
 typedef struct HvqTileRef {
     uint32_t job;                  /* 0xFFFFFFFF: padding entry of the XCD-dealt table */
@@ -167,7 +193,7 @@ typedef struct HvqTileRef {
 #define HVQ_TR_KIND_SHIFT   16     /* flags: HVQ_F_* in the low 16 bits, then picture kind, unk_shift, plane */
 #define HVQ_TR_UNK_SHIFT    20
 #define HVQ_TR_PLANE_SHIFT  28
-typedef struct HvqTileRec {
+typedef struct HvqTileRec {        /* dwords only: 16-bit members would be fetched with vector loads */
     uint64_t map;                  /* plane map, entry [-1][-1] */
     uint64_t dst;                  /* plane inside the destination picture */
     uint64_t pool;                 /* first payload dword OF THE TILE */
@@ -180,10 +206,12 @@ typedef struct HvqTileRec {
     uint32_t wrel[3];              /* payload offset of the tile's 64-block runs 1..3 relative to run 0 */
     uint32_t plane_off, slot_bytes;
     uint32_t flags;
-    uint16_t hb, vb, pw, lw, mcb_w;   /* hb == 0: padding entry, the workgroup exits */
-    uint8_t  ws, hs;
+    uint32_t hb;                   /* 4x4 blocks per row; 0: padding entry, the workgroup exits */
+    uint32_t pw_lw;                /* plane width | luma width << 16 (samples) */
+    uint32_t mcbw_sub;             /* macroblocks per row | ws << 16 | hs << 24 (subsampling shifts relative to luma) */
     float    rhb;                  /* 1 / hb */
-    uint32_t pad[5];
+    uint32_t wxy[4];               /* block coordinates (bx | by << 16) of the first block of each of the tile's 64-block runs */
+    uint32_t pad;
 } HvqTileRec;
 
 #if defined(__cplusplus)

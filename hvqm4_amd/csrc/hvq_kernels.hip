@@ -48,12 +48,6 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 #define HVQ_MIN_WAVES 8               /* waves per SIMD the register allocation must allow (64 VGPRs) */
 #endif
 
-/* ablation builds only (tools/ablate.sh): 1 = no phase B, 2 = no MC loads, 3 = no stores, 4 = descriptors only,
- * 5 = no cheap-kind compute */
-#ifndef HVQ_ABL
-#define HVQ_ABL 0
-#endif
-
 struct Blk { u32 r[4]; };
 
 __device__ __forceinline__ u32 sat_pack(s16x2 a, s16x2 b)
@@ -89,13 +83,13 @@ __device__ __forceinline__ i32 clampi(i32 v, i32 lo, i32 hi) { return min(max(v,
  * source sample inside the reference picture buffer. */
 struct McRows { uint64_t q[5]; };
 
-__device__ __forceinline__ McRows mc_load(const GLB uint8_t *ref, i32 a, i32 stride, int hy, i32 amax8)
+__device__ __forceinline__ McRows mc_load(const GLB uint8_t *ref, i32 a, i32 stride, int hy)
 {
     McRows r;
 #pragma unroll
-    for (int y = 0; y < 4; ++y) r.q[y] = *(const GLB u64u *)(ref + clampi(a + y * stride, 0, amax8));
+    for (int y = 0; y < 4; ++y) r.q[y] = *(const GLB u64u *)(ref + a + y * stride);
     r.q[4] = 0;
-    if (hy) r.q[4] = *(const GLB u64u *)(ref + clampi(a + 4 * stride, 0, amax8));   /* 5th row only for vertical half samples */
+    if (hy) r.q[4] = *(const GLB u64u *)(ref + a + 4 * stride);   /* 5th row only for vertical half samples */
     return r;
 }
 
@@ -104,20 +98,19 @@ __device__ __forceinline__ Blk mc_filter(const McRows &rows, int hx, int hy)
     const uint64_t *q = rows.q;
     Blk o;
     if (hx & hy) {
-        /* (a+b+c+d+2)>>2 exactly: two 16-bit lanes per dword, even and odd bytes */
-        const u32 M = 0x00FF00FFu;
-        u32 he[5], ho[5];
+        /* (a+b+c+d+2)>>2 exactly, four samples per instruction: with h = floor((a+b)/2), v = floor((c+d)/2) (v_lerp_u8,
+         * no rounding bit) the result is (h+v+1)>>1, plus one when both pair sums were odd and h+v is even */
+        u32 h[5], x[5];
 #pragma unroll
         for (int y = 0; y < 5; ++y) {
-            u32 p = (u32)q[y], n = (u32)(q[y] >> 8);
-            he[y] = (p & M) + (n & M);
-            ho[y] = ((p >> 8) & M) + ((n >> 8) & M);
+            const u32 p = (u32)q[y], n = (u32)(q[y] >> 8);
+            h[y] = __builtin_amdgcn_lerp(p, n, 0u);
+            x[y] = p ^ n;
         }
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
-            u32 e = ((he[y] + he[y + 1] + 0x00020002u) >> 2) & M;
-            u32 d = ((ho[y] + ho[y + 1] + 0x00020002u) >> 2) & M;
-            o.r[y] = e | (d << 8);
+            const u32 t = __builtin_amdgcn_lerp(h[y], h[y + 1], 0x01010101u);
+            o.r[y] = t + (x[y] & x[y + 1] & ~(h[y] ^ h[y + 1]) & 0x01010101u);
         }
     } else {
         /* copy, horizontal or vertical 2-tap: v_lerp_u8 of the row with itself is the identity, so the three cases
@@ -132,9 +125,10 @@ __device__ __forceinline__ Blk mc_filter(const McRows &rows, int hx, int hy)
     return o;
 }
 
-__device__ __forceinline__ Blk mc_block(const GLB uint8_t *ref, i32 a, i32 stride, int hx, int hy, i32 amax8)
+/* `a` is already clamped so that every row read stays inside the picture slot */
+__device__ __forceinline__ Blk mc_block(const GLB uint8_t *ref, i32 a, i32 stride, int hx, int hy)
 {
-    return mc_filter(mc_load(ref, a, stride, hy, amax8), hx, hy);
+    return mc_filter(mc_load(ref, a, stride, hy), hx, hy);
 }
 
 /* exact floor(num / den) for num <= 4096, den <= 511 (0 -> 0): v_rcp_f32 estimate, integer fix-up.
@@ -167,28 +161,26 @@ __device__ __forceinline__ u32 pack4(i32 a, i32 b, i32 c, i32 d)
 
 /*
  * AOT arithmetic (h4m:679-817).  reference: factor = (sum + off) * (+-divTable[max-min]);
- * acc[i] += factor * e[i] (uint32 wrap).  divTable[r] = 16 * (256 / r), so factor = 16 * s * q.
- * With <= 15 bases per block s < 2^14 and q <= 256: g = +-s*q fits 24 bits and sum_k g_k * e_ki < 2^31
- * never wraps, so products are full-rate 24-bit multiplies and the wrap-exact value is (sum << 4).
- * BIG (I-luma type byte > 15, never produced by real encoders) keeps generic 32-bit wrap arithmetic.
+ * acc[i] += factor * e[i] (uint32 wrap).  divTable[r] = 16 * (256 / r).  Everything is done in the reference's own
+ * uint32 wrap arithmetic: v_mul_lo_u32 issues at the same rate as the 24-bit multiplies on gfx950
+ * (profiles/r02c_ubench_valu_rate.txt), so there is no separate path for blocks with more than 15 bases.
  * The host stores the running coefficient sum in every basis dword, so bases are independent and are
  * processed one per lane; their products meet in LDS with ds_add_u32.
  */
-__device__ __forceinline__ i32 basis_gain(u32 d, u32 lo, u32 hi, bool big)
+__device__ __forceinline__ u32 basis_gain(u32 d, u32 lo, u32 hi)
 {
     const u32 q = udiv_small(256u, (hi - lo) & 15u);
     const u32 s = d >> 14;
-    i32 g = big ? (i32)(s * (q << 4)) : (i32)__umul24(s, q);
-    return (d & 0x2000u) ? -g : g;
+    const u32 g = s * (q << 4);
+    return (d & 0x2000u) ? 0u - g : g;
 }
 
-__device__ __forceinline__ void basis_scatter(i32 g, const u32 e[16], bool big, i32 *acc_lds, u32 stride)
+template <int STRIDE>
+__device__ __forceinline__ void basis_scatter(u32 g, const u32 e[16], u32 *acc_lds)
 {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const i32 t = big ? (i32)((u32)g * e[i]) : __mul24(g, (i32)e[i]);
-        __hip_atomic_fetch_add(acc_lds + i * stride, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    for (int i = 0; i < 16; ++i)
+        __hip_atomic_fetch_add(acc_lds + i * STRIDE, g * e[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 /* nest gather for one basis, intra (h4m:713-725).  The LDS nest holds two 4-bit values per byte at the
@@ -233,8 +225,9 @@ __device__ __forceinline__ void gather_window(u32 d, bool landscape, const GLB u
     else           { o = lw * ol + os; x2 = ss; ys = lw << sl; }
     const u32 sel = x2 ? 0x06040200u : 0x03020100u;                 /* stride 2: bytes 0,2,4,6 */
     uint64_t q[4];
+    const i32 base = clampi(origin + o, 0, slot - 8 - 3 * ys);      /* one clamp: legal windows lie inside the slot */
 #pragma unroll
-    for (int y = 0; y < 4; ++y) q[y] = *(const GLB u64u *)(ref + clampi(origin + o + y * ys, 0, slot - 8));
+    for (int y = 0; y < 4; ++y) q[y] = *(const GLB u64u *)(ref + base + y * ys);
     lo = 255; hi = 0;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
@@ -291,7 +284,6 @@ __device__ __forceinline__ Blk predi_finish(const u32 r[16], Blk m, u32 p0, u32 
     const i32 gain = (i32)p1;
     const u32 mcd = udiv_small(0x1000u, hi - lo);                    /* mcdivTable[max-min], h4m:272, 1407 */
     const u32 factor = (u32)gain * mcd;
-    const bool small = gain > -2048 && gain < 2048;                  /* |factor| < 2^23: 24-bit multiply is exact */
     Blk o4;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
@@ -299,7 +291,7 @@ __device__ __forceinline__ Blk predi_finish(const u32 r[16], Blk m, u32 p0, u32 
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const int i = 4 * y + x;
-            u32 t = small ? (u32)__mul24(px[i] - mean, (i32)factor) : (u32)(px[i] - mean) * factor;
+            const u32 t = (u32)(px[i] - mean) * factor;
             v[x] = sar(r[i] + addend + t, unk) + px[i];
         }
         o4.r[y] = pack4(v[0], v[1], v[2], v[3]);
@@ -383,9 +375,14 @@ void hvq_tilegen_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__res
         r.plane_off = P.plane_off; r.slot_bytes = J->slot_bytes;
         r.flags = (J->flags & 0xFFFFu) | ((u32)J->pic_kind << HVQ_TR_KIND_SHIFT) | ((u32)J->unk_shift << HVQ_TR_UNK_SHIFT) |
                   ((u32)p << HVQ_TR_PLANE_SHIFT);
-        r.hb = P.hb; r.vb = P.vb; r.pw = P.pw; r.lw = J->width; r.mcb_w = (uint16_t)J->mcb_w;
-        r.ws = P.ws; r.hs = P.hs;
+        r.hb = P.hb;
+        r.pw_lw = (u32)P.pw | ((u32)J->width << 16);
+        r.mcbw_sub = (J->mcb_w & 0xFFFFu) | ((u32)P.ws << 16) | ((u32)P.hs << 24);
         r.rhb = 1.0f / (float)P.hb;
+        for (int w = 0; w < HVQ_NW; ++w) {
+            const u32 bw = r.b0 + 64u * (u32)w;
+            r.wxy[w] = (bw % P.hb) | ((bw / P.hb) << 16);
+        }
     }
     recs[i] = r;
 }
@@ -398,158 +395,139 @@ extern "C" hipError_t hvq_launch_tilegen(const HvqJob *jobs_dev, const HvqTileRe
     return hipGetLastError();
 }
 
+/* block classes by type byte (hvq_type_class): one load replaces ~25 compare/select instructions per lane */
+__device__ u32 g_type_class[3 * 256];
+
+extern "C" hipError_t hvq_upload_tables(void)
+{
+    u32 t[3 * 256];
+    for (int ctx = 0; ctx < 3; ++ctx)
+        for (u32 ty = 0; ty < 256; ++ty) t[ctx * 256 + ty] = hvq_type_class(ty, ctx);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_type_class), t, sizeof t);
+}
+
 /* ------------------------------------------------------------------------------------------------------
  * Reconstruction.
  *
- * Workgroup = tile of 256 consecutive blocks of one plane; wave = 64 of them; lane = one block.
- * What bounds this kernel is the depth of its chain of dependent memory round trips (each ~1.7k cycles under load,
- * profiles/r02a_stamps.txt), so it is built as three levels with everything inside a level issued at once:
- *   level 0   one scalar load of the tile record;
- *   level 1   own map entry + four neighbours + macroblock vector per lane, and -- cooperatively -- the tile's whole
- *             payload (contiguous in the pool) and the nest into LDS;
- *   level 2   the gathers that depend on them: motion-compensation source rows, MC-residual window rows.
- * After the one barrier that publishes payload and nest, every wave works on its own 64 blocks without meeting the
- * others again:
- *   cheap kinds (flat, weighted DC, literal, plain MC) are reconstructed by the owning lane into the LDS tile;
- *   AOT blocks are queued PER WAVE, at most HVQ_CHUNK at a time, counting-sorted by (class, number of bases) with one
- *   returning LDS add per item; every (item, basis) pair becomes one lane's work (the serial basis loop of h4m:782-788
- *   turns into one parallel step), laid out basis-major -- pair (k, r) of the r-th item in sorted order sits at
- *   seg[k] + r -- so that the 64 lanes of one ds_add hit 64 different items = consecutive banks: no same-address
- *   serialisation and no bank conflict (item-major order made the 1..15 lanes of one item add to the same 16 words);
- *   the item's lane then turns the accumulators into samples (h4m:1367-1376 / 1385-1419);
- *   the wave's 64 blocks leave LDS as 16-byte row segments: one store instruction writes four complete 256-byte runs.
- * LDS traffic inside a wave needs no barrier: a wave's LDS instructions execute in order.
+ * What bounds this kernel is VALU issue (profiles/r02b, r02c: ~700 vector instructions per wave at 4.2-4.7 clocks
+ * each keep a SIMD with 8 waves busy for ~85 % of a wave's lifetime; removing memory round trips and barriers did
+ * not shorten it), so the structure is chosen for the fewest vector instructions per block and the fullest lanes:
+ *
+ * Workgroup = tile of 256 consecutive blocks of one plane.
+ *   phase A   every lane owns one block: one scalar load brings the tile record; descriptors are fetched with
+ *             independent loads (own map entry, four neighbours, macroblock vector); the block's class comes from a
+ *             256-entry table; cheap kinds (flat, weighted-DC, literal, plain MC) and the MC part of MC-residual
+ *             blocks are reconstructed at once into the LDS tile; AOT blocks are queued for the WHOLE workgroup
+ *             (intra items first, then MC-residual items; entries carry what the owner fetched) and every basis of
+ *             every queued block becomes one (item, basis) pair.
+ *   phase B1  one lane per PAIR, pooled over the workgroup: nest gather, min/max, gain, 16 products -> ds_add into
+ *             the item's accumulators.  The serial per-block basis loop of the reference (h4m:782-788) becomes one
+ *             parallel step; lane utilisation is independent of how basis counts are distributed.
+ *   phase B2  one lane per queued block: accumulators -> samples (h4m:1367-1376 / 1385-1419).
+ *   phase C   the finished tile leaves LDS as 16-byte row segments: one store instruction of a wave
+ *             writes four complete 256-byte runs of the destination plane (full lines, written once).
+ * ITEMS_CAP = accumulator rows per launch (the most queued blocks of any tile of the launch, rounded up): a compile-time
+ * stride puts every accumulator address into the instruction's offset field.
  */
-#define HVQ_POOL_LDS 640            /* payload dwords of a tile staged in LDS; larger tiles read the pool from HBM */
-#define HVQ_CHUNK    32             /* queued blocks accumulated at a time per wave */
-#define HVQ_PAIRWIN  128            /* (item, basis) pairs listed at a time per wave */
-
-struct WaveLds {
-    i32 acc[16 * HVQ_CHUNK];        /* [sample][item slot] */
-    u32 pair[HVQ_PAIRWIN];          /* item slot | payload index of the basis << 5 */
-    u32 hist[32];                   /* items per (class, bases) bin; then pair segment starts per (class, basis k) */
-    u32 item[HVQ_CHUNK];            /* owner lane | map entry {value, type} << 8 */
-    u32 imv[HVQ_CHUNK];             /* the owner's macroblock vector */
-    u32 ioff[HVQ_CHUNK];            /* the owner's payload index */
-};
-
-/* compiler-level ordering of LDS accesses between lanes of ONE wave (the hardware executes them in order) */
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-
+template <int ITEMS_CAP>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
-void hvq_recon_kernel(const HvqTileRec *__restrict__ recs HVQ_STAMP_ARG)
+void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAMP_ARG)
 {
-    __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];                  /* [sample row][block] packed dwords */
-    __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 16];  /* nest, two 4-bit values per byte */
-    __shared__ __attribute__((aligned(16))) u32 s_pool[HVQ_POOL_LDS];
-    __shared__ __attribute__((aligned(16))) WaveLds s_w[HVQ_NW];
+    extern __shared__ __attribute__((aligned(16))) u32 s_pair[];      /* item | payload index of the basis << 9, [pair_cap] */
+    __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];   /* nest packed two 4-bit values per byte */
+    __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];   /* [sample row][block] packed dwords */
+    __shared__ __attribute__((aligned(16))) u32 s_acc[16 * ITEMS_CAP];   /* AOT accumulators, [sample][queued block]: lanes of
+                                              one ds_add hit consecutive banks (a [block][16] layout is a 32-way conflict) */
+    constexpr u32 items_cap = ITEMS_CAP;
+    __shared__ u32 s_item0[HVQ_WG];    /* owner lane | payload offset << 10 */
+    __shared__ u32 s_item1[HVQ_WG];    /* map entry {value, type} */
+    __shared__ u32 s_item2[HVQ_WG];    /* macroblock vector */
+    __shared__ u32 s_cnt[HVQ_NW][3];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     STAMP(0, 0);
-    /* ---- level 0: the tile record ---- */
+    /* ---- the tile record: one scalar load ---- */
     const HvqTileRec *__restrict__ R = recs + blockIdx.x;
-    const i32 hb = R->hb;
+    const i32 hb = (i32)R->hb;
     if (hb == 0) return;                                  /* padding entry of the XCD-dealt table (uniform exit) */
     const u32 flags = R->flags;
     const u32 pic_kind = (flags >> HVQ_TR_KIND_SHIFT) & 3u;
     const i32 unk = (i32)((flags >> HVQ_TR_UNK_SHIFT) & 31u);
     const int plane_id = (int)(flags >> HVQ_TR_PLANE_SHIFT);
     const bool is_pb = pic_kind != HVQ_PIC_I;
-    const bool I_luma = !is_pb && plane_id == 0;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
-    const bool big = flags & HVQ_F_BIG_AOT;
-    const float rhb = R->rhb;
     const u32 nblocks = R->nblocks;
     const u32 b0 = R->b0;
-    const i32 ws = R->ws, hs = R->hs;
-    const i32 pw = R->pw;
+    const u32 mcbw_sub = R->mcbw_sub, pw_lw = R->pw_lw;
+    const i32 ws = (i32)((mcbw_sub >> 16) & 0xFFu), hs = (i32)(mcbw_sub >> 24);
+    const i32 pw = (i32)(pw_lw & 0xFFFFu);
     const i32 mstride = hb + 2;
     const GLB uint8_t *map = (const GLB uint8_t *)R->map;
-    const GLB u32 *__restrict__ gpool = (const GLB u32 *)R->pool;
+    const GLB u32 *__restrict__ pool = (const GLB u32 *)R->pool;          /* the tile's payload */
     const GLB u32 *__restrict__ mvs = (const GLB u32 *)R->mv;
-    const GLB u32 *__restrict__ gnest = (const GLB u32 *)R->nest;
     const GLB uint8_t *ref0 = (const GLB uint8_t *)R->ref0, *ref1 = (const GLB uint8_t *)R->ref1;
     const i32 plane_off = (i32)R->plane_off;
     GLB uint8_t *plane = (GLB uint8_t *)R->dst;
     const i32 slot = (i32)R->slot_bytes;
-    const i32 mcb_w = (i32)R->mcb_w;
-    const i32 lw = R->lw;
-    const u32 pool_dwords = R->pool_dwords;
-    const bool pool_lds = pool_dwords <= HVQ_POOL_LDS;
-    const bool need_nest = (flags & HVQ_F_HAS_NEST) && gnest;
+    const i32 mcb_w = (i32)(mcbw_sub & 0xFFFFu);
+    const i32 lw = (i32)(pw_lw >> 16);
+    const GLB u32 *__restrict__ tclass = (const GLB u32 *)g_type_class + (is_pb ? 512 : plane_id == 0 ? 0 : 256);
     STAMP(1, 0);
 
-    /* ---- level 1: own descriptors per lane; payload and nest for the workgroup ---- */
+    /* ---- phase A: own block ---- */
     const u32 b = b0 + (u32)tid;
     const bool valid = b < nblocks;
     i32 bx, by;
-    block_coords(valid ? b : 0u, hb, rhb, bx, by);
+    if (hb >= 64) {
+        /* the wave's first block comes with the record; a run of 64 blocks wraps at most once */
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        const u32 wxy = uw == 0 ? R->wxy[0] : uw == 1 ? R->wxy[1] : uw == 2 ? R->wxy[2] : R->wxy[3];
+        bx = (i32)(wxy & 0xFFFFu) + lane; by = (i32)(wxy >> 16);
+        const bool wrap = bx >= hb;
+        bx -= wrap ? hb : 0; by += wrap ? 1 : 0;
+    } else {
+        block_coords(b, hb, R->rhb, bx, by);
+    }
+    if (!valid) { bx = 0; by = 0; }
     const GLB uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
+    /* independent loads first: own entry, four neighbours, vector */
     const u32 e16 = *(const GLB uint16_t *)ent;
     const u32 nt = *(const GLB uint16_t *)(ent - 2 * mstride), nbt = *(const GLB uint16_t *)(ent + 2 * mstride);
     const u32 nl = *(const GLB uint16_t *)(ent - 2), nr = *(const GLB uint16_t *)(ent + 2);
     u32 mvw = 0;
     if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
-    u32 pq[(HVQ_POOL_LDS + HVQ_WG - 1) / HVQ_WG];
-    if (pool_lds) {
-#pragma unroll
-        for (int j = 0; j < (HVQ_POOL_LDS + HVQ_WG - 1) / HVQ_WG; ++j) {
-            pq[j] = 0;
-            if ((u32)tid + HVQ_WG * j < pool_dwords) pq[j] = gpool[tid + HVQ_WG * j];
-        }
-    }
-    u32 nq0 = 0, nq1 = 0;
-    if (need_nest) {
-        nq0 = gnest[tid];
-        if (tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4) nq1 = gnest[tid + HVQ_WG];
-    }
 
     const i32 V = e16 & 0xFF;
-    const u32 T = valid ? (e16 >> 8) : 0u;
-    const bool inter = is_pb && (T & 0x60u);
-    const u32 kind = I_luma ? T : (T & 0xFu);
-    const u32 npay = valid ? hvq_payload_dwords(T, is_pb, I_luma) : 0u;
-    /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual; nb = bases (selects only) */
-    const bool aot_kind = kind != 0 && kind != 6;
-    const bool c1 = valid && !inter && aot_kind && kind != 8;
-    const bool c2 = valid && inter && !(T & 0x10u) && aot_kind;
-    const int cls = c1 ? 1 : c2 ? 2 : 0;
-    const u32 nb = c1 ? kind : c2 ? kind - 1u : 0u;
-    /* payload index inside the tile: the wave's base from the record + prefix sum over the wave */
-    u32 off = wave == 0 ? 0u : wave == 1 ? R->wrel[0] : wave == 2 ? R->wrel[1] : R->wrel[2];
-    if (__ballot(npay != 0)) off += wave_incl_scan(npay) - npay;
+    const u32 T = e16 >> 8;
+    u32 tc = tclass[T];
+    if (!valid) tc = 0;
+    const u32 npay = HVQ_TC_NPAY(tc);
+    /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual; nb = bases */
+    const u32 cls = HVQ_TC_CLS(tc);
+    const u32 nb = HVQ_TC_NB(tc);
+    /* payload offset / pair slot: prefix sums over the wave, skipped when the wave carries no payload at all */
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    u32 off = uwave == 0 ? 0u : uwave == 1 ? R->wrel[0] : uwave == 2 ? R->wrel[1] : R->wrel[2], pincl = 0;
+    if (__ballot(npay != 0)) { off += wave_incl_scan(npay) - npay; pincl = wave_incl_scan(nb); }
+    const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+    if (lane == 63) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = pincl; }
     STAMP(2, 1);
 
-    if (pool_lds) {
-#pragma unroll
-        for (int j = 0; j < (HVQ_POOL_LDS + HVQ_WG - 1) / HVQ_WG; ++j)
-            if (tid + HVQ_WG * j < HVQ_POOL_LDS) s_pool[tid + HVQ_WG * j] = pq[j];
-    }
-    if (need_nest) {
-        ((u32 *)s_nest)[tid] = nq0;
-        if (tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
-    }
-    __syncthreads();                                    /* the only workgroup barrier: payload + nest published */
-    STAMP(3, 0);
-
-    /* ---- level 2a: motion-compensation rows of the own block go out first ... ---- */
-    const bool needs_mc = valid && inter && (cls == 2 || (T & 0x10u) || kind == 0);
-    McRows rows;
-    int hx = 0, hy = 0;
-    if (needs_mc) {
-        const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-        const GLB uint8_t *ref = (((T >> 5) & 3u) == 1u) ? ref0 : ref1;
-        const i32 pdx = rx >> ws, pdy = ry >> hs;
-        hx = is15 ? (pdx & 1) : (rx & 1); hy = is15 ? (pdy & 1) : (ry & 1);              /* h4m:1337-1343 */
-        const i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
-        rows = mc_load(ref, a, pw, hy, slot - 8);
-    }
-    /* ---- ... while the kinds that need nothing else are finished ---- */
-    if (valid && !needs_mc && cls == 0) {
+    if (valid && cls != 1) {
         Blk o;
-        if (!inter && kind == 0) {
+        if (tc & HVQ_TC_MC) {
+            /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
+            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+            const GLB uint8_t *ref = (((T >> 5) & 3u) == 1u) ? ref0 : ref1;
+            const i32 pdx = rx >> ws, pdy = ry >> hs;
+            const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
+            i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+            /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
+            a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
+            o = mc_block(ref, a, pw, hx, hy);
+        } else if (tc & HVQ_TC_WDC) {
             /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
              * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
             i32 Tt = (nt & 0x7700u) ? V : (i32)(nt & 0xFF);
@@ -562,147 +540,146 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs HVQ_STAMP_ARG)
             /* flat DC (h4m:281-286) or literal (h4m:543-549) */
             const u32 v = (u32)V * 0x01010101u;
             o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
-            if (kind == 6) {
-                if (pool_lds) { o.r[0] = s_pool[off]; o.r[1] = s_pool[off + 1]; o.r[2] = s_pool[off + 2]; o.r[3] = s_pool[off + 3]; }
-                else { o.r[0] = gpool[off]; o.r[1] = gpool[off + 1]; o.r[2] = gpool[off + 2]; o.r[3] = gpool[off + 3]; }
-            }
+            if (tc & HVQ_TC_LIT) { const GLB u32 *pay = pool + off; o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3]; }
         }
 #pragma unroll
         for (int y = 0; y < 4; ++y) s_out[y][tid] = o.r[y];
     }
+    STAMP(3, 1);
+
+    __syncthreads();                                                           /* barrier 1: queue counts */
     STAMP(4, 0);
-    if (needs_mc) {
-        const Blk o = mc_filter(rows, hx, hy);          /* plain MC, and the MC part of MC-residual blocks */
+    u32 nI = 0, nP = 0, myI = 0, myP = 0, npairs = 0, pbefore = 0;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) s_out[y][tid] = o.r[y];
+    for (int w = 0; w < HVQ_NW; ++w) {
+        const u32 ci = s_cnt[w][0], cp = s_cnt[w][1], cb = s_cnt[w][2];
+        if (w < wave) { myI += ci; myP += cp; pbefore += cb; }
+        nI += ci; nP += cp; npairs += cb;
     }
-    STAMP(5, 0);
-
-    /* ---- AOT blocks of this wave, HVQ_CHUNK at a time ---- */
-    const unsigned long long imask = __ballot(cls != 0);
-    const u32 nitems = (u32)__popcll(imask);
-    if (nitems) {
-        WaveLds &W = s_w[wave];
-        const u32 idx = lanes_below(imask);
-        for (u32 c0 = 0; c0 < nitems; c0 += HVQ_CHUNK) {
-            const bool act = cls != 0 && idx - c0 < (u32)HVQ_CHUNK;
-            const u32 nchunk = min(nitems - c0, (u32)HVQ_CHUNK);
-            /* counting sort by (class, bases descending): bin = class-2 flag * 16 + 15 - min(bases, 15) */
-            if (lane < 32) W.hist[lane] = 0;
+    const u32 total = nI + nP;
+    const bool parallel = npairs <= pair_cap && total <= items_cap;
+    if (total && parallel) {
+        /* 16 * items_cap dwords, items_cap a multiple of 32: 16-byte stores */
+        typedef u32 u32x4z __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int j = 0; j < 16 * HVQ_CHUNK / 64; ++j) W.acc[lane + 64 * j] = 0;
-            WAVE_SYNC();
-            const u32 bin = (cls == 2 ? 16u : 0u) + 15u - min(nb, 15u);
-            u32 rank = 0;
-            if (act) rank = __hip_atomic_fetch_add(&W.hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            WAVE_SYNC();
-            const u32 hcount = W.hist[lane & 31];
-            WAVE_SYNC();
-            const u32 hincl = wave_incl_scan(lane < 32 ? hcount : 0u);
-            const u32 hexcl = hincl - (lane < 32 ? hcount : 0u);                  /* lane j < 32: items in bins below j */
-            const u32 n1 = (u32)__builtin_amdgcn_readlane((int)hexcl, 16);        /* class-1 items of the chunk */
-            /* items of class c with more than k bases: E[c*16 + 15 - k] - E[c*16]; lane c*16 + k holds it */
-            const int cbase = lane & 16, kk = lane & 15;
-            const u32 e_hi = (u32)__builtin_amdgcn_ds_bpermute(4 * (cbase + 15 - kk), (int)hexcl);
-            const u32 e_lo = (u32)__builtin_amdgcn_ds_bpermute(4 * cbase, (int)hexcl);
-            const u32 cnt = lane < 32 ? e_hi - e_lo : 0u;
-            /* pair segment starts: exclusive prefix of cnt over k inside each class (a DPP row = 16 lanes), class 2 after class 1 */
-            u32 segi = cnt;
-            segi += (u32)__builtin_amdgcn_update_dpp(0, (int)segi, 0x111, 0xF, 0xF, false);
-            segi += (u32)__builtin_amdgcn_update_dpp(0, (int)segi, 0x112, 0xF, 0xF, false);
-            segi += (u32)__builtin_amdgcn_update_dpp(0, (int)segi, 0x114, 0xF, 0xF, false);
-            segi += (u32)__builtin_amdgcn_update_dpp(0, (int)segi, 0x118, 0xF, 0xF, false);
-            const u32 P1 = (u32)__builtin_amdgcn_readlane((int)segi, 15), P2 = (u32)__builtin_amdgcn_readlane((int)segi, 31);
-            u32 npairs = P1 + P2;
-            /* slot in sorted order (every lane takes part in the cross-lane read: a disabled source lane would read as 0) */
-            const u32 slotq = (u32)__builtin_amdgcn_ds_bpermute(4 * (int)bin, (int)hexcl) + rank;
-            u32 pstart = 0;
-            if (!big) {
-                if (lane < 32) W.hist[lane] = segi - cnt + (lane >= 16 ? P1 : 0u);
-            } else {
-                /* more than 15 bases per block possible (I-luma type bytes > 15, never produced by real encoders): the
-                 * prefix property of the sorted order does not hold beyond k = 15, pairs are listed item-major */
-                const u32 nbm = act ? nb : 0u;
-                const u32 pin = wave_incl_scan(nbm);
-                pstart = pin - nbm;
-                npairs = (u32)__builtin_amdgcn_readlane((int)pin, 63);
-            }
-            if (act) {
-                W.item[slotq] = (u32)lane | (e16 << 8);
-                W.imv[slotq] = mvw;
-                W.ioff[slotq] = off;
-            }
-            WAVE_SYNC();
-            const u32 rcls = slotq - (cls == 2 ? n1 : 0u);                        /* rank inside the class */
-            const u32 bidx = off + (cls == 2 ? 2u : 0u);
-            for (u32 w0 = 0; w0 < npairs; w0 += HVQ_PAIRWIN) {
-                if (act) {
-                    for (u32 k = 0; k < nb; ++k) {
-                        const u32 pos = (big ? pstart + k : W.hist[(cls == 2 ? 16u : 0u) + k] + rcls) - w0;
-                        if (pos < (u32)HVQ_PAIRWIN) W.pair[pos] = slotq | ((bidx + k) << 5);
-                    }
-                }
-                WAVE_SYNC();
-                const u32 wn = min(npairs - w0, (u32)HVQ_PAIRWIN);
-                /* ---- one lane per (item, basis) pair ---- */
-                for (u32 pi = (u32)lane; pi < wn; pi += 64) {
-                    const u32 pr = W.pair[pi];
-                    const u32 it = pr & 31u;
-                    const u32 d = pool_lds ? s_pool[pr >> 5] : gpool[pr >> 5];
-                    u32 e[16], lo, hi;
-                    if (it < n1) {
-                        gather_nest(d, landscape, s_nest, e, lo, hi);
-                    } else {
-                        const u32 t16 = W.item[it] >> 8, mv = W.imv[it];
-                        const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
-                        const GLB uint8_t *ref = ((t16 >> 13) & 3u) == 1u ? ref0 : ref1;
-                        const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
-                        gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
-                    }
-                    basis_scatter(basis_gain(d, lo, hi, big), e, big, W.acc + it, HVQ_CHUNK);
-                }
-                WAVE_SYNC();
-            }
-            /* ---- one lane per queued block: accumulators -> samples ---- */
-            if ((u32)lane < nchunk) {
-                const u32 info = W.item[lane];
-                const u32 owner = (u32)(wave * 64) + (info & 63u);
-                const u32 q16 = info >> 8;
-                u32 r[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) r[i] = (u32)W.acc[i * HVQ_CHUNK + lane];
-                if (!big) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) r[i] <<= 4;
-                }
-                Blk o;
-                if ((u32)lane >= n1) {
-                    const u32 po = W.ioff[lane];
-                    const u32 p0 = pool_lds ? s_pool[po] : gpool[po], p1 = pool_lds ? s_pool[po + 1] : gpool[po + 1];
-                    Blk m;                                       /* the owner left the MC block in the tile */
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) m.r[y] = s_out[y][owner];
-                    o = predi_finish(r, m, p0, p1, unk);
-                } else {
-                    o = intra_finish(r, (i32)(q16 & 0xFF), unk);
-                }
-#pragma unroll
-                for (int y = 0; y < 4; ++y) s_out[y][owner] = o.r[y];
-            }
-            WAVE_SYNC();
+        for (u32 i = (u32)tid; i < 4u * items_cap; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
+    }
+    if (cls) {
+        const u32 slotq = cls == 1 ? myI + lanes_below(m1) : nI + myP + lanes_below(m2);
+        s_item0[slotq] = (u32)tid | (off << 10);
+        s_item1[slotq] = e16;
+        s_item2[slotq] = mvw;
+        if (parallel) {
+            const u32 pstart = pbefore + pincl - nb, bidx = off + (cls == 2 ? 2u : 0u);
+            u32 ent = slotq | (bidx << 9);
+            u32 *dst = s_pair + pstart;
+#pragma clang loop unroll(disable) vectorize(disable)
+            for (u32 k = 0; k < nb; ++k, ent += 1u << 9) dst[k] = ent;            /* 1..15 entries: keep the loop as written */
         }
     }
-    STAMP(6, 1);
-    WAVE_SYNC();
+    if (nI) {
+        const GLB u32 *src = (const GLB u32 *)R->nest;                /* already nibble-packed by the host */
+        const bool second = tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4;
+        const u32 n0 = src[tid], n1 = second ? src[tid + HVQ_WG] : 0u;               /* both loads in flight together */
+        ((u32 *)s_nest)[tid] = n0;
+        if (second) ((u32 *)s_nest)[tid + HVQ_WG] = n1;
+    }
+    STAMP(5, 1);
+    if (total) __syncthreads();                                                /* barrier 2: queue + nest staged */
+    STAMP(6, 0);
 
-    /* ---- the wave's 64 blocks -> HBM ---- */
+    if (total) {
+        const bool has_item = (u32)tid < total;
+        const bool item_mc = has_item && (u32)tid >= nI;
+        u32 owner = 0, q16 = 0, p0 = 0, p1 = 0;
+        const GLB u32 *__restrict__ qpay = pool;
+        if (has_item) {
+            const u32 item = s_item0[tid];
+            owner = item & 1023u;
+            qpay = pool + (item >> 10);
+            q16 = s_item1[tid];
+        }
+        if (item_mc) { p0 = qpay[0]; p1 = qpay[1]; }          /* in flight while phase B1 runs */
+
+        u32 r[16];
+        if (parallel) {
+            /* ---- phase B1: one lane per (item, basis) pair ---- */
+            for (u32 pi = (u32)tid; pi < npairs; pi += HVQ_WG) {
+                const u32 pr = s_pair[pi];
+                const u32 it = pr & 511u;
+                const u32 d = pool[pr >> 9];
+                u32 e[16], lo, hi;
+                if (it < nI) {
+                    gather_nest(d, landscape, s_nest, e, lo, hi);
+                } else {
+                    const u32 t16 = s_item1[it], mv = s_item2[it];
+                    const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
+                    const GLB uint8_t *ref = ((t16 >> 13) & 3u) == 1u ? ref0 : ref1;
+                    const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
+                    gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
+                }
+                basis_scatter<ITEMS_CAP>(basis_gain(d, lo, hi), e, s_acc + it);
+            }
+            STAMP(7, 1);
+            __syncthreads();                                                   /* barrier 3: accumulators complete */
+            STAMP(8, 0);
+            if (has_item) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) r[i] = s_acc[i * ITEMS_CAP + tid];
+            }
+        } else if (has_item) {
+            /* serial fallback for tiles whose queue exceeds the launch's LDS sizing (pathological streams) */
+            u32 acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0;
+            const bool intra_item = (u32)tid < nI;
+            const u32 n = HVQ_TC_NB(tclass[q16 >> 8]);
+            const GLB u32 *bases = qpay + (intra_item ? 0 : 2);
+            const u32 mv = s_item2[tid];
+            const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
+            const GLB uint8_t *ref = ((q16 >> 13) & 3u) == 1u ? ref0 : ref1;
+            const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
+            for (u32 k = 0; k < n; ++k) {
+                const u32 d = bases[k];
+                u32 e[16], lo, hi;
+                if (intra_item) gather_nest(d, landscape, s_nest, e, lo, hi);
+                else gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
+                const u32 g = basis_gain(d, lo, hi);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += g * e[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i] = acc[i];
+        }
+
+        /* ---- phase B2: one lane per queued block ---- */
+        if (has_item) {
+            Blk o;
+            if (item_mc) {
+                Blk m;                                       /* the owner left the MC block in the tile */
+#pragma unroll
+                for (int y = 0; y < 4; ++y) m.r[y] = s_out[y][owner];
+                o = predi_finish(r, m, p0, p1, unk);
+            } else {
+                o = intra_finish(r, (i32)(q16 & 0xFF), unk);
+            }
+#pragma unroll
+            for (int y = 0; y < 4; ++y) s_out[y][owner] = o.r[y];
+        }
+        STAMP(9, 1);
+        __syncthreads();                                                       /* barrier 4: tile complete in LDS */
+        STAMP(10, 0);
+    }
+
+    /* ---- phase C: tile -> HBM ---- */
+    STAMP(11, 0);
     if ((hb & 3) == 0) {
         /* lane (g, r): sample row r of blocks 4g..4g+3 = 16 contiguous bytes of the plane */
         const int g = wave * 16 + (lane & 15), rr = lane >> 4;
         const u32 gb = b0 + 4u * (u32)g;
         if (gb < nblocks) {
             i32 gx, gy;
-            block_coords(gb, hb, rhb, gx, gy);
+            block_coords(gb, hb, R->rhb, gx, gy);
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = *(const u32x4 *)&s_out[rr][4 * g];
             /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors
@@ -715,18 +692,32 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs HVQ_STAMP_ARG)
 #pragma unroll
         for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[y][tid];
     }
-    STAMP(7, 0);
-    STAMP(8, 1);
+    STAMP(12, 0);
+    STAMP(13, 1);
 }
 
-extern "C" hipError_t hvq_launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, hipStream_t stream)
+template <int ITEMS_CAP>
+static void launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, uint32_t pair_cap, hipStream_t stream)
+{
+#ifdef HVQ_STAMPS
+    hipLaunchKernelGGL(hvq_recon_kernel<ITEMS_CAP>, dim3(ntiles), dim3(HVQ_WG), 4u * pair_cap, stream, recs_dev, pair_cap, g_stamps);
+#else
+    hipLaunchKernelGGL(hvq_recon_kernel<ITEMS_CAP>, dim3(ntiles), dim3(HVQ_WG), 4u * pair_cap, stream, recs_dev, pair_cap);
+#endif
+}
+
+/* items_cap: the most queued blocks of any tile of the launch; it selects the instantiation with the next larger
+ * accumulator array (tiles beyond 256 queued blocks cannot exist: a tile has 256 blocks) */
+extern "C" hipError_t hvq_launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, uint32_t items_cap, uint32_t pair_cap,
+                                       hipStream_t stream)
 {
     if (ntiles == 0) return hipSuccess;
-#ifdef HVQ_STAMPS
-    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), 0, stream, recs_dev, g_stamps);
-#else
-    hipLaunchKernelGGL(hvq_recon_kernel, dim3(ntiles), dim3(HVQ_WG), 0, stream, recs_dev);
-#endif
+    if (items_cap <= 32) launch_recon<32>(recs_dev, ntiles, pair_cap, stream);
+    else if (items_cap <= 64) launch_recon<64>(recs_dev, ntiles, pair_cap, stream);
+    else if (items_cap <= 96) launch_recon<96>(recs_dev, ntiles, pair_cap, stream);
+    else if (items_cap <= 128) launch_recon<128>(recs_dev, ntiles, pair_cap, stream);
+    else if (items_cap <= 192) launch_recon<192>(recs_dev, ntiles, pair_cap, stream);
+    else launch_recon<256>(recs_dev, ntiles, pair_cap, stream);
     return hipGetLastError();
 }
 

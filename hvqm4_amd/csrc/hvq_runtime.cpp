@@ -42,7 +42,9 @@ extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
 extern "C" hipError_t hvq_launch_tilegen(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, HvqTileRec *recs_dev, uint32_t n,
                                          hipStream_t stream);
-extern "C" hipError_t hvq_launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, hipStream_t stream);
+extern "C" hipError_t hvq_launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, uint32_t items_cap, uint32_t pair_cap,
+                                       hipStream_t stream);
+extern "C" hipError_t hvq_upload_tables(void);
 
 #ifdef HVQ_STAMPS
 extern "C" void hvq_set_stamps(unsigned long long *p);
@@ -124,6 +126,7 @@ struct Launch {
     int queue;                         /* 0: main HIP stream, 1: second stream (the other half of the clips) */
     int level;
     uint32_t first_tile, ntiles;
+    uint32_t items_cap, pair_cap;      /* LDS sizing of the launch: max over its pictures */
 };
 
 struct HvqContext {
@@ -256,6 +259,7 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     HIPCHK(hipSetDevice(device));
     HvqContext *c = new HvqContext();
     c->device = device;
+    HIPCHK(hvq_upload_tables());
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -763,7 +767,7 @@ static int run_launches(HvqContext *c)
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     for (auto &L : c->launches)
-        HIPCHK(hvq_launch_recon(c->recs_dev + L.first_tile, L.ntiles, L.queue ? c->stream2 : c->stream));
+        HIPCHK(hvq_launch_recon(c->recs_dev + L.first_tile, L.ntiles, L.items_cap, L.pair_cap, L.queue ? c->stream2 : c->stream));
     if (two) {
         HIPCHK(hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -797,7 +801,7 @@ static int build_tiles(HvqContext *c)
             for (uint32_t t = 0; t < p.ntiles; ++t) bin.push_back(HvqTileRef{ (uint32_t)i, t });
         }
         if (!nb) continue;
-        Launch L{ qi, lvl, (uint32_t)tiles.size(), 0 };
+        Launch L{ qi, lvl, (uint32_t)tiles.size(), 0, 0, 0 };
         if (nb < 8) {
             /* too few pictures to give every XCD its own: plain order, no padding */
             for (int x = 0; x < nb; ++x) tiles.insert(tiles.end(), bins[x].begin(), bins[x].end());
@@ -930,7 +934,18 @@ static int flush_end(HvqContext *c)
         st.flags_or |= hd->flags;
         st.gpu_parsed += p.dev ? 1u : 0u;
     }
-    for (auto &L : c->fl_launches) st.workgroups += L.ntiles;
+    /* LDS sizes of the launches (their tile ranges were dealt at begin): accumulators are 16 dwords per queued block,
+     * rows padded to 32 entries (LDS banks); pairs above the cap take the kernel's serial fallback */
+    for (auto &L : c->fl_launches) {
+        uint32_t mi = 0, mp = 0;
+        for (const Pending &p : c->fl_pending) {
+            if (p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
+            mi = std::max(mi, p.max_items); mp = std::max(mp, p.max_pairs);
+        }
+        L.items_cap = std::min(256u, std::max(32u, mi));
+        L.pair_cap = std::min(1024u, (mp + 63u) & ~63u);
+        st.workgroups += L.ntiles;
+    }
     c->launches = c->fl_launches;
     st.launches = (uint32_t)c->launches.size();
     st.parse_seconds = c->parse_seconds;
@@ -996,23 +1011,23 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
 #ifdef HVQ_STAMPS
     if (getenv("HVQM4_AMD_STAMPS")) {
         /* diagnostic build: one more pass with phase stamps, per-launch mean segment lengths on stderr */
-        static const char *seg[8] = { "tile record", "issue level-1 loads + classify", "level-1 loads land", "LDS staging + barrier",
-                                      "MC issue + cheap kinds", "MC rows land + filter", "AOT chunks", "store issue" };
-        static const int from[8] = { 0, 1, 1, 2, 3, 4, 5, 6 }, to[8] = { 1, 2, 2, 3, 4, 5, 6, 7 };
-        const int NS = 8, LAST = 8;
+        static const char *seg[13] = { "tile record", "issue descriptor loads + classify", "descriptor loads land", "phase A (MC,cheap)", "barrier1",
+                                       "queue+nest", "barrier2", "B1 pairs", "barrier3", "B2 finish", "barrier4", "store issue", "stores land" };
+        static const int from[13] = { 0, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12 }, to[13] = { 1, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13 };
+        const int NS = 13, LAST = 13;
         for (auto &L : c->launches) {
             unsigned long long *d = nullptr;
             const size_t n = (size_t)L.ntiles * 64;
             HIPCHK(hipMalloc((void **)&d, n * 8));
             HIPCHK(hipMemsetAsync(d, 0, n * 8, c->stream));
             hvq_set_stamps(d);
-            HIPCHK(hvq_launch_recon(c->recs_dev + L.first_tile, L.ntiles, c->stream));
+            HIPCHK(hvq_launch_recon(c->recs_dev + L.first_tile, L.ntiles, L.items_cap, L.pair_cap, c->stream));
             hvq_set_stamps(nullptr);
             std::vector<unsigned long long> h(n);
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost));
             HIPCHK(hipFree(d));
-            double sum[8] = {}, life = 0; size_t cnt[8] = {}, nw = 0;
+            double sum[13] = {}, life = 0; size_t cnt[13] = {}, nw = 0;
             for (size_t t = 0; t < L.ntiles; ++t)
                 for (int w = 0; w < 4; ++w) {
                     const unsigned long long *q = &h[t * 64 + w * 16];

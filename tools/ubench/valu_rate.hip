@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 8) void k_s_add_u32(uint32_t *out, int iters, 
 {
     uint32_t s0 = seed, s1 = seed + 1, s2 = seed + 2, s3 = seed + 3, s4 = seed + 4, s5 = seed + 5, s6 = seed + 6, s7 = seed + 7;
     for (int i = 0; i < iters; ++i) {
-#define SA(s) asm volatile("s_add_u32 %0, %0, 3" : "+s"(s));
+#define SA(s) asm volatile("s_add_u32 %0, %0, 3" : "+s"(s) : : "scc");
 #define SB SA(s0) SA(s1) SA(s2) SA(s3) SA(s4) SA(s5) SA(s6) SA(s7)
         SB SB SB SB
     }
