@@ -441,8 +441,9 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
     constexpr u32 items_cap = ITEMS_CAP;
     __shared__ u32 s_item0[HVQ_WG];    /* owner lane | payload offset << 10 */
     __shared__ u32 s_item1[HVQ_WG];    /* map entry {value, type} */
-    __shared__ u32 s_item2[HVQ_WG];    /* macroblock vector */
+    __shared__ u32 s_item2[HVQ_WG];    /* MC-residual items: origin of the 70x38 window in the reference picture (h4m:1865-1868) */
     __shared__ u32 s_cnt[HVQ_NW][3];
+    __shared__ u32 s_class[256];       /* block class by type byte for this tile's context (hvq_type_class) */
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -498,10 +499,14 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
     const u32 nl = *(const GLB uint16_t *)(ent - 2), nr = *(const GLB uint16_t *)(ent + 2);
     u32 mvw = 0;
     if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
+    /* the class table travels with the descriptor loads (same round trip) and is looked up in LDS: a lookup in HBM would
+     * put one more dependent memory access in front of everything else */
+    s_class[tid] = tclass[tid];
+    __syncthreads();
 
     const i32 V = e16 & 0xFF;
     const u32 T = e16 >> 8;
-    u32 tc = tclass[T];
+    u32 tc = s_class[T];
     if (!valid) tc = 0;
     const u32 npay = HVQ_TC_NPAY(tc);
     /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual; nb = bases */
@@ -568,7 +573,10 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
         const u32 slotq = cls == 1 ? myI + lanes_below(m1) : nI + myP + lanes_below(m2);
         s_item0[slotq] = (u32)tid | (off << 10);
         s_item1[slotq] = e16;
-        s_item2[slotq] = mvw;
+        if (cls == 2) {
+            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+            s_item2[slotq] = (u32)(landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16);
+        }
         if (parallel) {
             const u32 pstart = pbefore + pincl - nb, bidx = off + (cls == 2 ? 2u : 0u);
             u32 ent = slotq | (bidx << 9);
@@ -612,10 +620,9 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
                 if (it < nI) {
                     gather_nest(d, landscape, s_nest, e, lo, hi);
                 } else {
-                    const u32 t16 = s_item1[it], mv = s_item2[it];
-                    const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
+                    const u32 t16 = s_item1[it];
+                    const i32 origin = (i32)s_item2[it];
                     const GLB uint8_t *ref = ((t16 >> 13) & 3u) == 1u ? ref0 : ref1;
-                    const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
                     gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
                 }
                 basis_scatter<ITEMS_CAP>(basis_gain(d, lo, hi), e, s_acc + it);
@@ -633,12 +640,10 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0;
             const bool intra_item = (u32)tid < nI;
-            const u32 n = HVQ_TC_NB(tclass[q16 >> 8]);
+            const u32 n = HVQ_TC_NB(s_class[q16 >> 8]);
             const GLB u32 *bases = qpay + (intra_item ? 0 : 2);
-            const u32 mv = s_item2[tid];
-            const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
+            const i32 origin = (i32)s_item2[tid];
             const GLB uint8_t *ref = ((q16 >> 13) & 3u) == 1u ? ref0 : ref1;
-            const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
             for (u32 k = 0; k < n; ++k) {
                 const u32 d = bases[k];
                 u32 e[16], lo, hi;
