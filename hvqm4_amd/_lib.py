@@ -13,9 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HVQM4_AMD_LIB") or os.path.join(HERE, "libhvqm4_amd.so")   # override: ablation builds only
 
 HVQ_OK, HVQ_E_ARG, HVQ_E_OVERFLOW, HVQ_E_GEOMETRY, HVQ_E_NOGPU, HVQ_E_HIP, HVQ_E_STATE, HVQ_E_CONTAINER = 0, -1, -2, -3, -4, -5, -6, -7
+HVQ_E_UNSUPPORTED = -8
 ERROR_NAMES = {HVQ_E_ARG: "HVQ_E_ARG", HVQ_E_OVERFLOW: "HVQ_E_OVERFLOW", HVQ_E_GEOMETRY: "HVQ_E_GEOMETRY",
                HVQ_E_NOGPU: "HVQ_E_NOGPU", HVQ_E_HIP: "HVQ_E_HIP", HVQ_E_STATE: "HVQ_E_STATE",
-               HVQ_E_CONTAINER: "HVQ_E_CONTAINER"}
+               HVQ_E_CONTAINER: "HVQ_E_CONTAINER", HVQ_E_UNSUPPORTED: "HVQ_E_UNSUPPORTED"}
 
 HVQM4_VIDEOSTATE_SIZE = 28120
 HVQM4_VIDEOSTATE_PADDING = 28097

@@ -357,7 +357,7 @@ void hvq_tilegen_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__res
     const HvqTileRef ref = tiles[i];
     HvqTileRec r;
     __builtin_memset(&r, 0, sizeof r);
-    if (ref.job != 0xFFFFFFFFu) {
+    if (ref.job != 0xFFFFFFFFu && jobs[ref.job].total_tiles != 0) {      /* total_tiles 0: picture dropped by the flush */
         const HvqJob *J = jobs + ref.job;
         const u32 tile = ref.tile;
         const int p = (tile >= J->plane[1].tile_first) + (tile >= J->plane[2].tile_first);

@@ -78,6 +78,22 @@ HVQ_EXPORT const char *hvq_last_error_string(void) { return g_err.c_str(); }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+/* Pictures this back end refuses instead of decoding them differently from the reference:
+ *   HVQ_F_SELF_REF  a P picture with a future-referencing macroblock: the reference aliases `future` to the picture being
+ *                   written (h4m:2058-2061, read at h4m:1941-1949), so such a macroblock reads samples in raster-order-
+ *                   dependent states -- not reproducible by a data-parallel reconstruction;
+ *   HVQ_F_CLAMPED   a nest origin or vector target outside what the reference's arithmetic keeps in bounds was clamped
+ *                   (malformed input); HVQM4_AMD_ALLOW_CLAMPED=1 decodes such pictures with the clamped values. */
+static const char *unsupported_reason(uint32_t flags)
+{
+    if (flags & HVQ_F_SELF_REF) return "P picture with a future-referencing macroblock (the reference reads the picture being written, h4m:2058-2061)";
+    if (flags & HVQ_F_CLAMPED) {
+        const char *e = getenv("HVQM4_AMD_ALLOW_CLAMPED");
+        if (!(e && atoi(e) > 0)) return "malformed picture: a nest origin or vector target had to be clamped (HVQM4_AMD_ALLOW_CLAMPED=1 decodes it anyway)";
+    }
+    return nullptr;
+}
+
 /* ------------------------------------------------------------------ context */
 struct Slot {
     int w_level = -1;   /* level (in the pending batch) of the launch that writes the current content */
@@ -105,6 +121,7 @@ struct Stream {
     int nest_cur = 0;
     uint8_t *nest_keep_ptr(int which) const { return nest_keep + (size_t)which * GP_ALIGN16(HVQ_NESTP_BYTES); }
     int nest_src = -1;                       /* pending index of the last I picture queued in this batch, -1: nest_keep */
+    bool need_I = false;                     /* a picture of this stream was rejected: P/B pictures are refused until the next I picture */
     uint8_t *slot_ptr(int s) const { return dev + (size_t)(s < 0 ? (int)slots.size() : s) * slot_bytes; }
 };
 
@@ -120,6 +137,8 @@ struct Pending {
     int nest_ref = -1;                 /* pending index of the governing I picture, -1: the stream's nest_keep */
     uint64_t dev_blob = 0, dev_nest = 0, nest_ptr = 0;
     uint32_t flags = 0, unk_shift = 0, pool_dwords = 0;
+    int status = 0;                    /* device parse status bits (GP_ST_*) */
+    bool dropped = false;              /* rejected at flush time (or follows a rejected picture of its stream): not reconstructed */
 };
 
 struct Launch {
@@ -153,6 +172,7 @@ struct HvqContext {
     std::vector<Pending> fl_pending;
     std::vector<size_t> fl_idx;        /* its GPU-parsed pictures (indices into fl_pending) */
     std::vector<uint64_t> fl_nest_pairs;
+    std::vector<int> fl_nest_streams;  /* stream of each pair */
     uint8_t *fl_host = nullptr, *fl_dev = nullptr;
     int fl_arena_id = 0;
     int fl_nq = 1;
@@ -405,12 +425,27 @@ static int enqueue_picture(HvqContext *c, int sid, int frame_type, size_t off, s
     return enqueue_common(c, sid, frame_type, q);
 }
 
-static int check_submit_args(HvqContext *c, int sid, int frame_type, const uint8_t *pic, size_t len)
+static int check_submit_args(HvqContext *c, int sid, int frame_type, const uint8_t *pic, size_t len, bool check_resume = true)
 {
     if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
     if (!pic || len < 8 + 0x44 + 4) return fail(HVQ_E_ARG, "picture too short (%zu bytes)", len);
     if (frame_type != HVQ_FRAME_I && frame_type != HVQ_FRAME_P && frame_type != HVQ_FRAME_B)
         return fail(HVQ_E_ARG, "unknown frame type 0x%x", frame_type);
+    if (check_resume && c->streams[sid].need_I && frame_type != HVQ_FRAME_I)
+        return fail(HVQ_E_STATE, "stream %d: a picture was rejected, decoding resumes at the next I picture", sid);
+    return HVQ_OK;
+}
+
+/* the same rule over a list of pictures: an I picture earlier in the list re-opens its stream for the ones after it */
+static int check_resume_order(HvqContext *c, int n, const int *streams, const int *frame_types)
+{
+    std::vector<char> need(c->streams.size());
+    for (size_t i = 0; i < need.size(); ++i) need[i] = c->streams[i].need_I;
+    for (int i = 0; i < n; ++i) {
+        if (frame_types[i] == HVQ_FRAME_I) need[(size_t)streams[i]] = 0;
+        else if (need[(size_t)streams[i]])
+            return fail(HVQ_E_STATE, "stream %d: a picture was rejected, decoding resumes at the next I picture", streams[i]);
+    }
     return HVQ_OK;
 }
 
@@ -430,6 +465,11 @@ HVQ_EXPORT int hvq_stream_submit(HvqContext *c, int sid, int frame_type, const u
     rc = hvq_parse_picture(s.parser, frame_type, pic, len, c->host_arena + off, bound, &blen);
     c->parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc) return fail(rc, "parse failed (%d) for stream %d picture %d", rc, sid, s.npics);
+    if (const char *why = unsupported_reason(((const HvqPicHeader *)(c->host_arena + off))->flags)) {
+        s.need_I = true;
+        return fail(HVQ_E_UNSUPPORTED, "stream %d picture %d: %s", sid, s.npics, why);
+    }
+    if (frame_type == HVQ_FRAME_I) s.need_I = false;
     c->arena_used = off + align_up(blen, 256);
     return enqueue_picture(c, sid, frame_type, off, blen);
 }
@@ -439,10 +479,11 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
 {
     if (!c || n < 0 || !streams || !frame_types || !pics || !lens) return fail(HVQ_E_ARG, "bad arguments");
     for (int i = 0; i < n; ++i) {
-        int rc = check_submit_args(c, streams[i], frame_types[i], pics[i], lens[i]);
+        int rc = check_submit_args(c, streams[i], frame_types[i], pics[i], lens[i], false);
         if (rc) return rc;
     }
     if (n == 0) return HVQ_OK;
+    { int rc = check_resume_order(c, n, streams, frame_types); if (rc) return rc; }
     for (int i = 0; i < n; ++i) {
         Stream &s = c->streams[(size_t)streams[i]];
         if (s.parse_mode == 2) return fail(HVQ_E_STATE, "stream %d is parsed on the GPU; use hvq_submit_many_device", streams[i]);
@@ -497,6 +538,14 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
     for (int i = 0; i < n; ++i)
         if (rcs[(size_t)i] || pieces[(size_t)i].worker < 0)
             return fail(rcs[(size_t)i] ? rcs[(size_t)i] : HVQ_E_STATE, "parse failed for picture %d (stream %d)", i, streams[i]);
+    for (int i = 0; i < n; ++i) {
+        const Piece &pc = pieces[(size_t)i];
+        if (const char *why = unsupported_reason(((const HvqPicHeader *)(wbuf[(size_t)pc.worker].p + pc.off))->flags)) {
+            c->streams[(size_t)streams[i]].need_I = true;
+            return fail(HVQ_E_UNSUPPORTED, "picture %d (stream %d): %s; nothing of this call was queued", i, streams[i], why);
+        }
+    }
+    for (int i = 0; i < n; ++i) if (frame_types[i] == HVQ_FRAME_I) c->streams[(size_t)streams[i]].need_I = false;
     size_t need = 0;
     std::vector<size_t> offs((size_t)n);
     for (int i = 0; i < n; ++i) { offs[(size_t)i] = need; need += align_up(pieces[(size_t)i].len, 256); }
@@ -534,7 +583,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
     if (!c || n < 0 || !streams || !frame_types || !pics || !lens) return fail(HVQ_E_ARG, "bad arguments");
     size_t need = 0;
     for (int i = 0; i < n; ++i) {
-        int rc = check_submit_args(c, streams[i], frame_types[i], pics[i], lens[i]);
+        int rc = check_submit_args(c, streams[i], frame_types[i], pics[i], lens[i], false);
         if (rc) return rc;
         if (lens[i] > 0x7FFFFFF0u) return fail(HVQ_E_ARG, "picture %d: the GPU parser needs the real picture length", i);
         if (c->streams[(size_t)streams[i]].parse_mode == 1)
@@ -542,6 +591,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
         need += align_up(lens[i] + 16, 256);
     }
     if (n == 0) return HVQ_OK;
+    { int rcr = check_resume_order(c, n, streams, frame_types); if (rcr) return rcr; }
     HIPCHK(hipSetDevice(c->device));
     int rc = arena_reserve(c, need);
     if (rc) return rc;
@@ -571,6 +621,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
         q.nest_ref = s.nest_src;
         const int ord = enqueue_common(c, streams[i], frame_types[i], q);
         if (frame_types[i] == HVQ_FRAME_I) {
+            s.need_I = false;
             s.nest_src = (int)c->pending.size() - 1;
             c->pending.back().nest_ref = s.nest_src;
         }
@@ -746,9 +797,7 @@ static int device_parse_finish(HvqContext *c)
     }
     for (size_t k = 0; k < idx.size(); ++k) {
         Pending &p = c->fl_pending[idx[k]];
-        if (res[k].status)
-            return fail(res[k].status & GP_ST_OVERFLOW ? HVQ_E_OVERFLOW : HVQ_E_ARG,
-                        "GPU parse failed (status %u) for stream %d picture %d", res[k].status, p.stream, p.ordinal);
+        p.status = (int)res[k].status;                 /* judged per picture by flush_end: one bad clip must not poison the batch */
         p.max_items = res[k].max_items; p.max_pairs = res[k].max_pairs;
         p.flags = res[k].flags;
         p.pool_dwords = res[k].pool_dwords;
@@ -847,6 +896,7 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
     /* the nest a GPU-parsed P/B picture uses: its batch's governing I picture, else the stream's kept one; the last I
      * picture of every stream is committed to the other kept slot at the end of the batch */
     c->fl_nest_pairs.clear();
+    c->fl_nest_streams.clear();
     for (auto &p : c->pending)
         if (p.dev) {
             const Stream &s = c->streams[(size_t)p.stream];
@@ -856,6 +906,7 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
         if (s.open && s.nest_src >= 0) {
             c->fl_nest_pairs.push_back(c->pending[(size_t)s.nest_src].dev_nest);
             c->fl_nest_pairs.push_back((uint64_t)(uintptr_t)s.nest_keep_ptr(s.nest_cur ^ 1));   /* replays of this batch keep reading [nest_cur] */
+            c->fl_nest_streams.push_back((int)(&s - c->streams.data()));
             s.nest_cur ^= 1;
             s.nest_src = -1;
         }
@@ -885,6 +936,48 @@ static int flush_end(HvqContext *c)
     const double te0 = now_ms();
     { int rc = device_parse_finish(c); if (rc) { c->fl_pending.clear(); c->fl_idx.clear(); return rc; } }
     const double te1 = now_ms();
+    /* Judge the GPU-parsed pictures one by one.  A picture the parser could not take (status) or that this back end refuses
+     * (unsupported_reason) is dropped together with every later picture of ITS stream in the batch; all other streams are
+     * reconstructed as if it had not been there.  The dropped pictures read as "not resident", the stream waits for its next
+     * I picture, and the flush reports the first such error after everything else has been launched. */
+    int first_rc = HVQ_OK;
+    {
+        std::vector<char> broken(c->streams.size(), 0);
+        for (size_t i = 0; i < c->fl_pending.size(); ++i) {
+            Pending &p = c->fl_pending[i];
+            Stream &s = c->streams[(size_t)p.stream];
+            const char *why = nullptr;
+            int code = HVQ_OK;
+            if (!broken[(size_t)p.stream] && p.dev) {
+                if (p.status) { code = (p.status & GP_ST_OVERFLOW) ? HVQ_E_OVERFLOW : HVQ_E_ARG; why = "the GPU parser rejected the bitstream"; }
+                else if ((why = unsupported_reason(p.flags)) != nullptr) code = HVQ_E_UNSUPPORTED;
+            }
+            if (code) {
+                broken[(size_t)p.stream] = 1;
+                if (!first_rc) first_rc = fail(code, "stream %d picture %d: %s (status %d); dropped with the later pictures of this stream, "
+                                               "the other streams of the batch were decoded", p.stream, p.ordinal, why, p.status);
+            }
+            if (!broken[(size_t)p.stream]) continue;
+            p.dropped = true;
+            if ((size_t)p.ordinal < s.pic_slot.size() && s.pic_slot[(size_t)p.ordinal] == p.dst) {
+                s.pic_slot[(size_t)p.ordinal] = -1;
+                if (s.slots[(size_t)p.dst].pic == p.ordinal) s.slots[(size_t)p.dst].pic = -1;
+            }
+        }
+        for (size_t sid = 0; sid < broken.size(); ++sid)
+            if (broken[sid]) {
+                Stream &s = c->streams[sid];
+                s.anchor_old = s.anchor_new = -1;
+                s.need_I = true;
+                for (auto &q : c->pending)                  /* already queued for the next batch: they follow the rejected picture */
+                    if (q.stream == (int)sid && q.kind != HVQ_PIC_I) q.dropped = true;
+            }
+        /* nests of broken streams are not committed (their last I picture may be among the dropped) */
+        std::vector<uint64_t> keep;
+        for (size_t k = 0; k < c->fl_nest_streams.size(); ++k)
+            if (!broken[(size_t)c->fl_nest_streams[k]]) { keep.push_back(c->fl_nest_pairs[2 * k]); keep.push_back(c->fl_nest_pairs[2 * k + 1]); }
+        c->fl_nest_pairs.swap(keep);
+    }
     /* 2. job table (the tile table went up at begin) */
     std::vector<HvqJob> &jobs = c->jobs_host;
     jobs.assign(c->fl_pending.size(), HvqJob{});
@@ -916,7 +1009,8 @@ static int flush_end(HvqContext *c)
         j.pic_kind = hd->pic_kind; j.unk_shift = hd->unk_shift;
         j.mcb_w = hd->mcb_w;
         j.pool_dwords = p.dev ? p.pool_dwords : hd->pool_dwords;
-        j.total_tiles = hd->tile_first[3];
+        j.total_tiles = p.dropped ? 0u : hd->tile_first[3];          /* 0: the tile records of this picture become padding entries */
+        if (p.dropped) continue;
         for (int k = 0; k < 3; ++k) {
             HvqPlaneRec &r = j.plane[k];
             r.map = blob + hd->map_off[k];
@@ -939,7 +1033,7 @@ static int flush_end(HvqContext *c)
     for (auto &L : c->fl_launches) {
         uint32_t mi = 0, mp = 0;
         for (const Pending &p : c->fl_pending) {
-            if (p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
+            if (p.dropped || p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
             mi = std::max(mi, p.max_items); mp = std::max(mp, p.max_pairs);
         }
         L.items_cap = std::min(256u, std::max(32u, mi));
@@ -969,7 +1063,7 @@ static int flush_end(HvqContext *c)
     c->fl_pending.clear();
     c->fl_idx.clear();
     if (flush_timing()) fprintf(stderr, "flush_end   %.3f: parse results at %.3f, launches queued %.3f ms (parse kernel %.3f ms)\n", te0, te1, now_ms(), c->gpu_parse_ms);
-    return HVQ_OK;
+    return first_rc;
 }
 
 HVQ_EXPORT int hvq_flush_end(HvqContext *c)

@@ -61,6 +61,8 @@ class SynthConfig:
     gop: str = "IPBBPBB"              # decode-order picture kinds of one GOP
     n_gops: int = 1
     repeat_gops: int = 1              # the n_gops generated GOP blocks are written this many times (long clips, cheaply)
+    p_future_refs: bool = False       # P pictures may carry type-2 ("future") macroblocks: the reference then reads the
+                                      # picture being written (h4m:2058-2061); this back end rejects such pictures
     seed: int = 0
     preset: str = "dense"             # "dense"  | "realistic" | "flat" | "natural"
     dc_shifts: Sequence[int] = (0, 1, 2)
@@ -445,8 +447,9 @@ class _Gen:
         nm = mw * mh
         # 1. MCB type runs
         types = np.zeros(nm, dtype=np.int32)
-        allowed = (0, 1) if kind == P_FRAME else (0, 1, 2)
-        wts = np.array([0.25, 0.75] if kind == P_FRAME else [0.2, 0.4, 0.4])
+        p_two = kind == P_FRAME and not cfg.p_future_refs
+        allowed = (0, 1) if p_two else (0, 1, 2)
+        wts = np.array([0.25, 0.75] if p_two else [0.2, 0.4, 0.4])
         runs: List[Tuple[int, int]] = []
         i = 0
         cur = int(rng.choice(allowed, p=wts))

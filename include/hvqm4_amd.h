@@ -30,6 +30,10 @@ extern "C" {
 #define HVQ_E_HIP        -5
 #define HVQ_E_STATE      -6
 #define HVQ_E_CONTAINER  -7   /* malformed .h4m file (every case the reference exits on) */
+#define HVQ_E_UNSUPPORTED -8  /* a picture this back end refuses rather than decode differently from the reference: a P picture with
+                                 future-referencing macroblocks (h4m:2058-2061), or malformed input that had to be clamped
+                                 (HVQM4_AMD_ALLOW_CLAMPED=1 decodes the latter).  The picture is not decoded, `present` is untouched,
+                                 the stream resumes at its next I picture; other streams of the batch are unaffected. */
 
 #define HVQ_FRAME_I 0x10   /* container frame ids, h4m:2065-2070 */
 #define HVQ_FRAME_P 0x20

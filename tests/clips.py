@@ -24,6 +24,8 @@ SMALL = [
     ("yuv444_64x48", SynthConfig(width=64, height=48, gop="IPBBPBB", seed=18, sampling="444")),
     ("yuv444_13_portrait48x64", SynthConfig(width=48, height=64, gop="IPBB", seed=19, sampling="444", version="1.3", runoff_prob=0.3)),
     ("yuv444_296x160", SynthConfig(width=296, height=160, gop="IPB", seed=20, sampling="444", weird_kinds=True)),
+    # fills the last cells of tests/test_fixture_coverage.py: inter kind 8 in a chroma plane, past (P) and future (B)
+    ("weird160x128", SynthConfig(width=160, height=128, gop="IPPBBPBB", seed=34, weird_kinds=True)),
 ]
 
 MEDIUM = [
@@ -32,6 +34,16 @@ MEDIUM = [
     ("qvga_13", SynthConfig(width=320, height=240, gop="IPBBPBB", seed=22, version="1.3")),
     ("vga_realistic", SynthConfig(width=640, height=480, gop="IPBBPBB", seed=23, preset="realistic")),
 ]
+
+# config C4 -- the per-GPU share at 8 GPUs: clips 0, 8, ..., 56 of the 64 (4 x 320x240 + 4 x 640x480, HVQM4 1.3
+# and 1.5 alternating, seed = clip number), one 16-picture GOP each here (bench.py plays the GOP four times)
+def _c4(i):
+    small, v13 = (i // 8) % 2 == 0, ((i // 16) + i) % 2 == 0
+    return (f"c4_clip{i:02d}", SynthConfig(width=320 if small else 640, height=240 if small else 480, version="1.3" if v13 else "1.5",
+                                          gop="IPBBPBBPBBPBBPBB", seed=i))
+
+
+C4_SHARE = [_c4(i) for i in range(0, 64, 8)]
 
 _cache = {}
 

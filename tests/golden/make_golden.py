@@ -26,7 +26,7 @@ def main():
         raise SystemExit("oracle/_ref/libh4mref.so missing: run `make -C oracle ref` where /root/reference exists")
     manifest = {"generator": "tests/golden/make_golden.py", "reference": "Tilka/hvqm4 h4m_audio_decode.c (gcc -O2, -DNATIVE=1)",
                 "clips": {}}
-    for name, cfg in clips.SMALL + clips.MEDIUM:
+    for name, cfg in clips.SMALL + clips.MEDIUM + clips.C4_SHARE:
         clip = clips.get((name, cfg))
         pics, probe = bridge.ref_decode(clip.data, clip.n_pictures, probe=True)
         entry = {

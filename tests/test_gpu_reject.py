@@ -1,0 +1,156 @@
+"""GPU: pictures this back end refuses and what a refusal leaves behind.
+
+* A P picture with a future-referencing (type 2) macroblock: the reference aliases `future` to the picture being
+  written (h4m:2058-2061, read at h4m:1941-1949), a raster-order dependency a data-parallel reconstruction cannot
+  reproduce.  Every entry point reports HVQ_E_UNSUPPORTED instead of decoding something else, `present` stays
+  untouched, the stream resumes at its next I picture.
+* One bad picture must not poison the batch: the other streams of the same flush decode bit-exactly."""
+import numpy as np
+import pytest
+
+from tests import clips
+
+pytestmark = pytest.mark.gpu
+
+
+def _self_ref_clip(seed=5, w=64, h=48, gop="IPBBPB"):
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    return make_clip(SynthConfig(width=w, height=h, gop=gop, seed=seed, p_future_refs=True))
+
+
+def _pics(cl):
+    from hvqm4_amd.container import video_pictures
+    return [(ft, bytes(p)) for ft, _d, p in video_pictures(cl.data)]
+
+
+def test_host_parsed_self_referencing_P_picture_is_refused_and_the_stream_resumes_at_an_I_picture(gpu_ctx):
+    from hvqm4_amd._lib import HVQ_E_STATE, HVQ_E_UNSUPPORTED, HvqError
+    from oracle import bridge
+    bad = _self_ref_clip()
+    good = clips.get(clips.SMALL[3])
+    bp, gp = _pics(bad), _pics(good)
+    sb = gpu_ctx.open_stream(bad.width, bad.height, 2, 2, True, 8)
+    sg = gpu_ctx.open_stream(good.width, good.height, 2, 2, True, len(gp) + 3)
+    gpu_ctx.submit(sb, *bp[0])                                   # the I picture is fine
+    with pytest.raises(HvqError) as e:
+        gpu_ctx.submit(sb, *bp[1])                               # P with type-2 macroblocks
+    assert e.value.code == HVQ_E_UNSUPPORTED and "future-referencing" in str(e.value)
+    with pytest.raises(HvqError) as e:
+        gpu_ctx.submit(sb, *bp[2])                               # the B picture would reference the refused P
+    assert e.value.code == HVQ_E_STATE
+    for ft, p in gp:
+        gpu_ctx.submit(sg, ft, p)
+    gpu_ctx.flush()
+    want_g = bridge.oracle_decode(good.data, good.n_pictures)
+    for k in range(len(gp)):
+        assert np.array_equal(gpu_ctx.read_picture(sg, k), want_g[k])
+    want_b = bridge.oracle_decode(bad.data, 1)
+    assert np.array_equal(gpu_ctx.read_picture(sb, 0), want_b[0])
+    # a legal clip on the same stream, starting with its I picture, decodes exactly
+    ok = clips.get(clips.SMALL[3])
+    assert (ok.width, ok.height) == (bad.width, bad.height)
+    first = None
+    for ft, p in _pics(ok):
+        o = gpu_ctx.submit(sb, ft, p)
+        first = o if first is None else first
+    gpu_ctx.flush()
+    want = bridge.oracle_decode(ok.data, ok.n_pictures)
+    for k in range(ok.n_pictures):
+        assert np.array_equal(gpu_ctx.read_picture(sb, first + k), want[k])
+    gpu_ctx.close_stream(sb); gpu_ctx.close_stream(sg)
+
+
+@pytest.mark.parametrize("what", ["self_ref", "bad_tree"])
+def test_one_refused_picture_does_not_poison_the_other_streams_of_a_gpu_parsed_batch(gpu_ctx, what):
+    import struct
+    from hvqm4_amd._lib import HVQ_E_STATE, HVQ_E_UNSUPPORTED, HvqError
+    from oracle import bridge
+    good = [clips.get(clips.SMALL[3]), clips.get(clips.SMALL[4]), clips.get(clips.SMALL[11])]
+    bad = _self_ref_clip(seed=9)
+    bp = _pics(bad)
+    if what == "bad_tree":                                       # a tree nested deeper than 255: GP_ST_BADTREE at picture 1
+        legal = clips.get(clips.SMALL[3])
+        bad, bp = legal, _pics(legal)
+        b = bytearray(bp[1][1])
+        off = 8 + 0x44 + struct.unpack_from(">I", b, 8)[0] + 4
+        b[off:off + 64] = b"\xff" * 64
+        bp[1] = (bp[1][0], bytes(b))
+    streams = [(cl, _pics(cl), gpu_ctx.open_stream(cl.width, cl.height, 2, 2, cl.version == "1.5", 12)) for cl in good]
+    sb = gpu_ctx.open_stream(bad.width, bad.height, 2, 2, True, 12)
+    sids, fts, data = [], [], []
+    for k in range(max(len(bp), max(len(p) for _c, p, _s in streams))):      # decode-order interleave over all four streams
+        for cl, pics, sid in streams + [(bad, bp, sb)]:
+            if k < len(pics):
+                sids.append(sid); fts.append(pics[k][0]); data.append(pics[k][1])
+    gpu_ctx.submit_many_device(sids, fts, data)
+    with pytest.raises(HvqError) as e:
+        gpu_ctx.flush()
+    if what == "self_ref":
+        assert e.value.code == HVQ_E_UNSUPPORTED
+    assert f"stream {sb} picture 1" in str(e.value)
+    gpu_ctx.sync()
+    for cl, pics, sid in streams:                                # every other stream: all pictures, bit-exact
+        want = bridge.oracle_decode(cl.data, cl.n_pictures)
+        for k in range(len(pics)):
+            assert np.array_equal(gpu_ctx.read_picture(sid, k), want[k]), (cl.width, k)
+    want_b = bridge.oracle_decode(bad.data, 1)
+    assert np.array_equal(gpu_ctx.read_picture(sb, 0), want_b[0])           # what came before the refused picture stands
+    for k in range(1, len(bp)):                                             # the refused picture and what followed it: not resident
+        with pytest.raises(HvqError) as e2:
+            gpu_ctx.read_picture(sb, k)
+        assert e2.value.code == HVQ_E_STATE
+    with pytest.raises(HvqError) as e3:                                     # the stream waits for an I picture ...
+        gpu_ctx.submit_many_device([sb], [bp[2][0]], [bp[2][1]])
+    assert e3.value.code == HVQ_E_STATE
+    ok = clips.get(clips.SMALL[3])                                          # ... and then decodes exactly again
+    op = _pics(ok)
+    ords = gpu_ctx.submit_many_device([sb] * len(op), [p[0] for p in op], [p[1] for p in op])
+    gpu_ctx.flush()
+    want = bridge.oracle_decode(ok.data, ok.n_pictures)
+    for k, o in enumerate(ords):
+        assert np.array_equal(gpu_ctx.read_picture(sb, o), want[k])
+    # the resident batch replays (the dropped picture's tiles are padding entries)
+    assert gpu_ctx.replay(2) > 0
+    for _c, _p, sid in streams:
+        gpu_ctx.close_stream(sid)
+    gpu_ctx.close_stream(sb)
+
+
+def test_sdk_call_refuses_the_picture_and_leaves_present_untouched():
+    from hvqm4_amd import sdk
+    from hvqm4_amd._lib import HVQ_E_UNSUPPORTED, HvqError
+    from oracle import bridge
+    bad = _self_ref_clip(seed=11, gop="IP")
+    bp = _pics(bad)
+    pl = sdk.Player(bad.width, bad.height, 2, 2, True)
+    got_i = pl.decode(*bp[0])
+    assert np.array_equal(got_i, bridge.oracle_decode(bad.data, 1)[0])
+    pl.present[:] = 0xA5
+    with pytest.raises(HvqError) as e:
+        pl.decode(*bp[1])
+    assert e.value.code == HVQ_E_UNSUPPORTED
+    assert (pl.present == 0xA5).all(), "`present` must be left as it was"
+    pl.close()
+
+
+def test_clamped_nest_origin_is_refused_unless_opted_in(gpu_ctx, monkeypatch):
+    """an I picture whose nest window crosses the map edge (nest_x + 70 > blocks per row): refused by default,
+    decoded with the clamped origin (and without faulting) under HVQM4_AMD_ALLOW_CLAMPED=1"""
+    import struct
+    from hvqm4_amd._lib import HVQ_E_UNSUPPORTED, HvqError
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    cl = make_clip(SynthConfig(width=320, height=240, gop="I", seed=3))
+    ft, pic = _pics(cl)[0]
+    b = bytearray(pic)
+    struct.pack_into(">H", b, 4, 80 - 70 + 5)                     # nest_x: 5 columns too far to the right
+    sid = gpu_ctx.open_stream(320, 240, 2, 2, True, 4)
+    monkeypatch.delenv("HVQM4_AMD_ALLOW_CLAMPED", raising=False)
+    with pytest.raises(HvqError) as e:
+        gpu_ctx.submit(sid, ft, bytes(b))
+    assert e.value.code == HVQ_E_UNSUPPORTED
+    monkeypatch.setenv("HVQM4_AMD_ALLOW_CLAMPED", "1")
+    o = gpu_ctx.submit(sid, ft, bytes(b))
+    gpu_ctx.flush()
+    assert gpu_ctx.read_picture(sid, o).size == 320 * 240 * 3 // 2
+    assert gpu_ctx.stats().flags_or & 0x20
+    gpu_ctx.close_stream(sid)

@@ -124,3 +124,16 @@ def test_rgb_epilogue_extremes():
         assert (rgb == rgb[0, 0]).all()
         r = yv + np.float32(1.402) * np.float32(vv - 128)
         assert rgb[0, 0, 0] == int(min(max(r, 0), 255))
+
+
+def test_c4_share_clips_oracle_reproduces_reference_hashes():
+    """two of the eight C4-share clips (tests/test_gpu_configs.py decodes all eight on the GPU): one 320x240 1.3 and one
+    640x480 1.5 -- the CPU restatement against the reference's committed per-picture hashes"""
+    import hashlib
+    from oracle import bridge
+    for case in (clips.C4_SHARE[0], clips.C4_SHARE[3]):
+        e = MANIFEST["clips"][case[0]]
+        clip = clips.get(case)
+        assert hashlib.sha256(clip.data).hexdigest() == e["clip_sha256"]
+        got = bridge.oracle_decode(clip.data, clip.n_pictures)
+        assert [hashlib.sha256(p.tobytes()).hexdigest() for p in got] == e["picture_sha256"]
