@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--parse-threads", type=int, default=0, help="host parse threads for the end-to-end pass (0 = all cores, max 64)")
     ap.add_argument("--mv-bits", default="0,1,2", help="vector residual-bit choices of the synthetic P/B pictures (reach = 16 << bits samples)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that generate the synthetic clips (0 = cores / ranks)")
+    ap.add_argument("--clip-cache", default="", help="directory that keeps generated clips between runs (profiling passes of one workload)")
     return ap.parse_args(argv)
 
 
@@ -133,13 +134,27 @@ def _make(cfg):
     return make_clip(cfg)
 
 
-def gen_clips(cfgs, workers: int):
-    """synthetic clips, generated by a process pool (pure Python + numpy; no GPU or HIP call happens in the children)"""
-    if workers <= 1 or len(cfgs) <= 1:
-        return [_make(c) for c in cfgs]
-    import multiprocessing as mp
-    with mp.get_context("spawn").Pool(min(workers, len(cfgs))) as pool:
-        return pool.map(_make, cfgs, chunksize=1)
+def gen_clips(cfgs, workers: int, cache: str = ""):
+    """synthetic clips, generated by a process pool (pure Python + numpy; no GPU or HIP call happens in the children);
+    `cache`: directory of pickled clips keyed by their configuration"""
+    import hashlib
+    import pickle
+    paths = [os.path.join(cache, hashlib.sha256(repr(c).encode()).hexdigest()[:24] + ".clip") if cache else None for c in cfgs]
+    out = [pickle.load(open(p, "rb")) if p and os.path.exists(p) else None for p in paths]
+    todo = [i for i, o in enumerate(out) if o is None]
+    if todo:
+        if workers <= 1 or len(todo) <= 1:
+            made = [_make(cfgs[i]) for i in todo]
+        else:
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(min(workers, len(todo))) as pool:
+                made = pool.map(_make, [cfgs[i] for i in todo], chunksize=1)
+        for i, m in zip(todo, made):
+            out[i] = m
+            if paths[i]:
+                os.makedirs(cache, exist_ok=True)
+                pickle.dump(m, open(paths[i], "wb"))
+    return out
 
 
 def host_cores() -> int:
@@ -184,7 +199,7 @@ def main():
         stream_clip = list(range(len(cfgs)))
         what = (f"C4: 64 clips (32 x 320x240 + 32 x 640x480, HVQM4 1.3/1.5 alternating, seeds 0..63, 4 x 16-picture GOPs), "
                 f"clip i -> rank i mod {world}, {args.preset} synthetic streams, descriptors resident in HBM")
-    clips = gen_clips(cfgs, workers)
+    clips = gen_clips(cfgs, workers, args.clip_cache)
     gen_s = time.time() - t0
     pics = [list(video_pictures(c.data)) for c in clips]
 
