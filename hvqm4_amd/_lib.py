@@ -76,6 +76,7 @@ SYMBOLS = {
     "HVQM4GetLastErrorString": (C.c_char_p, []),
     "HVQM4SetVersion15": (None, [C.POINTER(SeqObj), C.c_int]),
     "HVQM4ReleaseBuffer": (None, [C.POINTER(SeqObj)]),
+    "HVQM4SetMaxFrameSize": (None, [C.POINTER(SeqObj), C.c_uint32]),
     "hvq_context_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "hvq_context_destroy": (None, [C.c_void_p]),
     "hvq_stream_open": (C.c_int, [C.c_void_p] + [C.c_int] * 6),
@@ -104,6 +105,7 @@ SYMBOLS = {
     "hvq_parser_destroy": (None, [C.c_void_p]),
     "hvq_parser_blob_bound": (C.c_size_t, [C.c_void_p]),
     "hvq_parser_pic_bytes": (C.c_uint32, [C.c_void_p]),
+    "hvq_picture_length": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_size_t)]),
     "hvq_parse_picture": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]),
 }

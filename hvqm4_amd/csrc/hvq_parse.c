@@ -13,6 +13,7 @@
  */
 #include "hvq_parse.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -174,14 +175,14 @@ struct HvqParser {
 
 #define ALIGN16(x) (((x) + 15u) & ~15u)
 
-static int g_type_info_ready;
+static pthread_once_t g_type_info_once = PTHREAD_ONCE_INIT;    /* two threads may create their first parser at once */
 static void build_type_info(void);
 
 HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int is15)
 {
     if (width < 8 || height < 8 || (width & 7) || (height & 7) || width > 8192 || height > 8192) return NULL;
     if (!((h_samp == 2 && v_samp == 2) || (h_samp == 1 && v_samp == 1))) return NULL;
-    if (!g_type_info_ready) build_type_info();        /* idempotent; identical content from any thread */
+    pthread_once(&g_type_info_once, build_type_info);
     HvqParser *p = calloc(1, sizeof *p);
     if (!p) return NULL;
     p->w = width; p->h = height; p->is15 = is15 != 0;
@@ -330,7 +331,6 @@ static void build_type_info(void)
             }
             g_type_info[ctx][t] = ti;
         }
-    g_type_info_ready = 1;
 }
 
 /* raster scan of the type maps: per-block pool offsets, per-64-block bases, flags; returns pool dwords */
@@ -731,4 +731,29 @@ int hvq_parse_picture(HvqParser *p, int frame_type, const uint8_t *pic, size_t l
     case 0x30: return parse_pbpic(p, 0, pic, blob, cap, blob_len);
     default: return HVQ_E_ARG;
     }
+}
+
+
+/* Length of the picture at `frame`, from its own section table: 8 header bytes, 16 (I) or 17 (P/B) big-endian section
+ * offsets, every section = 32-bit size + payload (h4m:1978-1993, 2029-2044).  The SDK signatures carry no length, and the
+ * reference itself reads exactly these words unchecked; with the length the parser bounds every later read (zeros beyond).
+ * `limit` (readable bytes at `frame`, 0 = unknown) additionally bounds the walk over the table itself. */
+int hvq_picture_length(const uint8_t *frame, int frame_type, uint32_t limit, size_t *out)
+{
+    const uint32_t nsec = frame_type == 0x10 ? 16u : 17u, base = 8u + 4u * nsec;
+    uint64_t end = base;
+    if (!frame || !out) return HVQ_E_ARG;
+    if (limit && limit < base) return HVQ_E_ARG;
+    for (uint32_t i = 0; i < nsec; ++i) {
+        const uint8_t *q = frame + 8 + 4 * i;
+        const uint64_t at = (uint64_t)base + (((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]);
+        if (at + 4 > (limit ? (uint64_t)limit : (uint64_t)0x7FFFFFF0u)) return HVQ_E_ARG;
+        const uint8_t *z = frame + at;
+        const uint64_t size = ((uint32_t)z[0] << 24) | ((uint32_t)z[1] << 16) | ((uint32_t)z[2] << 8) | z[3];
+        if (at + 4 + size > end) end = at + 4 + size;
+    }
+    if (limit && end > limit) end = limit;
+    if (end > 0x7FFFFFF0u) return HVQ_E_ARG;
+    *out = (size_t)end;
+    return HVQ_OK;
 }

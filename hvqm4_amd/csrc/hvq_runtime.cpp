@@ -279,6 +279,7 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     HIPCHK(hipSetDevice(device));
     HvqContext *c = new HvqContext();
     c->device = device;
+    struct Guard { HvqContext *c; ~Guard() { if (c) hvq_context_destroy(c); } } guard{ c };     /* a failing step below frees what exists */
     HIPCHK(hvq_upload_tables());
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -291,6 +292,7 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    guard.c = nullptr;
     *out = c;
     return HVQ_OK;
 }
@@ -1250,6 +1252,10 @@ struct SdkBinding {
     int stream = -1;
     int w = 0, h = 0, hs = 0, vs = 0, is15 = -1;
     uint32_t pic_bytes = 0;
+    uint32_t max_frame = 0;            /* HVQM4SetMaxFrameSize: readable bytes at `frame` (0 = unknown) */
+    /* what the three device slots hold: the host buffer whose content was last written there by this library */
+    const void *host[3] = { nullptr, nullptr, nullptr };
+    bool valid[3] = { false, false, false };
 };
 
 struct SdkHeader {          /* lives at the start of the caller's work buffer */
@@ -1307,7 +1313,10 @@ SdkBinding *sdk_bind(SeqObj *seq)
     return b;
 }
 
-/* One synchronous picture: upload the caller's reference pictures, reconstruct, read back. */
+/* One synchronous picture: upload the caller's reference pictures, reconstruct, read back.
+ * HVQM4_AMD_TRUST_PICTURES=1: a reference picture is not uploaded again when `past` / `future` is a host buffer this
+ * library itself filled last (as `present` of an earlier call on the same SeqObj) and its device copy is still in place --
+ * valid for players that do not touch decoded pictures, which the SDK contract does not promise (hence opt-in). */
 void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, const void *past, const void *future)
 {
     std::lock_guard<std::mutex> lk(g_sdk_mu);
@@ -1315,26 +1324,52 @@ void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, con
     if (!b) return;
     HvqContext *c = b->ctx;
     Stream &s = c->streams[(size_t)b->stream];
-    /* host pictures are authoritative in the SDK contract: refresh the two reference slots */
-    auto put = [&](int slot, const void *src) -> bool {
-        hipError_t e = hipMemcpyAsync(s.slot_ptr(slot), src, s.pic_bytes, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { fail(HVQ_E_HIP, "upload of reference picture: %s", hipGetErrorString(e)); sdk_fail(HVQ_E_HIP); return false; }
-        return true;
+    /* the SDK signatures carry no length: it comes from the picture's own section table (hvq_picture_length), so that the
+     * host parser bounds every later read */
+    size_t len = 0;
+    { int rc = hvq_picture_length(frame, ftype, b->max_frame, &len);
+      if (rc) { fail(rc, "malformed picture: a section lies outside the frame"); sdk_fail(rc); return; } }
+    const char *te = getenv("HVQM4_AMD_TRUST_PICTURES");
+    const bool trust = te && atoi(te) > 0;
+    int used[2] = { -1, -1 };
+    /* device slot that holds `src`: the resident copy if trusted, else a slot not already taken, refreshed from the host */
+    auto bring = [&](const void *src, int k) -> int {
+        int slot = -1;
+        if (trust)
+            for (int i = 0; i < 3; ++i) if (b->valid[i] && b->host[i] == src && i != used[0]) slot = i;
+        if (slot < 0) {
+            for (int i = 0; i < 3 && slot < 0; ++i) if (i != used[0] && !(b->valid[i] && trust && (b->host[i] == past || b->host[i] == future))) slot = i;
+            if (slot < 0) slot = used[0] == 0 ? 1 : 0;
+            hipError_t e = hipMemcpyAsync(s.slot_ptr(slot), src, s.pic_bytes, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) { fail(HVQ_E_HIP, "upload of reference picture: %s", hipGetErrorString(e)); sdk_fail(HVQ_E_HIP); return -1; }
+            b->host[slot] = src; b->valid[slot] = true;
+        }
+        used[k] = slot;
+        return slot;
     };
-    s.anchor_old = -1; s.anchor_new = -1; s.ring = 2;
+    s.anchor_old = -1; s.anchor_new = -1;
     if (ftype == HVQ_FRAME_P) {
-        if (!put(0, past)) return;
-        s.anchor_old = -1; s.anchor_new = 0;            /* swapped to "past" by the submit's rotation */
+        const int ps = bring(past, 0);
+        if (ps < 0) return;
+        s.anchor_new = ps;                               /* swapped to "past" by the submit's rotation */
     } else if (ftype == HVQ_FRAME_B) {
-        if (!put(0, past) || !put(1, future)) return;
-        s.anchor_old = 0; s.anchor_new = 1;
+        const int ps = bring(past, 0);
+        if (ps < 0) return;
+        const int fs = bring(future, 1);
+        if (fs < 0) return;
+        s.anchor_old = ps; s.anchor_new = fs;
     }
-    int ord = hvq_stream_submit(c, b->stream, ftype, frame, 0x7FFFFFFF);
+    int dst = -1;
+    for (int i = 0; i < 3; ++i) if (i != used[0] && i != used[1] && (dst < 0 || b->host[i] == present)) dst = i;
+    s.ring = dst;                                        /* alloc_slot takes the first slot from here that is no anchor */
+    b->valid[dst] = false;
+    int ord = hvq_stream_submit(c, b->stream, ftype, frame, len);
     if (ord < 0) { sdk_fail(ord); return; }
     int rc = hvq_flush(c);
     if (rc) { sdk_fail(rc); return; }
     rc = hvq_read_picture(c, b->stream, ord, present, s.pic_bytes);
-    if (rc) sdk_fail(rc);
+    if (rc) { sdk_fail(rc); return; }
+    b->host[dst] = present; b->valid[dst] = true;        /* host and device copies are the same now */
 }
 
 }  // namespace
@@ -1382,6 +1417,14 @@ HVQ_EXPORT void HVQM4ReleaseBuffer(SeqObj *seqobj)
 {
     std::lock_guard<std::mutex> lk(g_sdk_mu);
     if (seqobj && seqobj->state) sdk_release_locked((SdkHeader *)seqobj->state);
+}
+
+HVQ_EXPORT void HVQM4SetMaxFrameSize(SeqObj *seqobj, uint32_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_sdk_mu);
+    if (!seqobj || !seqobj->state) return;
+    SdkHeader *hd = (SdkHeader *)seqobj->state;
+    if (hd->magic == SDK_MAGIC && g_bindings.count(hd->binding)) hd->binding->max_frame = bytes;
 }
 
 HVQ_EXPORT void HVQM4SetVersion15(SeqObj *seqobj, int is15)

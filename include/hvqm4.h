@@ -67,6 +67,10 @@ int      HVQM4GetLastError(void);            /* 0 = ok; HVQ_E_* otherwise; stick
 const char *HVQM4GetLastErrorString(void);
 void     HVQM4SetVersion15(SeqObj *seqobj, int is_1_5);   /* explicit form of the padding[0] hack */
 void     HVQM4ReleaseBuffer(SeqObj *seqobj); /* frees the GPU resources bound by HVQM4SetBuffer; call before freeing workbuff */
+/* Optional: the number of readable bytes at every `frame` handed to the decode calls (the container's max_frame_size,
+ * h4m:2188; a player allocates exactly that).  The SDK signatures carry no length; without this the length of a picture
+ * is taken from its own section table (h4m:1978-1993, 2029-2044), whose words the reference reads unchecked too. */
+void     HVQM4SetMaxFrameSize(SeqObj *seqobj, uint32_t bytes);
 
 #ifdef __cplusplus
 }

@@ -143,6 +143,9 @@ size_t hvq_parser_blob_bound(const HvqParser *p);
 uint32_t hvq_parser_pic_bytes(const HvqParser *p);
 int  hvq_parse_picture(HvqParser *p, int frame_type, const uint8_t *pic, size_t len,
                        uint8_t *blob, size_t cap, size_t *blob_len);
+/* Length of a picture from its own section table (what the SDK entry points, whose signatures carry no length, parse with).
+ * `limit` = readable bytes at `pic` (0 = unknown: the table's words are trusted like the reference trusts them). */
+int  hvq_picture_length(const uint8_t *pic, int frame_type, uint32_t limit, size_t *len);
 
 #ifdef __cplusplus
 }

@@ -75,3 +75,38 @@ def test_rgb_epilogue_matches_oracle(case, gpu_ctx):
         exp = bridge.oracle_rgb(want[i], hdr.width, hdr.height).reshape(hdr.height, hdr.width, 3)
         assert np.array_equal(got, exp), i          # tolerance 0: IEEE single precision on both sides
     gpu_ctx.close_stream(sid)
+
+
+@pytest.mark.parametrize("trust", [False, True], ids=["host_authoritative", "trusted_pictures"])
+def test_sdk_calls_with_exactly_sized_frames(trust, monkeypatch):
+    """The SDK entry points get the frame without any slack behind it (the length comes from the picture's section table)
+    and, with HVQM4_AMD_TRUST_PICTURES=1, keep the reference pictures they wrote themselves on the device."""
+    import ctypes as C
+    from hvqm4_amd import sdk
+    from hvqm4_amd._lib import lib
+    from oracle import bridge
+    if trust:
+        monkeypatch.setenv("HVQM4_AMD_TRUST_PICTURES", "1")
+    else:
+        monkeypatch.delenv("HVQM4_AMD_TRUST_PICTURES", raising=False)
+    for case in (clips.SMALL[3], clips.SMALL[4], clips.MEDIUM[2]):
+        cl = clips.get(case)
+        want = bridge.oracle_decode(cl.data, cl.n_pictures)
+        pl = sdk.Player(cl.width, cl.height, 2, 2, cl.version == "1.5")
+        lib().HVQM4SetMaxFrameSize(C.byref(pl.seqobj), max(len(p) for p in cl.pictures))
+        for k, (ft, pic) in enumerate(zip(cl.kinds, cl.pictures)):
+            # the rotation of Player.decode (h4m:2087-2137) with the frame handed over exactly as long as it is
+            if ft != 0x30:
+                pl.past, pl.future = pl.future, pl.past
+            frame = (C.c_uint8 * len(pic)).from_buffer_copy(pic)
+            if ft == 0x10:
+                lib().HVQM4DecodeIpic(C.byref(pl.seqobj), C.cast(frame, C.c_char_p), pl.present.ctypes.data)
+            elif ft == 0x20:
+                lib().HVQM4DecodePpic(C.byref(pl.seqobj), C.cast(frame, C.c_char_p), pl.present.ctypes.data, pl.past.ctypes.data)
+            else:
+                lib().HVQM4DecodeBpic(C.byref(pl.seqobj), C.cast(frame, C.c_char_p), pl.present.ctypes.data, pl.past.ctypes.data, pl.future.ctypes.data)
+            assert lib().HVQM4GetLastError() == 0
+            assert np.array_equal(pl.present, want[k]), (case[0], k)
+            if ft != 0x30:
+                pl.present, pl.future = pl.future, pl.present
+        pl.close()

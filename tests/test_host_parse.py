@@ -92,3 +92,26 @@ def test_unsupported_geometry_is_rejected():
     assert not l.hvq_parser_create(60, 48, 2, 2, 1)       # width not a multiple of 8 (h4m:1749-1752)
     assert not l.hvq_parser_create(64, 48, 2, 1, 1)       # sampling the reference itself handles inconsistently
     assert not l.hvq_parser_create(0, 0, 2, 2, 1)
+
+
+def test_sdk_host_side_stays_inside_exactly_sized_frames_under_asan(tmp_path):
+    """The SDK signatures carry no frame length: it is derived from the picture's own section table
+    (hvq_picture_length) and bounds the host parse.  Compiled with AddressSanitizer, fed legal, truncated and
+    bit-flipped pictures in heap buffers without a spare byte (tests/native/sdk_bounds_asan.c)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "sdk_bounds_asan"
+    subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=shift", "-fno-omit-frame-pointer",
+                           os.path.join(root, "tests", "native", "sdk_bounds_asan.c"), os.path.join(root, "hvqm4_amd", "csrc", "hvq_parse.c"),
+                           "-lpthread", "-o", str(exe)])
+    for case in (clips.SMALL[3], clips.SMALL[4], clips.SMALL[9]):
+        clip = clips.get(case)
+        rec = tmp_path / "pics.bin"
+        with open(rec, "wb") as f:
+            for ft, pic in zip(clip.kinds, clip.pictures):
+                f.write(struct.pack("<II", ft, len(pic)) + pic)
+        r = subprocess.run([str(exe), str(clip.width), str(clip.height), "1" if clip.version == "1.5" else "0", str(rec)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        assert "legal lengths exact" in r.stdout
