@@ -116,17 +116,17 @@ HVQ_HD static inline uint32_t hvq_payload_dwords(uint32_t type, int is_pb, int i
     return kind == 6u ? ((inter && (type & 0x10u)) ? 0u : 4u) : (inter ? n_inter : n_intra);
 }
 
-/* one reconstruction job = one picture of one stream (device-visible): what the runtime knows about the picture.
- * hvq_tilegen_kernel expands it, together with the blob's wave_base[] (which only the device has when the picture was
- * parsed there), into one self-contained HvqTileRec per workgroup. */
+/* one reconstruction job = one picture of one stream (device-visible).  Every member is a dword or a qword: the kernel reads
+ * the record with scalar loads only (16-bit members would be fetched with vector loads), and because all tiles of a picture
+ * read the SAME record it stays in the scalar cache / L2 -- unlike a per-tile record, whose first touch is an HBM miss
+ * (~1.2-1.9k cycles, profiles/r02d). */
 typedef struct HvqPlaneRec {       /* per-plane part (32 bytes) */
     uint64_t map;                  /* device address of the plane's map (entry [-1][-1], i.e. incl. border) */
     uint64_t dst;                  /* device address of the plane inside the destination picture */
     uint32_t plane_off;            /* byte offset of the plane inside a picture buffer (reference reads) */
     uint32_t tile_first;           /* first tile index of the plane */
-    uint16_t hb, vb;               /* 4x4 blocks */
-    uint16_t pw;                   /* samples per row */
-    uint8_t  ws, hs;               /* subsampling shifts relative to luma */
+    uint32_t hbvb;                 /* 4x4 blocks per row | rows << 16 */
+    uint32_t pw_sub;               /* samples per row | ws << 16 | hs << 24 (subsampling shifts relative to luma) */
 } HvqPlaneRec;
 
 typedef struct HvqJob {
@@ -137,16 +137,17 @@ typedef struct HvqJob {
     uint64_t wave_base;
     uint64_t nest;                 /* nibble-packed nest (HVQ_NESTP_BYTES), 0 when absent */
     uint32_t slot_bytes;           /* readable bytes at ref0/ref1 (>= pic_bytes + 8) */
-    uint32_t flags;
-    uint16_t width, height;
-    uint8_t  pic_kind, unk_shift, pad0[2];
+    uint32_t flags;                /* HVQ_F_* | picture kind << 16 | unk_shift << 20 */
+    uint32_t width;                /* luma samples per row */
     uint32_t mcb_w;
-    uint32_t pool_dwords;          /* payload pool size: end of the last tile's payload */
-    uint32_t total_tiles;
-    uint32_t pad1;
+    uint32_t pool_dwords;          /* payload pool size */
+    uint32_t total_tiles;          /* 0: picture dropped by the flush, its workgroups exit */
+    uint32_t pad1[2];
     HvqPlaneRec plane[3];
     uint32_t pad2[8];
 } HvqJob;
+#define HVQ_JOB_KIND_SHIFT  16
+#define HVQ_JOB_UNK_SHIFT   20
 
 #if defined(__cplusplus)
 static_assert(sizeof(HvqPlaneRec) == 32, "HvqPlaneRec must be 32 bytes");
@@ -182,42 +183,13 @@ HVQ_HD static inline uint32_t hvq_type_class(uint32_t type, int ctx)
     return c;
 }
 
-/* one workgroup = one tile: the host deals {job, tile} pairs into launch order (XCD-aware) ... */
+/* launch table: one entry per picture of a launch.  The grid is (picture slots, tiles): consecutive workgroup ids differ in
+ * the picture, and with the slot count a multiple of 8 all tiles of a picture run on one XCD (workgroups are dealt round-robin
+ * over the 8 XCDs), keeping its map, nest and reference reads in that XCD's L2. */
 typedef struct HvqTileRef {
-    uint32_t job;                  /* 0xFFFFFFFF: padding entry of the XCD-dealt table */
-    uint32_t tile;
+    uint32_t job;                  /* 0xFFFFFFFF: padding slot */
+    uint32_t tile;                 /* tiles of the picture */
 } HvqTileRef;
 
-/* ... and the device turns each into everything its workgroup needs, ready to use: ONE 128-byte scalar load
- * replaces the tile table -> job -> plane record -> wave_base chain of dependent loads (each ~700 cycles under load). */
-#define HVQ_TR_KIND_SHIFT   16     /* flags: HVQ_F_* in the low 16 bits, then picture kind, unk_shift, plane */
-#define HVQ_TR_UNK_SHIFT    20
-#define HVQ_TR_PLANE_SHIFT  28
-typedef struct HvqTileRec {        /* dwords only: 16-bit members would be fetched with vector loads */
-    uint64_t map;                  /* plane map, entry [-1][-1] */
-    uint64_t dst;                  /* plane inside the destination picture */
-    uint64_t pool;                 /* first payload dword OF THE TILE */
-    uint64_t mv;
-    uint64_t nest;
-    uint64_t ref0, ref1;
-    uint32_t b0;                   /* first block of the tile inside its plane */
-    uint32_t nblocks;              /* blocks of the plane */
-    uint32_t pool_dwords;          /* payload dwords of the tile */
-    uint32_t wrel[3];              /* payload offset of the tile's 64-block runs 1..3 relative to run 0 */
-    uint32_t plane_off, slot_bytes;
-    uint32_t flags;
-    uint32_t hb;                   /* 4x4 blocks per row; 0: padding entry, the workgroup exits */
-    uint32_t pw_lw;                /* plane width | luma width << 16 (samples) */
-    uint32_t mcbw_sub;             /* macroblocks per row | ws << 16 | hs << 24 (subsampling shifts relative to luma) */
-    float    rhb;                  /* 1 / hb */
-    uint32_t wxy[4];               /* block coordinates (bx | by << 16) of the first block of each of the tile's 64-block runs */
-    uint32_t pad;
-} HvqTileRec;
-
-#if defined(__cplusplus)
-static_assert(sizeof(HvqTileRec) == 128, "HvqTileRec must be 128 bytes");
-#else
-_Static_assert(sizeof(HvqTileRec) == 128, "HvqTileRec must be 128 bytes");
-#endif
 
 #endif

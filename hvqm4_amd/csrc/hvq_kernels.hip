@@ -338,62 +338,11 @@ extern "C" __attribute__((visibility("default"))) void hvq_set_stamps(unsigned l
 #define STAMP(i, VM) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
         if (VM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-        if (stamps && (threadIdx.x & 63) == 0) stamps[(size_t)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + (i)] = t_; } while (0)
+        if (stamps && (threadIdx.x & 63) == 0) stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 + (threadIdx.x >> 6) * 16 + (i)] = t_; } while (0)
 #else
 #define HVQ_STAMP_ARG
 #define STAMP(i, VM) do { } while (0)
 #endif
-
-/* ------------------------------------------------------------------------------------------------------
- * Tile records.  The host deals {job, tile} pairs into launch order; this kernel expands each into the
- * self-contained 128-byte record its workgroup reads with one scalar load (hvq_desc.h).  It runs once per
- * flush (after the entropy parse, whose wave_base[] only the device has for GPU-parsed pictures).
- */
-__global__ __launch_bounds__(256)
-void hvq_tilegen_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ tiles, HvqTileRec *__restrict__ recs, u32 n)
-{
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const HvqTileRef ref = tiles[i];
-    HvqTileRec r;
-    __builtin_memset(&r, 0, sizeof r);
-    if (ref.job != 0xFFFFFFFFu && jobs[ref.job].total_tiles != 0) {      /* total_tiles 0: picture dropped by the flush */
-        const HvqJob *J = jobs + ref.job;
-        const u32 tile = ref.tile;
-        const int p = (tile >= J->plane[1].tile_first) + (tile >= J->plane[2].tile_first);
-        const HvqPlaneRec P = J->plane[p];
-        const u32 *wb = (const u32 *)J->wave_base + (size_t)tile * HVQ_NW;
-        const u32 w0 = wb[0];
-        const u32 wend = tile + 1 < J->total_tiles ? wb[HVQ_NW] : J->pool_dwords;
-        r.map = P.map; r.dst = P.dst;
-        r.pool = J->pool + 4ull * w0;
-        r.mv = J->mv; r.nest = J->nest; r.ref0 = J->ref0; r.ref1 = J->ref1;
-        r.b0 = (tile - P.tile_first) * HVQ_TILE_BLOCKS;
-        r.nblocks = (u32)P.hb * P.vb;
-        r.pool_dwords = wend - w0;
-        r.wrel[0] = wb[1] - w0; r.wrel[1] = wb[2] - w0; r.wrel[2] = wb[3] - w0;
-        r.plane_off = P.plane_off; r.slot_bytes = J->slot_bytes;
-        r.flags = (J->flags & 0xFFFFu) | ((u32)J->pic_kind << HVQ_TR_KIND_SHIFT) | ((u32)J->unk_shift << HVQ_TR_UNK_SHIFT) |
-                  ((u32)p << HVQ_TR_PLANE_SHIFT);
-        r.hb = P.hb;
-        r.pw_lw = (u32)P.pw | ((u32)J->width << 16);
-        r.mcbw_sub = (J->mcb_w & 0xFFFFu) | ((u32)P.ws << 16) | ((u32)P.hs << 24);
-        r.rhb = 1.0f / (float)P.hb;
-        for (int w = 0; w < HVQ_NW; ++w) {
-            const u32 bw = r.b0 + 64u * (u32)w;
-            r.wxy[w] = (bw % P.hb) | ((bw / P.hb) << 16);
-        }
-    }
-    recs[i] = r;
-}
-
-extern "C" hipError_t hvq_launch_tilegen(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, HvqTileRec *recs_dev, uint32_t n,
-                                         hipStream_t stream)
-{
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(hvq_tilegen_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, jobs_dev, tiles_dev, recs_dev, n);
-    return hipGetLastError();
-}
 
 /* block classes by type byte (hvq_type_class): one load replaces ~25 compare/select instructions per lane */
 __device__ u32 g_type_class[3 * 256];
@@ -413,8 +362,9 @@ extern "C" hipError_t hvq_upload_tables(void)
  * each keep a SIMD with 8 waves busy for ~85 % of a wave's lifetime; removing memory round trips and barriers did
  * not shorten it), so the structure is chosen for the fewest vector instructions per block and the fullest lanes:
  *
- * Workgroup = tile of 256 consecutive blocks of one plane.
- *   phase A   every lane owns one block: one scalar load brings the tile record; descriptors are fetched with
+ * Grid = (picture slots of the launch, tiles); workgroup = tile of 256 consecutive blocks of one plane.
+ *   phase A   every lane owns one block: the picture's job record comes through the scalar cache (all tiles of a picture
+ *             read the same one); descriptors are fetched with
  *             independent loads (own map entry, four neighbours, macroblock vector); the block's class comes from a
  *             256-entry table; cheap kinds (flat, weighted-DC, literal, plain MC) and the MC part of MC-residual
  *             blocks are reconstructed at once into the LDS tile; AOT blocks are queued for the WHOLE workgroup
@@ -431,7 +381,7 @@ extern "C" hipError_t hvq_upload_tables(void)
  */
 template <int ITEMS_CAP>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
-void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAMP_ARG)
+void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ pics, u32 pair_cap HVQ_STAMP_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_pair[];      /* item | payload index of the basis << 9, [pair_cap] */
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];   /* nest packed two 4-bit values per byte */
@@ -448,32 +398,68 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     STAMP(0, 0);
-    /* ---- the tile record: one scalar load ---- */
-    const HvqTileRec *__restrict__ R = recs + blockIdx.x;
-    const i32 hb = (i32)R->hb;
-    if (hb == 0) return;                                  /* padding entry of the XCD-dealt table (uniform exit) */
-    const u32 flags = R->flags;
-    const u32 pic_kind = (flags >> HVQ_TR_KIND_SHIFT) & 3u;
-    const i32 unk = (i32)((flags >> HVQ_TR_UNK_SHIFT) & 31u);
-    const int plane_id = (int)(flags >> HVQ_TR_PLANE_SHIFT);
+    /* ---- the picture's job record (hot: shared by all tiles of the picture) ---- */
+    /* grid = (8 pictures, tiles, groups of 8): workgroup ids run over the 8 pictures of a group first (one per XCD), then over
+     * tiles, then over groups -- eight pictures are in flight at a time, so their reference pictures stay in the L2s */
+    const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
+    const u32 job_id = pics[slot_id].job;
+    const u32 tile = blockIdx.y;
+    if (job_id == 0xFFFFFFFFu || tile >= pics[slot_id].tile) return;        /* padding slot / picture with fewer tiles (uniform) */
+    const HvqJob *__restrict__ J = jobs + job_id;
+    /* The per-plane part of the record is read for ALL THREE planes at once and selected in registers: the empty asm pins
+     * every word in a scalar register here.  Written as `p = ...; x = J->plane[p].x` the compiler selects the ADDRESS and
+     * loads afterwards -- a chain of four dependent scalar loads instead of one. */
+#define HVQ_PIN(x) do { x = (u32)__builtin_amdgcn_readfirstlane((int)(x)); asm volatile("" : "+s"(x)); } while (0)
+    const u32 *__restrict__ PW = (const u32 *)&J->plane[0];
+    u32 w0[8], w1[8], w2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w0[i] = PW[i]; w1[i] = PW[8 + i]; w2[i] = PW[16 + i]; }
+    u32 total_tiles = J->total_tiles;
+    /* the picture-wide part too (words 0..15 of the record: six addresses, slot size, flags, widths) */
+    const u32 *__restrict__ CW = (const u32 *)J;
+    u32 cw[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cw[i] = CW[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { HVQ_PIN(w0[i]); HVQ_PIN(w1[i]); HVQ_PIN(w2[i]); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) HVQ_PIN(cw[i]);
+    HVQ_PIN(total_tiles);
+    if (tile >= total_tiles) return;                                          /* picture dropped by the flush */
+    /* words of HvqPlaneRec: 0,1 map; 2,3 dst; 4 plane_off; 5 tile_first; 6 hbvb; 7 pw_sub */
+    const int p = (tile >= w1[5]) + (tile >= w2[5]);
+    u32 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = p == 0 ? w0[i] : p == 1 ? w1[i] : w2[i];
+    const u32 hbvb = w[6], pw_sub = w[7], tile_first = w[5];
+    const uint64_t map_a = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    const uint64_t dst_a = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    const i32 plane_off = (i32)w[4];
+    const i32 hb = (i32)(hbvb & 0xFFFFu);
+    const u32 flags = cw[13];
+    const u32 pic_kind = (flags >> HVQ_JOB_KIND_SHIFT) & 3u;
+    const i32 unk = (i32)((flags >> HVQ_JOB_UNK_SHIFT) & 31u);
+    const int plane_id = p;
     const bool is_pb = pic_kind != HVQ_PIC_I;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
-    const u32 nblocks = R->nblocks;
-    const u32 b0 = R->b0;
-    const u32 mcbw_sub = R->mcbw_sub, pw_lw = R->pw_lw;
-    const i32 ws = (i32)((mcbw_sub >> 16) & 0xFFu), hs = (i32)(mcbw_sub >> 24);
-    const i32 pw = (i32)(pw_lw & 0xFFFFu);
+    const u32 nblocks = (u32)hb * (hbvb >> 16);
+    const u32 b0 = (tile - tile_first) * HVQ_TILE_BLOCKS;
+    const i32 ws = (i32)((pw_sub >> 16) & 0xFFu), hs = (i32)(pw_sub >> 24);
+    const i32 pw = (i32)(pw_sub & 0xFFFFu);
     const i32 mstride = hb + 2;
-    const GLB uint8_t *map = (const GLB uint8_t *)R->map;
-    const GLB u32 *__restrict__ pool = (const GLB u32 *)R->pool;          /* the tile's payload */
-    const GLB u32 *__restrict__ mvs = (const GLB u32 *)R->mv;
-    const GLB uint8_t *ref0 = (const GLB uint8_t *)R->ref0, *ref1 = (const GLB uint8_t *)R->ref1;
-    const i32 plane_off = (i32)R->plane_off;
-    GLB uint8_t *plane = (GLB uint8_t *)R->dst;
-    const i32 slot = (i32)R->slot_bytes;
-    const i32 mcb_w = (i32)(mcbw_sub & 0xFFFFu);
-    const i32 lw = (i32)(pw_lw >> 16);
+    const float rhb = 1.0f / (float)hb;
+    const GLB uint8_t *map = (const GLB uint8_t *)map_a;
+#define HVQ_W64(i) ((uint64_t)cw[i] | ((uint64_t)cw[(i) + 1] << 32))
+    const GLB uint8_t *ref0 = (const GLB uint8_t *)HVQ_W64(0), *ref1 = (const GLB uint8_t *)HVQ_W64(2);
+    const GLB u32 *__restrict__ pool = (const GLB u32 *)HVQ_W64(4);
+    const GLB u32 *__restrict__ mvs = (const GLB u32 *)HVQ_W64(6);
+    const GLB u32 *__restrict__ wave_base = (const GLB u32 *)HVQ_W64(8);
+    const GLB u32 *__restrict__ nestp = (const GLB u32 *)HVQ_W64(10);
+    GLB uint8_t *plane = (GLB uint8_t *)dst_a;
+    const i32 slot = (i32)cw[12];
+    const i32 lw = (i32)cw[14];
+    const i32 mcb_w = (i32)cw[15];
     const GLB u32 *__restrict__ tclass = (const GLB u32 *)g_type_class + (is_pb ? 512 : plane_id == 0 ? 0 : 256);
     STAMP(1, 0);
 
@@ -481,17 +467,7 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
     const u32 b = b0 + (u32)tid;
     const bool valid = b < nblocks;
     i32 bx, by;
-    if (hb >= 64) {
-        /* the wave's first block comes with the record; a run of 64 blocks wraps at most once */
-        const int uw = __builtin_amdgcn_readfirstlane(wave);
-        const u32 wxy = uw == 0 ? R->wxy[0] : uw == 1 ? R->wxy[1] : uw == 2 ? R->wxy[2] : R->wxy[3];
-        bx = (i32)(wxy & 0xFFFFu) + lane; by = (i32)(wxy >> 16);
-        const bool wrap = bx >= hb;
-        bx -= wrap ? hb : 0; by += wrap ? 1 : 0;
-    } else {
-        block_coords(b, hb, R->rhb, bx, by);
-    }
-    if (!valid) { bx = 0; by = 0; }
+    block_coords(valid ? b : 0u, hb, rhb, bx, by);
     const GLB uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
     /* independent loads first: own entry, four neighbours, vector */
     const u32 e16 = *(const GLB uint16_t *)ent;
@@ -499,6 +475,7 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
     const u32 nl = *(const GLB uint16_t *)(ent - 2), nr = *(const GLB uint16_t *)(ent + 2);
     u32 mvw = 0;
     if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
+    const u32 wbase = wave_base[tile * HVQ_NW + (u32)__builtin_amdgcn_readfirstlane(wave)];   /* wave-uniform: a scalar load */
     /* the class table travels with the descriptor loads (same round trip) and is looked up in LDS: a lookup in HBM would
      * put one more dependent memory access in front of everything else */
     s_class[tid] = tclass[tid];
@@ -513,8 +490,7 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
     const u32 cls = HVQ_TC_CLS(tc);
     const u32 nb = HVQ_TC_NB(tc);
     /* payload offset / pair slot: prefix sums over the wave, skipped when the wave carries no payload at all */
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    u32 off = uwave == 0 ? 0u : uwave == 1 ? R->wrel[0] : uwave == 2 ? R->wrel[1] : R->wrel[2], pincl = 0;
+    u32 off = wbase, pincl = 0;
     if (__ballot(npay != 0)) { off += wave_incl_scan(npay) - npay; pincl = wave_incl_scan(nb); }
     const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
     if (lane == 63) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = pincl; }
@@ -586,7 +562,7 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
         }
     }
     if (nI) {
-        const GLB u32 *src = (const GLB u32 *)R->nest;                /* already nibble-packed by the host */
+        const GLB u32 *src = nestp;                                   /* already nibble-packed by the host */
         const bool second = tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4;
         const u32 n0 = src[tid], n1 = second ? src[tid + HVQ_WG] : 0u;               /* both loads in flight together */
         ((u32 *)s_nest)[tid] = n0;
@@ -684,7 +660,7 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
         const u32 gb = b0 + 4u * (u32)g;
         if (gb < nblocks) {
             i32 gx, gy;
-            block_coords(gb, hb, R->rhb, gx, gy);
+            block_coords(gb, hb, rhb, gx, gy);
             typedef u32 u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = *(const u32x4 *)&s_out[rr][4 * g];
             /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors
@@ -692,8 +668,10 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
             if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
             else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
         }
-    } else if (valid) {
-        GLB uint8_t *dst = plane + (size_t)(by * 4) * pw + bx * 4;
+    } else if (b < nblocks) {
+        i32 sx, sy;                                      /* recomputed: keeping bx, by alive through phase B costs a spill */
+        block_coords(b, hb, rhb, sx, sy);
+        GLB uint8_t *dst = plane + (size_t)(sy * 4) * pw + sx * 4;
 #pragma unroll
         for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[y][tid];
     }
@@ -702,27 +680,31 @@ void hvq_recon_kernel(const HvqTileRec *__restrict__ recs, u32 pair_cap HVQ_STAM
 }
 
 template <int ITEMS_CAP>
-static void launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, uint32_t pair_cap, hipStream_t stream)
+static void launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_tiles, uint32_t pair_cap,
+                         hipStream_t stream)
 {
 #ifdef HVQ_STAMPS
-    hipLaunchKernelGGL(hvq_recon_kernel<ITEMS_CAP>, dim3(ntiles), dim3(HVQ_WG), 4u * pair_cap, stream, recs_dev, pair_cap, g_stamps);
+    const dim3 grid = nslots >= 8 ? dim3(8, max_tiles, nslots / 8) : dim3(nslots, max_tiles, 1);     /* nslots is a multiple of 8 then */
+    hipLaunchKernelGGL(hvq_recon_kernel<ITEMS_CAP>, grid, dim3(HVQ_WG), 4u * pair_cap, stream, jobs_dev, pics_dev, pair_cap, g_stamps);
 #else
-    hipLaunchKernelGGL(hvq_recon_kernel<ITEMS_CAP>, dim3(ntiles), dim3(HVQ_WG), 4u * pair_cap, stream, recs_dev, pair_cap);
+    const dim3 grid = nslots >= 8 ? dim3(8, max_tiles, nslots / 8) : dim3(nslots, max_tiles, 1);     /* nslots is a multiple of 8 then */
+    hipLaunchKernelGGL(hvq_recon_kernel<ITEMS_CAP>, grid, dim3(HVQ_WG), 4u * pair_cap, stream, jobs_dev, pics_dev, pair_cap);
 #endif
 }
 
-/* items_cap: the most queued blocks of any tile of the launch; it selects the instantiation with the next larger
- * accumulator array (tiles beyond 256 queued blocks cannot exist: a tile has 256 blocks) */
-extern "C" hipError_t hvq_launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, uint32_t items_cap, uint32_t pair_cap,
-                                       hipStream_t stream)
+/* pics_dev: the launch's picture slots {job, tiles} (count a multiple of 8 when there are at least 8 pictures);
+ * items_cap: the most queued blocks of any tile of the launch; it selects the instantiation with the next larger
+ * accumulator array (a tile has 256 blocks, so 256 always suffices) */
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_tiles,
+                                       uint32_t items_cap, uint32_t pair_cap, hipStream_t stream)
 {
-    if (ntiles == 0) return hipSuccess;
-    if (items_cap <= 32) launch_recon<32>(recs_dev, ntiles, pair_cap, stream);
-    else if (items_cap <= 64) launch_recon<64>(recs_dev, ntiles, pair_cap, stream);
-    else if (items_cap <= 96) launch_recon<96>(recs_dev, ntiles, pair_cap, stream);
-    else if (items_cap <= 128) launch_recon<128>(recs_dev, ntiles, pair_cap, stream);
-    else if (items_cap <= 192) launch_recon<192>(recs_dev, ntiles, pair_cap, stream);
-    else launch_recon<256>(recs_dev, ntiles, pair_cap, stream);
+    if (nslots == 0 || max_tiles == 0) return hipSuccess;
+    if (items_cap <= 32) launch_recon<32>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
+    else if (items_cap <= 64) launch_recon<64>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
+    else if (items_cap <= 96) launch_recon<96>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
+    else if (items_cap <= 128) launch_recon<128>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
+    else if (items_cap <= 192) launch_recon<192>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
+    else launch_recon<256>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
     return hipGetLastError();
 }
 

@@ -16,6 +16,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -40,10 +41,8 @@ extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t
 extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
-extern "C" hipError_t hvq_launch_tilegen(const HvqJob *jobs_dev, const HvqTileRef *tiles_dev, HvqTileRec *recs_dev, uint32_t n,
-                                         hipStream_t stream);
-extern "C" hipError_t hvq_launch_recon(const HvqTileRec *recs_dev, uint32_t ntiles, uint32_t items_cap, uint32_t pair_cap,
-                                       hipStream_t stream);
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_tiles,
+                                       uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
 extern "C" hipError_t hvq_upload_tables(void);
 
 #ifdef HVQ_STAMPS
@@ -144,7 +143,8 @@ struct Pending {
 struct Launch {
     int queue;                         /* 0: main HIP stream, 1: second stream (the other half of the clips) */
     int level;
-    uint32_t first_tile, ntiles;
+    uint32_t first_tile, ntiles;       /* its picture slots in the launch table: first entry, count */
+    uint32_t max_tiles, workgroups;    /* grid = (ntiles slots, max_tiles); workgroups that do work */
     uint32_t items_cap, pair_cap;      /* LDS sizing of the launch: max over its pictures */
 };
 
@@ -188,7 +188,6 @@ struct HvqContext {
     /* last flushed batch (kept resident for hvq_replay) */
     HvqJob *jobs_dev = nullptr;
     HvqTileRef *tiles_dev = nullptr;
-    HvqTileRec *recs_dev = nullptr;    /* one self-contained record per workgroup, expanded on the device (hvq_tilegen_kernel) */
     size_t jobs_cap = 0, tiles_cap = 0;
     std::vector<Launch> launches;
     std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
@@ -325,7 +324,6 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tiles_dev) (void)hipFree(c->tiles_dev);
-    if (c->recs_dev) (void)hipFree(c->recs_dev);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
     if (c->rgb_jobs_dev) (void)hipFree(c->rgb_jobs_dev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -818,7 +816,8 @@ static int run_launches(HvqContext *c)
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     for (auto &L : c->launches)
-        HIPCHK(hvq_launch_recon(c->recs_dev + L.first_tile, L.ntiles, L.items_cap, L.pair_cap, L.queue ? c->stream2 : c->stream));
+        HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.items_cap, L.pair_cap,
+                                L.queue ? c->stream2 : c->stream));
     if (two) {
         HIPCHK(hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -826,8 +825,9 @@ static int run_launches(HvqContext *c)
     return HVQ_OK;
 }
 
-/* tile table of the batch in flight: one launch per dependency level (and queue), tiles dealt so that a picture stays
- * on one XCD.  Needs nothing from the GPU, so it is built and uploaded while the parse kernel runs. */
+/* launch table of the batch in flight: one launch per dependency level (and queue), one slot {job, tiles} per picture; the
+ * slot count is padded to a multiple of 8 so that grid column x runs on XCD x % 8 and a picture's tiles share one L2.
+ * Needs nothing from the GPU, so it is built and uploaded while the parse kernel runs. */
 static int build_tiles(HvqContext *c)
 {
     std::vector<HvqTileRef> &tiles = c->tiles_host;
@@ -843,37 +843,30 @@ static int build_tiles(HvqContext *c)
     const int nq = (qenv && atoi(qenv) >= 2) ? 2 : 1;
     for (int lvl = 0; lvl <= max_level; ++lvl)
       for (int qi = 0; qi < nq; ++qi) {
-        std::vector<HvqTileRef> bins[8];
-        int nb = 0;
+        Launch L{ qi, lvl, (uint32_t)tiles.size(), 0, 0, 0, 0, 0 };
+        std::vector<uint32_t> order;                     /* submission order (sorting same-stream pictures into one grid column of
+                                                            consecutive groups was tried: +1 % dense, -3 % flat, dropped) */
         for (size_t i = 0; i < c->fl_pending.size(); ++i) {
             const Pending &p = c->fl_pending[i];
-            if (p.level != lvl || (nq == 2 && (p.stream & 1) != qi)) continue;
-            auto &bin = bins[nb++ & 7];
-            for (uint32_t t = 0; t < p.ntiles; ++t) bin.push_back(HvqTileRef{ (uint32_t)i, t });
+            if (p.level == lvl && !(nq == 2 && (p.stream & 1) != qi)) order.push_back((uint32_t)i);
         }
-        if (!nb) continue;
-        Launch L{ qi, lvl, (uint32_t)tiles.size(), 0, 0, 0 };
-        if (nb < 8) {
-            /* too few pictures to give every XCD its own: plain order, no padding */
-            for (int x = 0; x < nb; ++x) tiles.insert(tiles.end(), bins[x].begin(), bins[x].end());
-        } else {
-            /* blockIdx % 8 selects the XCD: entry 8k+x comes from bin x; ragged tails are padded
-             * with {0xFFFFFFFF,0} entries that exit at once */
-            size_t longest = 0;
-            for (auto &b : bins) longest = std::max(longest, b.size());
-            for (size_t k = 0; k < longest; ++k)
-                for (int x = 0; x < 8; ++x)
-                    tiles.push_back(k < bins[x].size() ? bins[x][k] : HvqTileRef{ 0xFFFFFFFFu, 0u });
+        for (uint32_t i : order) {
+            const Pending &p = c->fl_pending[i];
+            tiles.push_back(HvqTileRef{ i, p.ntiles });
+            L.max_tiles = std::max(L.max_tiles, p.ntiles);
+            L.workgroups += p.ntiles;
         }
         L.ntiles = (uint32_t)tiles.size() - L.first_tile;
+        if (!L.ntiles) continue;
+        if (L.ntiles >= 8)
+            while (L.ntiles & 7u) { tiles.push_back(HvqTileRef{ 0xFFFFFFFFu, 0u }); ++L.ntiles; }   /* padding slots exit at once */
         c->fl_launches.push_back(L);
       }
     c->fl_nq = nq;
     if (tiles.size() > c->tiles_cap) {
-        if (c->tiles_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tiles_dev)); HIPCHK(hipFree(c->recs_dev)); }
+        if (c->tiles_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tiles_dev)); }
         c->tiles_cap = tiles.size() * 2;
         HIPCHK(hipMalloc((void **)&c->tiles_dev, c->tiles_cap * sizeof(HvqTileRef)));
-        HIPCHK(hipMalloc((void **)&c->recs_dev, c->tiles_cap * sizeof(HvqTileRec)));
     }
     return staged_upload(c, c->fl_arena_id, 1, c->tiles_dev, tiles.data(), tiles.size() * sizeof(HvqTileRef));
 }
@@ -1007,8 +1000,8 @@ static int flush_end(HvqContext *c)
         j.nest = hd->nest_off ? blob + hd->nest_off : 0;
         if (p.dev) j.nest = p.nest_ptr;
         j.slot_bytes = s.slot_bytes;
-        j.flags = hd->flags; j.width = hd->width; j.height = hd->height;
-        j.pic_kind = hd->pic_kind; j.unk_shift = hd->unk_shift;
+        j.flags = (hd->flags & 0xFFFFu) | ((uint32_t)hd->pic_kind << HVQ_JOB_KIND_SHIFT) | ((uint32_t)hd->unk_shift << HVQ_JOB_UNK_SHIFT);
+        j.width = hd->width;
         j.mcb_w = hd->mcb_w;
         j.pool_dwords = p.dev ? p.pool_dwords : hd->pool_dwords;
         j.total_tiles = p.dropped ? 0u : hd->tile_first[3];          /* 0: the tile records of this picture become padding entries */
@@ -1019,9 +1012,9 @@ static int flush_end(HvqContext *c)
             r.dst = dst + hd->plane_off[k];
             r.plane_off = hd->plane_off[k];
             r.tile_first = hd->tile_first[k];
-            r.hb = hd->hb[k]; r.vb = hd->vb[k];
-            r.ws = k ? hd->wshift : 0; r.hs = k ? hd->hshift : 0;
-            r.pw = (uint16_t)(hd->width >> r.ws);
+            const uint32_t ws = k ? hd->wshift : 0, hs = k ? hd->hshift : 0;
+            r.hbvb = (uint32_t)hd->hb[k] | ((uint32_t)hd->vb[k] << 16);
+            r.pw_sub = (uint32_t)(hd->width >> ws) | (ws << 16) | (hs << 24);
         }
         st.pictures++;
         st.luma_pixels += (uint64_t)p.w * p.h;
@@ -1040,7 +1033,7 @@ static int flush_end(HvqContext *c)
         }
         L.items_cap = std::min(256u, std::max(32u, mi));
         L.pair_cap = std::min(1024u, (mp + 63u) & ~63u);
-        st.workgroups += L.ntiles;
+        st.workgroups += L.workgroups;
     }
     c->launches = c->fl_launches;
     st.launches = (uint32_t)c->launches.size();
@@ -1053,8 +1046,7 @@ static int flush_end(HvqContext *c)
     }
     /* stream-ordered after whatever still reads the previous table */
     { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return rcu; }
-    /* 3. {job, tile} pairs -> self-contained tile records (needs the parse kernel's wave_base[]), then one launch per level */
-    HIPCHK(hvq_launch_tilegen(c->jobs_dev, c->tiles_dev, c->recs_dev, (uint32_t)c->tiles_host.size(), c->stream));
+    /* 3. one launch per level */
     { int rc = run_launches(c); if (rc) return rc; }
     if (!c->fl_nest_pairs.empty()) {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
         { int rcu = staged_upload(c, c->fl_arena_id, 3, c->np_dev, c->fl_nest_pairs.data(), c->fl_nest_pairs.size() * sizeof(uint64_t)); if (rcu) return rcu; }
@@ -1113,18 +1105,18 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
         const int NS = 13, LAST = 13;
         for (auto &L : c->launches) {
             unsigned long long *d = nullptr;
-            const size_t n = (size_t)L.ntiles * 64;
+            const size_t n = (size_t)L.ntiles * L.max_tiles * 64;
             HIPCHK(hipMalloc((void **)&d, n * 8));
             HIPCHK(hipMemsetAsync(d, 0, n * 8, c->stream));
             hvq_set_stamps(d);
-            HIPCHK(hvq_launch_recon(c->recs_dev + L.first_tile, L.ntiles, L.items_cap, L.pair_cap, c->stream));
+            HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.items_cap, L.pair_cap, c->stream));
             hvq_set_stamps(nullptr);
             std::vector<unsigned long long> h(n);
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost));
             HIPCHK(hipFree(d));
             double sum[13] = {}, life = 0; size_t cnt[13] = {}, nw = 0;
-            for (size_t t = 0; t < L.ntiles; ++t)
+            for (size_t t = 0; t < (size_t)L.ntiles * L.max_tiles; ++t)
                 for (int w = 0; w < 4; ++w) {
                     const unsigned long long *q = &h[t * 64 + w * 16];
                     if (!q[LAST]) continue;
@@ -1132,7 +1124,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
                         if (q[from[k]] && q[to[k]]) { sum[k] += (double)(q[to[k]] - q[from[k]]); cnt[k]++; }
                     life += (double)(q[LAST] - q[0]); nw++;
                 }
-            fprintf(stderr, "stamps L%d q%d: %u tiles, %zu waves, mean wave lifetime %.0f cycles;", L.level, L.queue, L.ntiles, nw, nw ? life / nw : 0.0);
+            fprintf(stderr, "stamps L%d q%d: %u workgroups, %zu waves, mean wave lifetime %.0f cycles;", L.level, L.queue, L.workgroups, nw, nw ? life / nw : 0.0);
             for (int k = 0; k < NS; ++k) fprintf(stderr, " %s %.0f |", seg[k], cnt[k] ? sum[k] / cnt[k] : 0.0);
             fprintf(stderr, "\n");
         }
