@@ -327,6 +327,11 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 }
 
 #define HVQ_NW (HVQ_WG / 64)
+/* ablation builds only (tools/variant.sh <name> -DHVQ_ABL=n; outputs are wrong, only the time matters):
+ * 1 = no phase-B2 arithmetic, 2 = no phase-B1 pair work, 3 = no phase-A arithmetic (MC loads kept), 4 = 2 + 1 */
+#ifndef HVQ_ABL
+#define HVQ_ABL 0
+#endif
 
 /* Diagnostic build only (-DHVQ_STAMPS, tools/variant.sh): s_memtime stamps of wave phases into a buffer of their own
  * (64 x u64 per workgroup: [wave][16]); the shipped kernel executes no stamp.  VM = also wait for the wave's
@@ -507,7 +512,8 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
             /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
             a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
-            o = mc_block(ref, a, pw, hx, hy);
+            if (HVQ_ABL == 3) { const McRows q = mc_load(ref, a, pw, hy); o.r[0] = (u32)q.q[0]; o.r[1] = (u32)q.q[1]; o.r[2] = (u32)q.q[2]; o.r[3] = (u32)(q.q[3] ^ q.q[4]); }
+            else o = mc_block(ref, a, pw, hx, hy);
         } else if (tc & HVQ_TC_WDC) {
             /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
              * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
@@ -516,7 +522,8 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             i32 Rr = (nr & 0x7700u) ? V : (i32)(nr & 0xFF);
             bool lexp = is_pb ? !(nl & 0x7700u) : ((nl >> 8) == 0 || (nl >> 8) == 8);
             i32 Ll = lexp ? (i32)(nl & 0xFF) : V;
-            o = weight_block(V, Tt, Bb, Ll, Rr);
+            if (HVQ_ABL == 3) { o.r[0] = (u32)Tt; o.r[1] = (u32)Bb; o.r[2] = (u32)Rr; o.r[3] = (u32)Ll; }
+            else o = weight_block(V, Tt, Bb, Ll, Rr);
         } else {
             /* flat DC (h4m:281-286) or literal (h4m:543-549) */
             const u32 v = (u32)V * 0x01010101u;
@@ -588,7 +595,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         u32 r[16];
         if (parallel) {
             /* ---- phase B1: one lane per (item, basis) pair ---- */
-            for (u32 pi = (u32)tid; pi < npairs; pi += HVQ_WG) {
+            for (u32 pi = (u32)tid; pi < ((HVQ_ABL == 2 || HVQ_ABL == 4) ? 0u : npairs); pi += HVQ_WG) {
                 const u32 pr = s_pair[pi];
                 const u32 it = pr & 511u;
                 const u32 d = pool[pr >> 9];
@@ -636,7 +643,9 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         /* ---- phase B2: one lane per queued block ---- */
         if (has_item) {
             Blk o;
-            if (item_mc) {
+            if (HVQ_ABL == 1 || HVQ_ABL == 4) {
+                o.r[0] = r[0] ^ p0; o.r[1] = r[5] ^ p1; o.r[2] = r[10]; o.r[3] = r[15] ^ q16;
+            } else if (item_mc) {
                 Blk m;                                       /* the owner left the MC block in the tile */
 #pragma unroll
                 for (int y = 0; y < 4; ++y) m.r[y] = s_out[y][owner];
