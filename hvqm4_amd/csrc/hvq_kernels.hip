@@ -384,32 +384,36 @@ extern "C" hipError_t hvq_upload_tables(void)
  * ITEMS_CAP = accumulator rows per launch (the most queued blocks of any tile of the launch, rounded up): a compile-time
  * stride puts every accumulator address into the instruction's offset field.
  */
-template <int ITEMS_CAP>
+/* TPW = tiles per workgroup (1 or 2): every lane owns one block of each, and everything of both is requested before anything
+ * is used.  Two tiles double the memory-level parallelism of a wave -- what streams with few AOT blocks are short of (natural
+ * preset +17 %) -- but also the LDS of the pooled queue, which costs AOT-dense streams their occupancy (dense preset -7 %):
+ * hvq_launch_recon picks per launch (profiles/r02o_ab_two_tiles.txt). */
+template <int ITEMS_CAP, int TPW>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
 void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ pics, u32 pair_cap HVQ_STAMP_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_pair[];      /* item | payload index of the basis << 9, [pair_cap] */
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];   /* nest packed two 4-bit values per byte */
-    __shared__ __attribute__((aligned(16))) u32 s_out[4][HVQ_WG];   /* [sample row][block] packed dwords */
+    __shared__ __attribute__((aligned(16))) u32 s_out[TPW][4][HVQ_WG];   /* [tile][sample row][block] packed dwords */
     __shared__ __attribute__((aligned(16))) u32 s_acc[16 * ITEMS_CAP];   /* AOT accumulators, [sample][queued block]: lanes of
                                               one ds_add hit consecutive banks (a [block][16] layout is a 32-way conflict) */
     constexpr u32 items_cap = ITEMS_CAP;
-    __shared__ u32 s_item0[HVQ_WG];    /* owner lane | payload offset << 10 */
-    __shared__ u32 s_item1[HVQ_WG];    /* map entry {value, type} */
-    __shared__ u32 s_item2[HVQ_WG];    /* MC-residual items: origin of the 70x38 window in the reference picture (h4m:1865-1868) */
-    __shared__ u32 s_cnt[HVQ_NW][3];
-    __shared__ u32 s_class[256];       /* block class by type byte for this tile's context (hvq_type_class) */
+    __shared__ u32 s_item0[ITEMS_CAP];  /* owner (tile-of-the-pair * 256 + lane) | payload offset << 10 */
+    __shared__ u32 s_item1[ITEMS_CAP];  /* map entry {value, type} */
+    __shared__ u32 s_item2[ITEMS_CAP];  /* MC-residual items: origin of the 70x38 window in the reference picture (h4m:1865-1868) */
+    __shared__ u32 s_cnt[TPW * HVQ_NW][3];
+    __shared__ u32 s_class[256];        /* block class by type byte for this plane's context (hvq_type_class) */
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     STAMP(0, 0);
-    /* ---- the picture's job record (hot: shared by all tiles of the picture) ---- */
-    /* grid = (8 pictures, tiles, groups of 8): workgroup ids run over the 8 pictures of a group first (one per XCD), then over
-     * tiles, then over groups -- eight pictures are in flight at a time, so their reference pictures stay in the L2s */
+    /* ---- the picture's job record (hot: shared by all workgroups of the picture) ---- */
+    /* grid = (8 pictures, tile pairs, groups of 8): workgroup ids run over the 8 pictures of a group first (one per XCD), then
+     * over tile pairs, then over groups -- eight pictures are in flight at a time, so their reference pictures stay in the L2s */
     const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
     const u32 job_id = pics[slot_id].job;
-    const u32 tile = blockIdx.y;
-    if (job_id == 0xFFFFFFFFu || tile >= pics[slot_id].tile) return;        /* padding slot / picture with fewer tiles (uniform) */
+    const u32 wg = blockIdx.y;
+    if (job_id == 0xFFFFFFFFu || wg >= pics[slot_id].tile) return;          /* padding slot / picture with fewer tiles (uniform) */
     const HvqJob *__restrict__ J = jobs + job_id;
     /* The per-plane part of the record is read for ALL THREE planes at once and selected in registers: the empty asm pins
      * every word in a scalar register here.  Written as `p = ...; x = J->plane[p].x` the compiler selects the ADDRESS and
@@ -430,13 +434,20 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 #pragma unroll
     for (int i = 0; i < 16; ++i) HVQ_PIN(cw[i]);
     HVQ_PIN(total_tiles);
-    if (tile >= total_tiles) return;                                          /* picture dropped by the flush */
-    /* words of HvqPlaneRec: 0,1 map; 2,3 dst; 4 plane_off; 5 tile_first; 6 hbvb; 7 pw_sub */
-    const int p = (tile >= w1[5]) + (tile >= w2[5]);
+    /* words of HvqPlaneRec: 0,1 map; 2,3 dst; 4 plane_off; 5 tile_first; 6 hbvb; 7 pw_sub.
+     * Workgroup wg of the picture -> plane and the TPW consecutive tiles of that plane it owns (the last group may be short) */
+    const u32 n0 = w1[5] - w0[5], n1 = w2[5] - w1[5], n2 = total_tiles - w2[5];
+    const u32 pf1 = (n0 + TPW - 1) / TPW, pf2 = pf1 + (n1 + TPW - 1) / TPW, pend = pf2 + (n2 + TPW - 1) / TPW;
+    if (total_tiles == 0 || wg >= pend) return;                              /* picture dropped by the flush */
+    const int p = (wg >= pf1) + (wg >= pf2);
     u32 w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = p == 0 ? w0[i] : p == 1 ? w1[i] : w2[i];
     const u32 hbvb = w[6], pw_sub = w[7], tile_first = w[5];
+    const u32 nplane_tiles = p == 0 ? n0 : p == 1 ? n1 : n2;
+    const u32 pair = wg - (p == 0 ? 0u : p == 1 ? pf1 : pf2);
+    const u32 tile0 = tile_first + (u32)TPW * pair;
+    const int ntl = (int)min((u32)TPW, nplane_tiles - (u32)TPW * pair);      /* tiles of this workgroup */
     const uint64_t map_a = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
     const uint64_t dst_a = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
     const i32 plane_off = (i32)w[4];
@@ -449,7 +460,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
     const u32 nblocks = (u32)hb * (hbvb >> 16);
-    const u32 b0 = (tile - tile_first) * HVQ_TILE_BLOCKS;
+    const u32 b0 = (u32)TPW * pair * HVQ_TILE_BLOCKS;
     const i32 ws = (i32)((pw_sub >> 16) & 0xFFu), hs = (i32)(pw_sub >> 24);
     const i32 pw = (i32)(pw_sub & 0xFFFFu);
     const i32 mstride = hb + 2;
@@ -468,131 +479,151 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const GLB u32 *__restrict__ tclass = (const GLB u32 *)g_type_class + (is_pb ? 512 : plane_id == 0 ? 0 : 256);
     STAMP(1, 0);
 
-    /* ---- phase A: own block ---- */
-    const u32 b = b0 + (u32)tid;
-    const bool valid = b < nblocks;
-    i32 bx, by;
-    block_coords(valid ? b : 0u, hb, rhb, bx, by);
-    const GLB uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
-    /* independent loads first: own entry, four neighbours, vector */
-    const u32 e16 = *(const GLB uint16_t *)ent;
-    const u32 nt = *(const GLB uint16_t *)(ent - 2 * mstride), nbt = *(const GLB uint16_t *)(ent + 2 * mstride);
-    const u32 nl = *(const GLB uint16_t *)(ent - 2), nr = *(const GLB uint16_t *)(ent + 2);
-    u32 mvw = 0;
-    if (is_pb) mvw = mvs[(by >> (1 - hs)) * mcb_w + (bx >> (1 - ws))];
-    const u32 wbase = wave_base[tile * HVQ_NW + (u32)__builtin_amdgcn_readfirstlane(wave)];   /* wave-uniform: a scalar load */
+    /* ---- phase A: one block of each of the two tiles per lane; everything of both is requested before anything is used ---- */
+    bool valid[TPW];
+    i32 bx[TPW], by[TPW];
+    u32 e16[TPW], nt[TPW], nbt[TPW], nl[TPW], nr[TPW], mvw[TPW], wbase[TPW];
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        const u32 b = b0 + (u32)(h * HVQ_TILE_BLOCKS + tid);
+        valid[h] = b < nblocks;
+        block_coords(valid[h] ? b : 0u, hb, rhb, bx[h], by[h]);
+        const GLB uint8_t *ent = map + 2 * ((by[h] + 1) * mstride + bx[h] + 1);
+        /* independent loads first: own entry, four neighbours, vector */
+        e16[h] = *(const GLB uint16_t *)ent;
+        nt[h] = *(const GLB uint16_t *)(ent - 2 * mstride); nbt[h] = *(const GLB uint16_t *)(ent + 2 * mstride);
+        nl[h] = *(const GLB uint16_t *)(ent - 2); nr[h] = *(const GLB uint16_t *)(ent + 2);
+        mvw[h] = 0;
+        if (is_pb) mvw[h] = mvs[(by[h] >> (1 - hs)) * mcb_w + (bx[h] >> (1 - ws))];
+        wbase[h] = h < ntl ? wave_base[(tile0 + (u32)h) * HVQ_NW + (u32)__builtin_amdgcn_readfirstlane(wave)] : 0u;   /* scalar load */
+    }
     /* the class table travels with the descriptor loads (same round trip) and is looked up in LDS: a lookup in HBM would
      * put one more dependent memory access in front of everything else */
     s_class[tid] = tclass[tid];
     __syncthreads();
 
-    const i32 V = e16 & 0xFF;
-    const u32 T = e16 >> 8;
-    u32 tc = s_class[T];
-    if (!valid) tc = 0;
-    const u32 npay = HVQ_TC_NPAY(tc);
-    /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual; nb = bases */
-    const u32 cls = HVQ_TC_CLS(tc);
-    const u32 nb = HVQ_TC_NB(tc);
-    /* payload offset / pair slot: prefix sums over the wave, skipped when the wave carries no payload at all */
-    u32 off = wbase, pincl = 0;
-    if (__ballot(npay != 0)) { off += wave_incl_scan(npay) - npay; pincl = wave_incl_scan(nb); }
-    const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
-    if (lane == 63) { s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = pincl; }
+    u32 tc[TPW], off[TPW], pincl[TPW], nb[TPW], cls[TPW];
+    unsigned long long m1[TPW], m2[TPW];
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        tc[h] = valid[h] ? s_class[e16[h] >> 8] : 0u;
+        const u32 npay = HVQ_TC_NPAY(tc[h]);
+        /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual; nb = bases */
+        cls[h] = HVQ_TC_CLS(tc[h]);
+        nb[h] = HVQ_TC_NB(tc[h]);
+        /* payload offset / pair slot: prefix sums over the wave, skipped when the wave carries no payload at all */
+        off[h] = wbase[h]; pincl[h] = 0;
+        if (__ballot(npay != 0)) { off[h] += wave_incl_scan(npay) - npay; pincl[h] = wave_incl_scan(nb[h]); }
+        m1[h] = __ballot(cls[h] == 1); m2[h] = __ballot(cls[h] == 2);
+        if (lane == 63) { s_cnt[h * HVQ_NW + wave][0] = (u32)__popcll(m1[h]); s_cnt[h * HVQ_NW + wave][1] = (u32)__popcll(m2[h]); s_cnt[h * HVQ_NW + wave][2] = pincl[h]; }
+    }
     STAMP(2, 1);
 
-    if (valid && cls != 1) {
-        Blk o;
-        if (tc & HVQ_TC_MC) {
+    /* motion-compensation rows of both blocks go out before either is filtered */
+    McRows rows[TPW];
+    int hxy[TPW];
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        hxy[h] = 0;
+        if (tc[h] & HVQ_TC_MC) {
             /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
-            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+            const u32 T = e16[h] >> 8;
+            const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFF), ry = (i32)(int16_t)(mvw[h] >> 16);
             const GLB uint8_t *ref = (((T >> 5) & 3u) == 1u) ? ref0 : ref1;
             const i32 pdx = rx >> ws, pdy = ry >> hs;
             const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
-            i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+            i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by[h] & (1 - hs)) * 4 * pw + (bx[h] & (1 - ws)) * 4;
             /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
             a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
-            if (HVQ_ABL == 3) { const McRows q = mc_load(ref, a, pw, hy); o.r[0] = (u32)q.q[0]; o.r[1] = (u32)q.q[1]; o.r[2] = (u32)q.q[2]; o.r[3] = (u32)(q.q[3] ^ q.q[4]); }
-            else o = mc_block(ref, a, pw, hx, hy);
-        } else if (tc & HVQ_TC_WDC) {
-            /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
-             * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
-            i32 Tt = (nt & 0x7700u) ? V : (i32)(nt & 0xFF);
-            i32 Bb = (nbt & 0x7700u) ? V : (i32)(nbt & 0xFF);
-            i32 Rr = (nr & 0x7700u) ? V : (i32)(nr & 0xFF);
-            bool lexp = is_pb ? !(nl & 0x7700u) : ((nl >> 8) == 0 || (nl >> 8) == 8);
-            i32 Ll = lexp ? (i32)(nl & 0xFF) : V;
-            if (HVQ_ABL == 3) { o.r[0] = (u32)Tt; o.r[1] = (u32)Bb; o.r[2] = (u32)Rr; o.r[3] = (u32)Ll; }
-            else o = weight_block(V, Tt, Bb, Ll, Rr);
-        } else {
-            /* flat DC (h4m:281-286) or literal (h4m:543-549) */
-            const u32 v = (u32)V * 0x01010101u;
-            o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
-            if (tc & HVQ_TC_LIT) { const GLB u32 *pay = pool + off; o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3]; }
+            rows[h] = mc_load(ref, a, pw, hy);
+            hxy[h] = hx | (hy << 1);
         }
+    }
 #pragma unroll
-        for (int y = 0; y < 4; ++y) s_out[y][tid] = o.r[y];
+    for (int h = 0; h < TPW; ++h) {
+        if (valid[h] && cls[h] != 1) {
+            Blk o;
+            const i32 V = e16[h] & 0xFF;
+            if (tc[h] & HVQ_TC_MC) {
+                if (HVQ_ABL == 3) { o.r[0] = (u32)rows[h].q[0]; o.r[1] = (u32)rows[h].q[1]; o.r[2] = (u32)rows[h].q[2]; o.r[3] = (u32)(rows[h].q[3] ^ rows[h].q[4]); }
+                else o = mc_filter(rows[h], hxy[h] & 1, hxy[h] >> 1);
+            } else if (tc[h] & HVQ_TC_WDC) {
+                /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
+                 * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
+                i32 Tt = (nt[h] & 0x7700u) ? V : (i32)(nt[h] & 0xFF);
+                i32 Bb = (nbt[h] & 0x7700u) ? V : (i32)(nbt[h] & 0xFF);
+                i32 Rr = (nr[h] & 0x7700u) ? V : (i32)(nr[h] & 0xFF);
+                bool lexp = is_pb ? !(nl[h] & 0x7700u) : ((nl[h] >> 8) == 0 || (nl[h] >> 8) == 8);
+                i32 Ll = lexp ? (i32)(nl[h] & 0xFF) : V;
+                if (HVQ_ABL == 3) { o.r[0] = (u32)Tt; o.r[1] = (u32)Bb; o.r[2] = (u32)Rr; o.r[3] = (u32)Ll; }
+                else o = weight_block(V, Tt, Bb, Ll, Rr);
+            } else {
+                /* flat DC (h4m:281-286) or literal (h4m:543-549) */
+                const u32 v = (u32)V * 0x01010101u;
+                o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
+                if (tc[h] & HVQ_TC_LIT) { const GLB u32 *pay = pool + off[h]; o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3]; }
+            }
+#pragma unroll
+            for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
+        }
     }
     STAMP(3, 1);
 
     __syncthreads();                                                           /* barrier 1: queue counts */
     STAMP(4, 0);
-    u32 nI = 0, nP = 0, myI = 0, myP = 0, npairs = 0, pbefore = 0;
+    /* the queue is pooled over both tiles: intra items first, then MC-residual items, each in (tile, wave, lane) order */
+    u32 nI = 0, nP = 0, npairs = 0, myI[TPW], myP[TPW], pbefore[TPW];
 #pragma unroll
-    for (int w = 0; w < HVQ_NW; ++w) {
-        const u32 ci = s_cnt[w][0], cp = s_cnt[w][1], cb = s_cnt[w][2];
-        if (w < wave) { myI += ci; myP += cp; pbefore += cb; }
+    for (int h = 0; h < TPW; ++h) { myI[h] = 0; myP[h] = 0; pbefore[h] = 0; }
+#pragma unroll
+    for (int v = 0; v < TPW * HVQ_NW; ++v) {
+        const u32 ci = s_cnt[v][0], cp = s_cnt[v][1], cb = s_cnt[v][2];
+#pragma unroll
+        for (int h = 0; h < TPW; ++h)
+            if (v < h * HVQ_NW + wave) { myI[h] += ci; myP[h] += cp; pbefore[h] += cb; }
         nI += ci; nP += cp; npairs += cb;
     }
-    const u32 total = nI + nP;
-    const bool parallel = npairs <= pair_cap && total <= items_cap;
+    const u32 total = min(nI + nP, items_cap);         /* items_cap covers every tile pair of the launch (flush_end) */
+    const bool parallel = npairs <= pair_cap && nI + nP <= items_cap;
     if (total && parallel) {
         /* 16 * items_cap dwords, items_cap a multiple of 32: 16-byte stores */
         typedef u32 u32x4z __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (u32 i = (u32)tid; i < 4u * items_cap; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
     }
-    if (cls) {
-        const u32 slotq = cls == 1 ? myI + lanes_below(m1) : nI + myP + lanes_below(m2);
-        s_item0[slotq] = (u32)tid | (off << 10);
-        s_item1[slotq] = e16;
-        if (cls == 2) {
-            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-            s_item2[slotq] = (u32)(landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16);
-        }
-        if (parallel) {
-            const u32 pstart = pbefore + pincl - nb, bidx = off + (cls == 2 ? 2u : 0u);
-            u32 ent = slotq | (bidx << 9);
-            u32 *dst = s_pair + pstart;
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        if (cls[h]) {
+            const u32 slotq = cls[h] == 1 ? myI[h] + lanes_below(m1[h]) : nI + myP[h] + lanes_below(m2[h]);
+            if (slotq < items_cap) {
+                s_item0[slotq] = (u32)(h * HVQ_WG + tid) | (off[h] << 10);
+                s_item1[slotq] = e16[h];
+                if (cls[h] == 2) {
+                    const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFF), ry = (i32)(int16_t)(mvw[h] >> 16);
+                    s_item2[slotq] = (u32)(landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16);
+                }
+                if (parallel) {
+                    const u32 pstart = pbefore[h] + pincl[h] - nb[h], bidx = off[h] + (cls[h] == 2 ? 2u : 0u);
+                    u32 ent = slotq | (bidx << 9);
+                    u32 *dst = s_pair + pstart;
 #pragma clang loop unroll(disable) vectorize(disable)
-            for (u32 k = 0; k < nb; ++k, ent += 1u << 9) dst[k] = ent;            /* 1..15 entries: keep the loop as written */
+                    for (u32 k = 0; k < nb[h]; ++k, ent += 1u << 9) dst[k] = ent;      /* 1..15 entries: keep the loop as written */
+                }
+            }
         }
     }
     if (nI) {
         const GLB u32 *src = nestp;                                   /* already nibble-packed by the host */
         const bool second = tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4;
-        const u32 n0 = src[tid], n1 = second ? src[tid + HVQ_WG] : 0u;               /* both loads in flight together */
-        ((u32 *)s_nest)[tid] = n0;
-        if (second) ((u32 *)s_nest)[tid + HVQ_WG] = n1;
+        const u32 q0 = src[tid], q1 = second ? src[tid + HVQ_WG] : 0u;               /* both loads in flight together */
+        ((u32 *)s_nest)[tid] = q0;
+        if (second) ((u32 *)s_nest)[tid + HVQ_WG] = q1;
     }
     STAMP(5, 1);
     if (total) __syncthreads();                                                /* barrier 2: queue + nest staged */
     STAMP(6, 0);
 
     if (total) {
-        const bool has_item = (u32)tid < total;
-        const bool item_mc = has_item && (u32)tid >= nI;
-        u32 owner = 0, q16 = 0, p0 = 0, p1 = 0;
-        const GLB u32 *__restrict__ qpay = pool;
-        if (has_item) {
-            const u32 item = s_item0[tid];
-            owner = item & 1023u;
-            qpay = pool + (item >> 10);
-            q16 = s_item1[tid];
-        }
-        if (item_mc) { p0 = qpay[0]; p1 = qpay[1]; }          /* in flight while phase B1 runs */
-
-        u32 r[16];
         if (parallel) {
             /* ---- phase B1: one lane per (item, basis) pair ---- */
             for (u32 pi = (u32)tid; pi < ((HVQ_ABL == 2 || HVQ_ABL == 4) ? 0u : npairs); pi += HVQ_WG) {
@@ -613,107 +644,125 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             STAMP(7, 1);
             __syncthreads();                                                   /* barrier 3: accumulators complete */
             STAMP(8, 0);
-            if (has_item) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) r[i] = s_acc[i * ITEMS_CAP + tid];
-            }
-        } else if (has_item) {
-            /* serial fallback for tiles whose queue exceeds the launch's LDS sizing (pathological streams) */
-            u32 acc[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0;
-            const bool intra_item = (u32)tid < nI;
-            const u32 n = HVQ_TC_NB(s_class[q16 >> 8]);
-            const GLB u32 *bases = qpay + (intra_item ? 0 : 2);
-            const i32 origin = (i32)s_item2[tid];
-            const GLB uint8_t *ref = ((q16 >> 13) & 3u) == 1u ? ref0 : ref1;
-            for (u32 k = 0; k < n; ++k) {
-                const u32 d = bases[k];
-                u32 e[16], lo, hi;
-                if (intra_item) gather_nest(d, landscape, s_nest, e, lo, hi);
-                else gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
-                const u32 g = basis_gain(d, lo, hi);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] += g * e[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = acc[i];
         }
-
-        /* ---- phase B2: one lane per queued block ---- */
-        if (has_item) {
+        /* ---- phase B2: one lane per queued block (two rounds when the pair of tiles queued more than 256) ---- */
+        for (u32 it = (u32)tid; it < total; it += HVQ_WG) {
+            const u32 item = s_item0[it];
+            const u32 owner = item & 1023u;
+            const GLB u32 *__restrict__ qpay = pool + (item >> 10);
+            const u32 q16 = s_item1[it];
+            const bool item_mc = it >= nI;
+            u32 p0 = 0, p1 = 0;
+            if (item_mc) { p0 = qpay[0]; p1 = qpay[1]; }
+            u32 r[16];
+            if (parallel) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) r[i] = s_acc[i * ITEMS_CAP + it];
+            } else {
+                /* serial fallback for tile pairs whose pair list exceeds the launch's LDS sizing (pathological streams) */
+#pragma unroll
+                for (int i = 0; i < 16; ++i) r[i] = 0;
+                const u32 n = HVQ_TC_NB(s_class[q16 >> 8]);
+                const GLB u32 *bases = qpay + (item_mc ? 2 : 0);
+                const i32 origin = (i32)s_item2[it];
+                const GLB uint8_t *ref = ((q16 >> 13) & 3u) == 1u ? ref0 : ref1;
+                for (u32 k = 0; k < n; ++k) {
+                    const u32 d = bases[k];
+                    u32 e[16], lo, hi;
+                    if (!item_mc) gather_nest(d, landscape, s_nest, e, lo, hi);
+                    else gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
+                    const u32 g = basis_gain(d, lo, hi);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) r[i] += g * e[i];
+                }
+            }
+            u32 *so = &s_out[0][0][0] + (owner >> 8) * (4 * HVQ_WG) + (owner & 255u);
             Blk o;
             if (HVQ_ABL == 1 || HVQ_ABL == 4) {
                 o.r[0] = r[0] ^ p0; o.r[1] = r[5] ^ p1; o.r[2] = r[10]; o.r[3] = r[15] ^ q16;
             } else if (item_mc) {
                 Blk m;                                       /* the owner left the MC block in the tile */
 #pragma unroll
-                for (int y = 0; y < 4; ++y) m.r[y] = s_out[y][owner];
+                for (int y = 0; y < 4; ++y) m.r[y] = so[y * HVQ_WG];
                 o = predi_finish(r, m, p0, p1, unk);
             } else {
                 o = intra_finish(r, (i32)(q16 & 0xFF), unk);
             }
 #pragma unroll
-            for (int y = 0; y < 4; ++y) s_out[y][owner] = o.r[y];
+            for (int y = 0; y < 4; ++y) so[y * HVQ_WG] = o.r[y];
         }
         STAMP(9, 1);
-        __syncthreads();                                                       /* barrier 4: tile complete in LDS */
+        __syncthreads();                                                       /* barrier 4: tiles complete in LDS */
         STAMP(10, 0);
     }
 
-    /* ---- phase C: tile -> HBM ---- */
+    /* ---- phase C: tiles -> HBM ---- */
     STAMP(11, 0);
-    if ((hb & 3) == 0) {
-        /* lane (g, r): sample row r of blocks 4g..4g+3 = 16 contiguous bytes of the plane */
-        const int g = wave * 16 + (lane & 15), rr = lane >> 4;
-        const u32 gb = b0 + 4u * (u32)g;
-        if (gb < nblocks) {
-            i32 gx, gy;
-            block_coords(gb, hb, rhb, gx, gy);
-            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 v = *(const u32x4 *)&s_out[rr][4 * g];
-            /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors
-             * in L2 (+1 % on MC-dominated streams, neutral on the dense one; profiles/r01j_ab_nontemporal.txt) */
-            if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
-            else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
-        }
-    } else if (b < nblocks) {
-        i32 sx, sy;                                      /* recomputed: keeping bx, by alive through phase B costs a spill */
-        block_coords(b, hb, rhb, sx, sy);
-        GLB uint8_t *dst = plane + (size_t)(sy * 4) * pw + sx * 4;
 #pragma unroll
-        for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[y][tid];
+    for (int h = 0; h < TPW; ++h) {
+        if ((hb & 3) == 0) {
+            /* lane (g, r): sample row r of blocks 4g..4g+3 = 16 contiguous bytes of the plane */
+            const int g = wave * 16 + (lane & 15), rr = lane >> 4;
+            const u32 gb = b0 + (u32)(h * HVQ_TILE_BLOCKS) + 4u * (u32)g;
+            if (gb < nblocks) {
+                i32 gx, gy;
+                block_coords(gb, hb, rhb, gx, gy);
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = *(const u32x4 *)&s_out[h][rr][4 * g];
+                /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors
+                 * in L2 (+1 % on MC-dominated streams, neutral on the dense one; profiles/r01j_ab_nontemporal.txt) */
+                if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
+                else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
+            }
+        } else if (b0 + (u32)(h * HVQ_TILE_BLOCKS + tid) < nblocks) {
+            i32 sx, sy;                                      /* recomputed: keeping bx, by alive through phase B costs registers */
+            block_coords(b0 + (u32)(h * HVQ_TILE_BLOCKS + tid), hb, rhb, sx, sy);
+            GLB uint8_t *dst = plane + (size_t)(sy * 4) * pw + sx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[h][y][tid];
+        }
     }
     STAMP(12, 0);
     STAMP(13, 1);
 }
 
-template <int ITEMS_CAP>
-static void launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_tiles, uint32_t pair_cap,
+template <int ITEMS_CAP, int TPW>
+static void launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs, uint32_t pair_cap,
                          hipStream_t stream)
 {
+    const dim3 grid = nslots >= 8 ? dim3(8, max_wgs, nslots / 8) : dim3(nslots, max_wgs, 1);     /* nslots is a multiple of 8 then */
 #ifdef HVQ_STAMPS
-    const dim3 grid = nslots >= 8 ? dim3(8, max_tiles, nslots / 8) : dim3(nslots, max_tiles, 1);     /* nslots is a multiple of 8 then */
-    hipLaunchKernelGGL(hvq_recon_kernel<ITEMS_CAP>, grid, dim3(HVQ_WG), 4u * pair_cap, stream, jobs_dev, pics_dev, pair_cap, g_stamps);
+    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 4u * pair_cap, stream, jobs_dev, pics_dev, pair_cap, g_stamps);
 #else
-    const dim3 grid = nslots >= 8 ? dim3(8, max_tiles, nslots / 8) : dim3(nslots, max_tiles, 1);     /* nslots is a multiple of 8 then */
-    hipLaunchKernelGGL(hvq_recon_kernel<ITEMS_CAP>, grid, dim3(HVQ_WG), 4u * pair_cap, stream, jobs_dev, pics_dev, pair_cap);
+    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 4u * pair_cap, stream, jobs_dev, pics_dev, pair_cap);
 #endif
 }
 
 /* pics_dev: the launch's picture slots {job, tiles} (count a multiple of 8 when there are at least 8 pictures);
- * items_cap: the most queued blocks of any tile of the launch; it selects the instantiation with the next larger
- * accumulator array (a tile has 256 blocks, so 256 always suffices) */
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_tiles,
-                                       uint32_t items_cap, uint32_t pair_cap, hipStream_t stream)
+ * tiles_per_wg: 1 or 2; max_wgs: the most workgroups of any picture of the launch at that setting;
+ * items_cap: the most queued blocks of any workgroup of the launch (it selects the instantiation with the next larger
+ * accumulator array); pair_cap: the most (block, basis) pairs of any workgroup (dynamic LDS, beyond it the serial fallback) */
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs,
+                                       uint32_t tiles_per_wg, uint32_t items_cap, uint32_t pair_cap, hipStream_t stream)
 {
-    if (nslots == 0 || max_tiles == 0) return hipSuccess;
-    if (items_cap <= 32) launch_recon<32>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
-    else if (items_cap <= 64) launch_recon<64>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
-    else if (items_cap <= 96) launch_recon<96>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
-    else if (items_cap <= 128) launch_recon<128>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
-    else if (items_cap <= 192) launch_recon<192>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
-    else launch_recon<256>(jobs_dev, pics_dev, nslots, max_tiles, pair_cap, stream);
+    if (nslots == 0 || max_wgs == 0) return hipSuccess;
+    if (tiles_per_wg >= 2) {
+        if (items_cap <= 32) launch_recon<32, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 64) launch_recon<64, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 96) launch_recon<96, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 128) launch_recon<128, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 192) launch_recon<192, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 256) launch_recon<256, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 384) launch_recon<384, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else launch_recon<512, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+    } else {
+        if (items_cap <= 32) launch_recon<32, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 64) launch_recon<64, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 96) launch_recon<96, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 128) launch_recon<128, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else if (items_cap <= 192) launch_recon<192, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        else launch_recon<256, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+    }
     return hipGetLastError();
 }
 

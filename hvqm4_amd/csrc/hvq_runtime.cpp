@@ -41,8 +41,8 @@ extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t
 extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_tiles,
-                                       uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs,
+                                       uint32_t tiles_per_wg, uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
 extern "C" hipError_t hvq_upload_tables(void);
 
 #ifdef HVQ_STAMPS
@@ -76,6 +76,14 @@ static int fail(int code, const char *fmt, ...)
 HVQ_EXPORT const char *hvq_last_error_string(void) { return g_err.c_str(); }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/* workgroups of a picture: one per pair of consecutive tiles of a plane (the kernel's mapping) */
+static uint32_t picture_workgroups(const uint32_t tile_first[4])
+{
+    uint32_t n = 0;
+    for (int k = 0; k < 3; ++k) n += (tile_first[k + 1] - tile_first[k] + 1) / 2;
+    return n;
+}
 
 /* Pictures this back end refuses instead of decoding them differently from the reference:
  *   HVQ_F_SELF_REF  a P picture with a future-referencing macroblock: the reference aliases `future` to the picture being
@@ -130,6 +138,7 @@ struct Pending {
     size_t blob_off, blob_len;
     int dst, ref0, ref1;
     uint32_t ntiles, kind;
+    uint32_t nwg;                      /* workgroups: pairs of consecutive tiles, plane by plane */
     uint32_t w, h;
     /* device-parsed pictures: raw bitstream in the arena instead of a blob */
     bool dev = false;
@@ -144,7 +153,9 @@ struct Launch {
     int queue;                         /* 0: main HIP stream, 1: second stream (the other half of the clips) */
     int level;
     uint32_t first_tile, ntiles;       /* its picture slots in the launch table: first entry, count */
-    uint32_t max_tiles, workgroups;    /* grid = (ntiles slots, max_tiles); workgroups that do work */
+    uint32_t max_tiles, workgroups;    /* grid = (8, max_tiles, slots / 8) at the chosen tiles per workgroup; workgroups that do work */
+    uint32_t max_wg[2], wgs[2];        /* the same for one / two tiles per workgroup (chosen at flush_end, when the queues are known) */
+    uint32_t tpw;
     uint32_t items_cap, pair_cap;      /* LDS sizing of the launch: max over its pictures */
 };
 
@@ -420,7 +431,8 @@ static int enqueue_picture(HvqContext *c, int sid, int frame_type, size_t off, s
     Pending q{};
     q.blob_off = off; q.blob_len = blen;
     const HvqPicHeader *hd = (const HvqPicHeader *)(c->host_arena + off);
-    q.ntiles = hd->tile_first[3]; q.kind = hd->pic_kind; q.w = hd->width; q.h = hd->height;
+    q.ntiles = hd->tile_first[3]; q.nwg = picture_workgroups(hd->tile_first);
+    q.kind = hd->pic_kind; q.w = hd->width; q.h = hd->height;
     q.max_items = hd->max_items; q.max_pairs = hd->max_pairs;
     return enqueue_common(c, sid, frame_type, q);
 }
@@ -614,7 +626,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
         Pending q{};
         q.dev = true;
         q.blob_off = offs[(size_t)i]; q.blob_len = lens[i];
-        q.ntiles = s.layout.tile_first[3];
+        q.ntiles = s.layout.tile_first[3]; q.nwg = picture_workgroups(s.layout.tile_first);
         q.kind = frame_types[i] == HVQ_FRAME_I ? HVQ_PIC_I : (frame_types[i] == HVQ_FRAME_P ? HVQ_PIC_P : HVQ_PIC_B);
         q.w = s.layout.width; q.h = s.layout.height;
         q.unk_shift = pics[i][1];
@@ -816,7 +828,7 @@ static int run_launches(HvqContext *c)
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     for (auto &L : c->launches)
-        HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.items_cap, L.pair_cap,
+        HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap,
                                 L.queue ? c->stream2 : c->stream));
     if (two) {
         HIPCHK(hipEventRecord(c->ev_join, c->stream2));
@@ -843,7 +855,8 @@ static int build_tiles(HvqContext *c)
     const int nq = (qenv && atoi(qenv) >= 2) ? 2 : 1;
     for (int lvl = 0; lvl <= max_level; ++lvl)
       for (int qi = 0; qi < nq; ++qi) {
-        Launch L{ qi, lvl, (uint32_t)tiles.size(), 0, 0, 0, 0, 0 };
+        Launch L{};
+        L.queue = qi; L.level = lvl; L.first_tile = (uint32_t)tiles.size();
         std::vector<uint32_t> order;                     /* submission order (sorting same-stream pictures into one grid column of
                                                             consecutive groups was tried: +1 % dense, -3 % flat, dropped) */
         for (size_t i = 0; i < c->fl_pending.size(); ++i) {
@@ -853,8 +866,8 @@ static int build_tiles(HvqContext *c)
         for (uint32_t i : order) {
             const Pending &p = c->fl_pending[i];
             tiles.push_back(HvqTileRef{ i, p.ntiles });
-            L.max_tiles = std::max(L.max_tiles, p.ntiles);
-            L.workgroups += p.ntiles;
+            L.max_wg[0] = std::max(L.max_wg[0], p.ntiles); L.wgs[0] += p.ntiles;
+            L.max_wg[1] = std::max(L.max_wg[1], p.nwg); L.wgs[1] += p.nwg;
         }
         L.ntiles = (uint32_t)tiles.size() - L.first_tile;
         if (!L.ntiles) continue;
@@ -1027,12 +1040,21 @@ static int flush_end(HvqContext *c)
      * rows padded to 32 entries (LDS banks); pairs above the cap take the kernel's serial fallback */
     for (auto &L : c->fl_launches) {
         uint32_t mi = 0, mp = 0;
-        for (const Pending &p : c->fl_pending) {
+        uint64_t payload = 0, ntl = 0;
+        for (size_t i = 0; i < c->fl_pending.size(); ++i) {
+            const Pending &p = c->fl_pending[i];
             if (p.dropped || p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
             mi = std::max(mi, p.max_items); mp = std::max(mp, p.max_pairs);
+            payload += jobs[i].pool_dwords; ntl += p.ntiles;
         }
-        L.items_cap = std::min(256u, std::max(32u, mi));
-        L.pair_cap = std::min(1024u, (mp + 63u) & ~63u);
+        /* Two tiles per workgroup (pooled queue, twice the loads in flight per wave) while the pooled accumulators still leave
+         * 8 workgroups per CU; AOT-dense launches keep one tile per workgroup (profiles/r02o_ab_two_tiles.txt). */
+        static const int force_tpw = getenv("HVQM4_AMD_TILES_PER_WG") ? atoi(getenv("HVQM4_AMD_TILES_PER_WG")) : 0;
+        /* the AOT density of the launch decides: payload dwords per tile (dense synthetic stream ~220, realistic ~35, flat ~1) */
+        L.tpw = force_tpw ? (force_tpw >= 2 ? 2u : 1u) : (payload < 128u * std::max<uint64_t>(ntl, 1) ? 2u : 1u);
+        L.items_cap = std::min(256u * L.tpw, std::max(32u, L.tpw * mi));
+        L.pair_cap = std::min(1024u * L.tpw, (L.tpw * mp + 63u) & ~63u);
+        L.max_tiles = L.max_wg[L.tpw - 1]; L.workgroups = L.wgs[L.tpw - 1];
         st.workgroups += L.workgroups;
     }
     c->launches = c->fl_launches;
@@ -1109,7 +1131,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
             HIPCHK(hipMalloc((void **)&d, n * 8));
             HIPCHK(hipMemsetAsync(d, 0, n * 8, c->stream));
             hvq_set_stamps(d);
-            HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.items_cap, L.pair_cap, c->stream));
+            HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, c->stream));
             hvq_set_stamps(nullptr);
             std::vector<unsigned long long> h(n);
             HIPCHK(hipStreamSynchronize(c->stream));
