@@ -5,7 +5,8 @@
 // mode 4: as 0 but 16-byte loads; mode 5: every lane its own random 128-byte line, 8 loads inside that line
 // (1 miss + 7 L1 hits); mode 6: as 5 but 4 loads per line (two lines per 8 loads);
 // mode 7: groups of 5 adjacent lanes share a random 128-byte line (8B at 16*j); mode 8: groups of 4; mode 9: groups of 8;
-// mode 10: lanes i and i+32 share a line (non-adjacent).
+// mode 10: lanes i and i+32 share a line (non-adjacent); mode 11: as 0 but 16-byte loads at 2-byte aligned addresses (the
+// interleaved-UV row shape); mode 12: two 8-byte loads 8 bytes apart at a 2-byte aligned address (the same bytes in two instructions).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -13,6 +14,7 @@
 typedef uint64_t __attribute__((aligned(1))) u64u;
 typedef uint32_t __attribute__((aligned(1))) u32u;
 struct __attribute__((aligned(4))) q16 { uint32_t a, b, c, d; };
+struct __attribute__((aligned(2))) q16b { uint32_t a, b, c, d; };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(const uint8_t* buf, uint32_t mask, uint32_t* out, int iters)
@@ -34,7 +36,9 @@ __global__ __launch_bounds__(256) void k(const uint8_t* buf, uint32_t mask, uint
             if (MODE == 8) off = (off & ~127u) + (t & 3) * 16 + 3;
             if (MODE == 9) off = (off & ~127u) + (t & 7) * 16 + 3;
             if (MODE == 10) off = (off & ~127u) + ((t >> 5) & 1) * 16 + 3;
-            if (MODE == 3) acc += *(const u32u*)(buf + off);
+            if (MODE == 11) { q16b v = *(const q16b*)(buf + (off & ~1u)); acc += v.a + v.b + v.c + v.d; }
+            else if (MODE == 12) { acc += *(const u64u*)(buf + (off & ~1u)); acc += *(const u64u*)(buf + (off & ~1u) + 8); }
+            else if (MODE == 3) acc += *(const u32u*)(buf + off);
             else if (MODE == 4) { q16 v = *(const q16*)(buf + (off & ~3u)); acc += v.a + v.b + v.c + v.d; }
             else acc += *(const u64u*)(buf + off);
         }
@@ -76,6 +80,8 @@ int main()
         run<8>(buf, mask, out, "4 adjacent lanes share a line");
         run<9>(buf, mask, out, "8 adjacent lanes share a line");
         run<10>(buf, mask, out, "lanes i, i+32 share a line");
+        run<11>(buf, mask, out, "random 16B, 2-byte aligned");
+        run<12>(buf, mask, out, "2 x 8B adjacent, 2-byte aligned");
         hipFree(buf); hipFree(out);
     }
     return 0;
