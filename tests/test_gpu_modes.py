@@ -1,0 +1,24 @@
+"""GPU: both workgroup shapes of the reconstruction kernel on every parity clip.
+
+The runtime picks one or two tiles per workgroup per launch from the AOT payload density (hvq_runtime.cpp, flush_end); the
+test clips are dense synthetic streams, so the default run exercises mostly the one-tile kernels.  Here the parity, batch and
+GPU-parse suites run once more in a child process with each shape forced (HVQM4_AMD_TILES_PER_WG is read once per process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tiles", ["1", "2"])
+def test_parity_suites_with_forced_tiles_per_workgroup(tiles):
+    env = dict(os.environ, HVQM4_AMD_TILES_PER_WG=tiles)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "tests/test_gpu_parity.py", "tests/test_gpu_batch.py", "tests/test_gpu_gparse.py", "tests/test_gpu_configs.py",
+                        "tests/test_gpu_reject.py"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert " passed" in r.stdout
