@@ -586,8 +586,12 @@ GP_FN void gp_nest(GPic *g, int tid, int nthr)
     int mcols = g->nest_w - cols; if (mcols > cols) mcols = cols;
     int mrows = g->nest_h - rows; if (mrows > rows) mrows = rows;
     int nx = g->nx, ny = g->ny, clamped = 0;
-    if (nx + cols > Y->hb) { nx = Y->hb - cols; clamped = 1; }
-    if (ny + rows > Y->vb) { ny = Y->vb - rows; clamped = 1; }
+    /* flat indexing of the bordered map like the reference (h4m:1169); clamped only when the window would leave the array */
+    if ((ny + rows - 1) * Y->stride + nx + cols - 1 > Y->stride * (Y->vb + 1) - 2) {
+        if (nx + cols > Y->hb) nx = Y->hb - cols;
+        if (ny + rows > Y->vb) ny = Y->vb - rows;
+        clamped = 1;
+    }
     if (tid == 0) g->part[GP_MISC + 2 * GC_COUNT] = clamped ? HVQ_F_CLAMPED : 0u;
     const int nbytes = (int)GP_ALIGN16(HVQ_NESTP_BYTES);
     for (int o = tid; o < nbytes; o += nthr) {

@@ -475,9 +475,15 @@ static void make_nest(HvqParser *p, const uint8_t *blob, int nx, int ny)        
     int rows = Y->vb < p->nest_h ? Y->vb : p->nest_h;
     int mcols = p->nest_w - cols; if (mcols > cols) mcols = cols;
     int mrows = p->nest_h - rows; if (mrows > rows) mrows = rows;
-    /* malformed nest origin: keep the window inside the map (reference reads out of bounds) */
-    if (nx + cols > Y->hb) { nx = Y->hb - cols; p->flags |= HVQ_F_CLAMPED; }
-    if (ny + rows > Y->vb) { ny = Y->vb - rows; p->flags |= HVQ_F_CLAMPED; }
+    /* The reference indexes the bordered map FLAT (payload + stride * nest_y + nest_x, h4m:1169): a window that overlaps the
+     * border column / row reads border entries (value 0x7F) and the next row's first entries -- in bounds and deterministic as
+     * long as its last element lies inside the (hb+2) x (vb+2) array, and reproduced here by the same flat indexing.  Only an
+     * origin whose window would leave the array (the reference then reads foreign memory) is clamped and flagged. */
+    if ((ny + rows - 1) * Y->stride + nx + cols - 1 > Y->stride * (Y->vb + 1) - 2) {
+        if (nx + cols > Y->hb) nx = Y->hb - cols;
+        if (ny + rows > Y->vb) ny = Y->vb - rows;
+        p->flags |= HVQ_F_CLAMPED;
+    }
     memset(p->nest, 0, sizeof p->nest);
     for (int r = 0; r < rows; ++r) {
         uint8_t *row = p->nest + r * p->nest_w;

@@ -61,6 +61,8 @@ class SynthConfig:
     gop: str = "IPBBPBB"              # decode-order picture kinds of one GOP
     n_gops: int = 1
     repeat_gops: int = 1              # the n_gops generated GOP blocks are written this many times (long clips, cheaply)
+    nest_overhang: int = 0            # I pictures: nest window this many columns over the right edge of the block map (<= 2 stays
+                                      # inside the reference's bordered array: border entries and the next row's first are read)
     p_future_refs: bool = False       # P pictures may carry type-2 ("future") macroblocks: the reference then reads the
                                       # picture being written (h4m:2058-2061); this back end rejects such pictures
     seed: int = 0
@@ -334,6 +336,8 @@ class _Gen:
         dc_shift = int(rng.choice(self.cfg.dc_shifts))
         unk_shift = int(rng.choice(self.cfg.unk_shifts))
         nest_x = int(rng.integers(0, self.hb - self.nest_w + 1)) if self.hb >= self.nest_w else 0
+        if self.cfg.nest_overhang and self.hb >= self.nest_w:
+            nest_x = self.hb - self.nest_w + self.cfg.nest_overhang
         nest_y = int(rng.integers(0, self.vb - self.nest_h + 1)) if self.vb >= self.nest_h else 0
         pic.header = struct.pack(">BBHHH", dc_shift, unk_shift, 0, nest_x, nest_y)
         # kinds: luma then chroma (Ipic_BasisNumDec)

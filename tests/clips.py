@@ -33,6 +33,10 @@ MEDIUM = [
     ("c3_640x480", SynthConfig(width=640, height=480, gop="IPBBPBB", seed=21)),
     ("qvga_13", SynthConfig(width=320, height=240, gop="IPBBPBB", seed=22, version="1.3")),
     ("vga_realistic", SynthConfig(width=640, height=480, gop="IPBBPBB", seed=23, preset="realistic")),
+    # nest windows that overlap the border column of the block map by one and by two entries: the reference indexes the bordered
+    # map flat (h4m:1169), so it reads border values and the next row's first entries -- deterministic, reproduced exactly
+    ("nest_border1_320x240", SynthConfig(width=320, height=240, gop="IPB", seed=24, nest_overhang=1)),
+    ("nest_border2_296x160", SynthConfig(width=296, height=160, gop="IPB", seed=25, nest_overhang=2)),
 ]
 
 # config C4 -- the per-GPU share at 8 GPUs: clips 0, 8, ..., 56 of the 64 (4 x 320x240 + 4 x 640x480, HVQM4 1.3

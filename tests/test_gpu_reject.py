@@ -134,15 +134,17 @@ def test_sdk_call_refuses_the_picture_and_leaves_present_untouched():
 
 
 def test_clamped_nest_origin_is_refused_unless_opted_in(gpu_ctx, monkeypatch):
-    """an I picture whose nest window crosses the map edge (nest_x + 70 > blocks per row): refused by default,
-    decoded with the clamped origin (and without faulting) under HVQM4_AMD_ALLOW_CLAMPED=1"""
+    """an I picture whose nest window leaves the bordered block map altogether (the reference would read foreign memory;
+    a window that merely overlaps the border is reproduced exactly, tests/clips.py nest_border*): refused by default, decoded
+    with the clamped origin (and without faulting) under HVQM4_AMD_ALLOW_CLAMPED=1"""
     import struct
     from hvqm4_amd._lib import HVQ_E_UNSUPPORTED, HvqError
     from hvqm4_amd.synth import SynthConfig, make_clip
     cl = make_clip(SynthConfig(width=320, height=240, gop="I", seed=3))
     ft, pic = _pics(cl)[0]
     b = bytearray(pic)
-    struct.pack_into(">H", b, 4, 80 - 70 + 5)                     # nest_x: 5 columns too far to the right
+    struct.pack_into(">H", b, 4, 80 - 70 + 5)                     # nest_x: 5 columns too far to the right ...
+    struct.pack_into(">H", b, 6, 60 - 38 + 3)                     # ... and nest_y 3 rows too low: the window leaves the bordered map
     sid = gpu_ctx.open_stream(320, 240, 2, 2, True, 4)
     monkeypatch.delenv("HVQM4_AMD_ALLOW_CLAMPED", raising=False)
     with pytest.raises(HvqError) as e:
