@@ -18,7 +18,7 @@ for lvl in range(nlev):
     i = nlev + lvl
     a, b, c, e = d1[i], d2[i], d3[i], d4[i]
     w = a['SQ_WAVES']
-    print(f"L{lvl}: WGs {int(rows[i]['Grid_Size_X'])//256:6d} us {t[i]:7.1f} VALU/w {b['SQ_INSTS_VALU']/w:5.0f} SALU/w {b['SQ_INSTS_SALU']/w:4.0f} "
+    print(f"L{lvl}: WGs {(int(rows[i]['Grid_Size_X'])*int(rows[i].get('Grid_Size_Y',1) or 1)*int(rows[i].get('Grid_Size_Z',1) or 1))//256:6d} us {t[i]:7.1f} VALU/w {b['SQ_INSTS_VALU']/w:5.0f} SALU/w {b['SQ_INSTS_SALU']/w:4.0f} "
           f"LDS/w {b['SQ_INSTS_LDS']/w:4.0f} VMRD/w {b['SQ_INSTS_VMEM_RD']/w:4.0f} VMWR/w {b['SQ_INSTS_VMEM_WR']/w:4.1f} SMEM/w {b['SQ_INSTS_SMEM']/w:4.1f} "
           f"cyc/w {a['SQ_WAVE_CYCLES']*4/w:6.0f} wait% {100*a['SQ_WAIT_ANY']/a['SQ_WAVE_CYCLES']:3.0f} issuewait% {100*a['SQ_WAIT_INST_ANY']/a['SQ_WAVE_CYCLES']:3.0f} "
           f"busy_cyc {a['SQ_BUSY_CYCLES']:.0f} FETCH {c['FETCH_SIZE']/1024:5.0f}MB WRITE {e['WRITE_SIZE']/1024:5.0f}MB L2hit {100*e['TCC_HIT_sum']/(e['TCC_HIT_sum']+e['TCC_MISS_sum']):3.0f}%")
