@@ -178,9 +178,16 @@ __device__ __forceinline__ u32 basis_gain(u32 d, u32 lo, u32 hi)
 template <int STRIDE>
 __device__ __forceinline__ void basis_scatter(u32 g, const u32 e[16], u32 *acc_lds)
 {
+#if defined(HVQ_ABL) && HVQ_ABL == 5            /* ablation: all products, ONE LDS add (prices the 16 same-address atomics) */
+    u32 t = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t ^= g * e[i];
+    __hip_atomic_fetch_add(acc_lds, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
 #pragma unroll
     for (int i = 0; i < 16; ++i)
         __hip_atomic_fetch_add(acc_lds + i * STRIDE, g * e[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 
 /* nest gather for one basis, intra (h4m:713-725).  The LDS nest holds two 4-bit values per byte at the
