@@ -233,8 +233,14 @@ __device__ __forceinline__ void gather_window(u32 d, bool landscape, const GLB u
     const u32 sel = x2 ? 0x06040200u : 0x03020100u;                 /* stride 2: bytes 0,2,4,6 */
     uint64_t q[4];
     const i32 base = clampi(origin + o, 0, slot - 8 - 3 * ys);      /* one clamp: legal windows lie inside the slot */
+#if defined(HVQ_ABL) && (HVQ_ABL == 6 || HVQ_ABL == 7)   /* ablation: 6 = two of the four window rows fetched, 7 = one (prices the gathers) */
+    q[0] = *(const GLB u64u *)(ref + base);
+    q[1] = HVQ_ABL == 6 ? *(const GLB u64u *)(ref + base + ys) : q[0] * 3u;
+    q[2] = q[0] ^ 0x5555555555555555ull; q[3] = q[1] + 0x0101010101010101ull;
+#else
 #pragma unroll
     for (int y = 0; y < 4; ++y) q[y] = *(const GLB u64u *)(ref + base + y * ys);
+#endif
     lo = 255; hi = 0;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
@@ -646,7 +652,11 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
                     const GLB uint8_t *ref = ((t16 >> 13) & 3u) == 1u ? ref0 : ref1;
                     gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
                 }
+#if defined(HVQ_ABL) && HVQ_ABL == 8             /* ablation: gathers kept, gain / products / adds replaced by one add */
+                __hip_atomic_fetch_add(s_acc + it, e[0] ^ e[5] ^ e[10] ^ e[15] ^ lo ^ hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
                 basis_scatter<ITEMS_CAP>(basis_gain(d, lo, hi), e, s_acc + it);
+#endif
             }
             STAMP(7, 1);
             __syncthreads();                                                   /* barrier 3: accumulators complete */
