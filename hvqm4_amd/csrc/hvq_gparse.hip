@@ -23,32 +23,404 @@
  */
 #include <hip/hip_runtime.h>
 
-#include "hvq_gparse_core.h"
+#include "hvq_gparse_flat.h"
 
 #define GPW 256
 
-extern "C" __global__ __launch_bounds__(GPW) __attribute__((amdgpu_num_sgpr(80)))
+/* ------------------------------------------------------------------ flat path: wave-level pieces */
+/* The decode wave and the staging wave talk through LDS: the decoder publishes each lane's bit position, the stager
+ * keeps four 64-byte quarters of every lane's section in that lane's ring (64 dwords of gp_stage) and publishes how far
+ * the data reaches.  The decoder never issues a load, so it never waits on the memory counter -- which on gfx950 it
+ * could not do without also waiting for its own symbol stores. */
+__shared__ uint32_t gf_pos_pub[16];
+__shared__ uint32_t gf_avail_pub[16];
+__shared__ uint32_t gf_done;
+__shared__ uint32_t gf_types_done;
+#ifdef GF_PROFILE
+__shared__ uint32_t gf_slow_count;
+#endif
+/* relaxed LDS accesses the compiler may neither cache nor drop (a `volatile` LDS object becomes a flat access here) */
+#define GF_LD(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define GF_ST(x, v) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+#define GF_RING 64u
+#define GF_AHEAD 640u         /* bits a round of eight codes normally touches, with room for a long one (the stager keeps
+                                 at least 1537 ahead of the published position) */
+#define GF_AHEAD_SLOW 384u    /* one code of any length (at most 9 + 255 bits) and its window */
+#define GF_SPIN_CAP (1u << 22)
+
+/* ring of lane l: lanes 0-9 over the staging slots, lanes 10-12 (I pictures) inside the tree an I picture lacks */
+__device__ static inline uint32_t *gf_ring(int l)
+{
+    return l < 10 ? gp_stage + GF_RING * (uint32_t)l : gp_stage + ((GP_TREE_DWORD(GC_MV) + 8u) & ~7u) + GF_RING * (uint32_t)(l - 10);
+}
+#define GF_SIDE_SLOT 20u                      /* P/B: slots 20-23 for the chains that run beside the rings */
+
+__device__ static inline uint32_t gf_ring_dword(const uint32_t *ring, uint32_t i) { return __builtin_bswap32(ring[i & (GF_RING - 1u)]); }
+
+__device__ static inline uint64_t gf_ring_window(const uint32_t *ring, uint32_t pos)       /* at least 33 valid bits */
+{
+    const uint32_t i = pos >> 5;
+    return (((uint64_t)gf_ring_dword(ring, i) << 32) | gf_ring_dword(ring, i + 1)) << (pos & 31u);
+}
+
+__device__ static inline uint64_t gf_ring_window64(const uint32_t *ring, uint32_t pos)       /* 64 valid bits */
+{
+    const uint32_t i = pos >> 5, sh = pos & 31u;
+    const uint32_t w0 = gf_ring_dword(ring, i), w1 = gf_ring_dword(ring, i + 1), w2 = gf_ring_dword(ring, i + 2);
+    return ((((uint64_t)w0 << 32) | w1) << sh & 0xFFFFFFFF00000000ull) | (((((uint64_t)w1 << 32) | w2) << sh) >> 32);
+}
+
+/* four symbols from a 64-bit window at `pos` (4 x 9 table bits fit it).  A code longer than the lane's table is rare per
+ * lane but not per wave -- some lane of the thirteen meets one in every third group -- so it is finished on the spot:
+ * the tree is walked bit by bit from the node the table gave, the window is taken anew behind it, the other lanes wait
+ * for that one symbol only.  `a` = how far the lane's ring is known to reach. */
+__device__ static inline uint2 gf_four(const GCode *c, const uint32_t *tab, int bits, const uint32_t *ring, int l,
+                                       uint32_t *ppos, uint32_t *pa, uint32_t nbits, uint32_t *guard)
+{
+    uint32_t pos = *ppos;
+    uint64_t w = gf_ring_window64(ring, pos);
+    const int down = 64 - bits;
+    uint32_t sy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t e = tab[w >> down];
+        const uint32_t len = e & 63u;
+        pos += len;
+        sy[k] = e;
+        if (__builtin_expect((e & 0x80u) != 0, 1)) { w <<= len; continue; }
+        if (*pa < pos + GF_AHEAD_SLOW) {                    /* the walk may run up to 255 bits further */
+            GF_ST(gf_pos_pub[l], pos);
+            while ((*pa = GF_LD(gf_avail_pub[l])) < pos + GF_AHEAD_SLOW && ++*guard <= GF_SPIN_CAP) __builtin_amdgcn_s_sleep(1);
+        }
+        int id = (int)(e >> 16);
+        w = gf_ring_window64(ring, pos);                   /* the bits behind the table's part of the code */
+        for (uint32_t left = 64; id >= 256; --left) {
+            if (left == 0) { w = gf_ring_window64(ring, pos); left = 64; }
+            const uint32_t bit = pos < nbits ? (uint32_t)(w >> 63) : 0u;
+            id = c->kid[bit][id - 256];
+            w <<= 1; ++pos;
+        }
+        sy[k] = (uint32_t)gc_leaf(c, id) << 16;
+#ifdef GF_PROFILE
+        gf_slow_count++;
+#endif
+    }
+    *ppos = pos;
+    return make_uint2(__builtin_amdgcn_perm(sy[1], sy[0], 0x07060302u), __builtin_amdgcn_perm(sy[3], sy[2], 0x07060302u));
+}
+
+/* the lanes of this wave decode one section each, in lockstep (gf_decode_lane is the same loop for one lane): eight
+ * symbols per round */
+__device__ static void gf_decode_wave(GPic *g, const GCode *codes, int lane, uint32_t lanes)
+{
+    const int nl = g->is_pb ? GF_RLE0 : GF_LANES;
+    const int l = lane < nl ? lane : 0;
+    GLane *q = &g->lane[l];
+    const GCode *c = &codes[q->tree];
+    const bool mine = lane < nl && ((lanes >> lane) & 1u) && c->root >= 256 && !g->status;
+    const uint32_t end = mine ? q->end : 0u, cap = q->cap, nbits = g->nd * 32u;
+    uint32_t pos = q->pos, n = 0, guard = 0;
+    GP_G int16_t *out = g->sym + q->off;
+    const uint32_t *ring = gf_ring(l);
+    const uint32_t *tab = gf_lane_table(c, (int)q->tree);
+    const int bits = gf_lane_bits((int)q->tree);
+#ifdef GF_PROFILE
+    uint64_t ta = 0, tb = 0, rounds = 0;
+#define GF_T(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define GF_T(x)
+#endif
+    for (;;) {
+        GF_T(t0);
+        const bool act = pos < end && n + 8 <= cap;
+        if (!__builtin_amdgcn_ballot_w64(act)) break;
+        if (act) GF_ST(gf_pos_pub[l], pos);
+        uint32_t a;
+        for (;;) {                                                   /* until the stager is far enough ahead of every lane */
+            a = GF_LD(gf_avail_pub[l]);
+            if (!__builtin_amdgcn_ballot_w64(act && a < pos + GF_AHEAD)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++guard > GF_SPIN_CAP) break;
+        }
+        if (guard > GF_SPIN_CAP) { g->status |= GP_ST_BADARG; break; }
+        GF_T(t1);
+        if (act) {
+            const uint2 lo = gf_four(c, tab, bits, ring, l, &pos, &a, nbits, &guard);
+            const uint2 hi = gf_four(c, tab, bits, ring, l, &pos, &a, nbits, &guard);
+            *(GP_G uint4 *)(out + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            n += 8;
+        }
+#ifdef GF_PROFILE
+        { GF_T(t2); ta += t1 - t0; tb += t2 - t1; ++rounds; }
+#endif
+    }
+#ifdef GF_PROFILE
+    if (lane == 0) { g->prof[0] = (uint32_t)ta; g->prof[1] = (uint32_t)tb; g->prof[2] = (uint32_t)rounds | (gf_slow_count << 16); }
+#endif
+    if (mine) q->n = n;
+    if (lane == 0) { g->spins = guard; __hip_atomic_fetch_add(&gf_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+}
+
+/* the staging wave: lane l owns ring l; every round fetches ALL quarters that are missing behind any lane (up to four
+ * per ring), waits for them once and publishes */
+__device__ static void gf_stage_wave(GPic *g, int lane, uint32_t decoders)
+{
+    const int nl = g->is_pb ? GF_RLE0 : GF_LANES;
+    const bool own = lane < nl && !g->status && g->nd > 0;
+    uint32_t have = own ? g->lane[lane < nl ? lane : 0].pos >> 9 : 0u;     /* next quarter (16 dwords) to fetch */
+    const GP_G uint32_t *d = g->d;
+    const uint32_t last = g->nd ? g->nd - 1u : 0u;
+    uint32_t idle = 0;
+    for (;;) {
+        const uint32_t done = GF_LD(gf_done) >= decoders;
+        const uint32_t p = GF_LD(gf_pos_pub[lane & 15]);
+        const uint32_t want = own ? (p >> 9) + 4u : 0u;                  /* quarters up to here may be resident */
+        const bool need = own && have < want;
+        uint64_t mask = __builtin_amdgcn_ballot_w64(need);
+        if (!mask) {
+            if (done || ++idle > GF_SPIN_CAP) break;
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        while (mask) {
+            const int l = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)have, l), k1 = (uint32_t)__builtin_amdgcn_readlane((int)want, l);
+            for (uint32_t k = k0; k < k1 && k < k0 + 4u; ++k) {
+                if (lane < 16) {
+                    uint32_t idx = 16u * k + (uint32_t)lane;
+                    if (idx > last) idx = last;
+                    __builtin_amdgcn_global_load_lds(d + idx, (__attribute__((address_space(3))) uint32_t *)(gf_ring(l) + 16u * (k & 3u)), 4, 0, 0);
+                }
+            }
+        }
+        if (need) have = want < have + 4u ? want : have + 4u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (need) GF_ST(gf_avail_pub[lane], have << 9);
+    }
+}
+
+/* exclusive scan of the 256 chunk partials of `inst` by one wave (four per lane); total -> g->tot[inst] */
+__device__ static inline uint32_t gf_wave_incl_add(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64); if (lane >= d) v += o; }
+    return v;
+}
+
+__device__ static void gfd_scan_add(GPic *g, int inst, int lane, uint32_t *also)
+{
+    GP_G uint4 *p = (GP_G uint4 *)(g->part + GF_P(inst, 0)) + lane;
+    uint4 v = *p;
+    const uint32_t s = v.x + v.y + v.z + v.w;
+    const uint32_t incl = gf_wave_incl_add(s, lane);
+    uint32_t run = incl - s;
+    uint4 o;
+    o.x = run; run += v.x; o.y = run; run += v.y; o.z = run; run += v.z; o.w = run;
+    *p = o;
+    if (lane == 63) { if (inst >= 16) g->tot[inst - 16] = incl; if (also) *also = incl; }
+}
+
+__device__ static void gfd_scan_seg(GPic *g, int inst_flag, int inst_val, int lane)
+{
+    GP_G uint4 *pf = (GP_G uint4 *)(g->part + GF_P(inst_flag, 0)) + lane, *pv = (GP_G uint4 *)(g->part + GF_P(inst_val, 0)) + lane;
+    const uint4 f = *pf, v = *pv;
+    const uint32_t fs[4] = { f.x, f.y, f.z, f.w }, vs[4] = { v.x, v.y, v.z, v.w };
+    uint32_t F = 0, V = 0;                                            /* this lane's four chunks as one */
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { V = fs[k] ? vs[k] : V + vs[k]; F |= fs[k]; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {                                /* inclusive over the lanes */
+        const uint32_t oF = (uint32_t)__shfl_up((int)F, d, 64), oV = (uint32_t)__shfl_up((int)V, d, 64);
+        if (lane >= d) { V = F ? V : oV + V; F |= oF; }
+    }
+    uint32_t run = (uint32_t)__shfl_up((int)V, 1, 64);
+    if (lane == 0) run = 0;
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[k] = run; run = fs[k] ? vs[k] : run + vs[k]; }
+    *pv = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+/* wave64 inclusive prefix sum on the DPP network (all lanes active) */
+__device__ static inline uint32_t gfd_dpp_incl(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+/* gf_emit_merge with consecutive entries on consecutive lanes: a wave owns the entries of its 64 threads' chunks (whose
+ * starting offsets gf_emit_count + the scans have already produced), walks them 64 at a time and gets every entry's
+ * position in the coefficient symbols, in the fixed-length section and among the MC-residual blocks from three wave
+ * scans.  The lanes of one step read neighbouring symbols and words and write neighbouring pool dwords -- a handful of
+ * cache lines per instruction where the chunk-per-thread form touches 64. */
+__device__ static void gfd_emit_merge(GPic *g, int tid)
+{
+    if (g->status || g->retry) return;
+    if (gf_emit_short(g)) { g->retry = 1; return; }
+    const int lane = tid & 63, wave = tid >> 6;
+    GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
+    const int sh_dc = g->dc_shift & 31, sh_unk = g->unk_shift & 31;
+    for (int i = 0; i < 3; ++i) {
+        const GP_G uint32_t *ents = g->pinfo + g->pl[i].blk_first;
+        const GP_G int16_t *S = g->sym + g->lane[GF_BT0 + i].off;
+        const GP_G uint32_t *V = g->val + g->val_off[i] + g->ntype0 * (uint32_t)g->pl[i].nblk;
+        const uint32_t n = g->pl[i].nblocks, per = (n + GPW - 1) / GPW;
+        const uint32_t e0 = per * 64u * (uint32_t)wave < n ? per * 64u * (uint32_t)wave : n;
+        const uint32_t e1 = per * 64u * (uint32_t)(wave + 1) < n ? per * 64u * (uint32_t)(wave + 1) : n;
+        uint64_t fx = g->fx_off[i] + g->part[GF_P(GF_I_FX(i), 64 * wave)];
+        uint32_t si = g->part[GF_P(GF_I_NB(i), 64 * wave)], pi = g->part[GF_P(GF_I_PREDI(i), 64 * wave)];
+        for (uint32_t eb = e0; eb < e1; eb += 64) {
+            const uint32_t e = eb + (uint32_t)lane;
+            const uint32_t ent = e < e1 ? ents[e] : 0u, mode = ent >> 30;
+            const uint32_t nb = mode >= GP_MODE_BASES ? (ent >> 22) & 0xFFu : 0u, fb = gp_ent_fx_bytes(ent), ip = mode == GP_MODE_PREDI;
+            const uint32_t s_nb = gfd_dpp_incl(nb), s_fb = gfd_dpp_incl(fb), s_ip = gfd_dpp_incl(ip);
+            const uint32_t my_si = si + s_nb - nb, my_pi = pi + s_ip - ip;
+            const uint64_t my_fx = fx + (s_fb - fb);
+            si += (uint32_t)__builtin_amdgcn_readlane((int)s_nb, 63);
+            fx += (uint32_t)__builtin_amdgcn_readlane((int)s_fb, 63);
+            pi += (uint32_t)__builtin_amdgcn_readlane((int)s_ip, 63);
+            if (mode == GP_MODE_NONE) continue;
+            GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
+            if (mode == GP_MODE_LITERAL) {
+                uint32_t v[4];
+                for (int k = 0; k < 4; ++k) v[k] = __builtin_bswap32(gp_be32(g, my_fx + 4u * (uint32_t)k));
+                for (int k = 0; k < 4; ++k) dst[k] = v[k];
+                continue;
+            }
+            if (mode == GP_MODE_PREDI) {
+                const int32_t s1 = (int32_t)V[2u * my_pi], s2 = (int32_t)V[2u * my_pi + 1u];
+                dst[0] = (uint32_t)(s1 >> sh_dc) << sh_unk;
+                dst[1] = (uint32_t)(s2 >> sh_dc);
+                dst += 2;
+            }
+            uint32_t run = 0;
+            for (uint32_t k0 = 0; k0 < nb; k0 += 4) {
+                uint32_t w[4];
+                int32_t sv[4];
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const int live = k0 + j < nb;
+                    w[j] = live ? gp_be16(g, my_fx + 2u * (k0 + j)) : 0u;
+                    sv[j] = live ? S[my_si + k0 + j] : 0;
+                }
+                for (uint32_t j = 0; j < 4; ++j) {
+                    run += (uint32_t)sv[j];
+                    if (k0 + j < nb) dst[k0 + j] = HVQ_BASIS(w[j], (run + ((w[j] >> 13) & 3u)) & 0x3FFFFu);
+                }
+            }
+        }
+    }
+}
+
+/* one wave: scan of the threads' tile totals, maxima and flags of the layout, then sizes and header (gf_layout_finish) */
+__device__ static void gfd_layout_finish(GPic *g, int lane)
+{
+    if (g->status || g->retry) return;
+    gfd_scan_add(g, GF_I_LS, lane, 0);
+    const uint4 a = *((const GP_G uint4 *)(g->part + GF_P(GF_I_MI, 0)) + lane), b = *((const GP_G uint4 *)(g->part + GF_P(GF_I_MP, 0)) + lane);
+    const uint4 f0 = *((const GP_G uint4 *)g->part + lane);
+    uint32_t mi = max(max(a.x, a.y), max(a.z, a.w)), mp = max(max(b.x, b.y), max(b.z, b.w)), fl = f0.x | f0.y | f0.z | f0.w;
+    if (g->is_pb) { const uint4 f1 = *((const GP_G uint4 *)(g->part + GP_PART2) + lane); fl |= f1.x | f1.y | f1.z | f1.w; }
+    else fl |= g->part[GP_MISC + 2 * GC_COUNT];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mi = max(mi, (uint32_t)__shfl_xor((int)mi, d, 64));
+        mp = max(mp, (uint32_t)__shfl_xor((int)mp, d, 64));
+        fl |= (uint32_t)__shfl_xor((int)fl, d, 64);
+    }
+    const uint32_t off = (uint32_t)__shfl((int)(g->tot[GF_I_LS - 16]), 0, 64);   /* written by lane 63 just now: LDS is in order within the wave */
+    gp_layout_finish(g, off, fl, mi, mp);
+}
+
+/* I picture: DC prediction of plane i by one wave (gf_idc_predict is the raster form).  value(by, bx) needs its left and
+ * upper neighbours, so the cells of an anti-diagonal are independent: bands of 16 rows, lane = row, lane L works on
+ * column t - L in step t and gets the value above from lane L - 1's previous step.  The deltas of 16 columns x 16 rows
+ * are fetched one block ahead by all 64 lanes into a three-block ring in LDS (`tile`, 192 dwords). */
+#define GF_LDS __attribute__((address_space(3)))
+#define GF_WAVE_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+__device__ static void gf_idc_predict_wave(GPic *g, int i, uint8_t *rowbuf, uint32_t *tile, int lane)
+{
+    if (g->status || g->retry) return;
+    const GPlane *q = &g->pl[i];
+    const int hb = q->hb, vb = q->vb;
+    GF_LDS uint8_t *tb = (GF_LDS uint8_t *)tile;                      /* [3][16 rows][16 columns] */
+    GF_LDS uint8_t *rb = (GF_LDS uint8_t *)rowbuf;
+    const int lrow = lane >> 2, lpart = lane & 3;
+    for (int r0 = 0; r0 < vb; r0 += 16) {
+        const int nr = vb - r0 < 16 ? vb - r0 : 16;
+        const int by = r0 + lane;
+        const bool rowlive = lane < nr;
+        GP_G uint8_t *myrow = gp_map_ent(g, i, rowlive ? by : r0, 0);
+        const GP_G uint8_t *ldrow = gp_map_ent(g, i, lrow < nr ? r0 + lrow : r0, 0);
+        uint32_t pend = 0;                                            /* the four deltas this lane fetched for the next block */
+        for (int k = 0; k < 4; ++k) { const int bx = 4 * lpart + k; if (lrow < nr && bx < hb) pend |= (uint32_t)ldrow[2 * bx] << (8 * k); }
+        uint32_t left = 0, cur = 0;
+        const int steps = hb + nr - 1;
+        for (int t = 0; t < steps; ++t) {
+            if ((t & 15) == 0) {
+                const int c = t >> 4;
+                ((GF_LDS uint32_t *)tb)[(c % 3) * 64 + lrow * 4 + lpart] = pend;
+                uint32_t v = 0;
+                for (int k = 0; k < 4; ++k) { const int bx = 16 * (c + 1) + 4 * lpart + k; if (lrow < nr && bx < hb) v |= (uint32_t)ldrow[2 * bx] << (8 * k); }
+                pend = v;
+                GF_WAVE_SYNC();
+            }
+            const uint32_t up = (uint32_t)__shfl_up((int)cur, 1, 64);
+            const int bx = t - lane;
+            if (rowlive && bx >= 0 && bx < hb) {
+                const uint32_t delta = tb[((bx >> 4) % 3) * 256 + lane * 16 + (bx & 15)];
+                const uint32_t above = by == 0 ? 0x7Fu : (lane == 0 ? rb[bx] : up);
+                const uint32_t pred = bx == 0 ? above : (left + above + 1u) >> 1;
+                const uint32_t v = (pred + delta) & 0xFFu;
+                myrow[2 * bx] = (uint8_t)v;
+                if (lane == nr - 1) rb[bx] = (uint8_t)v;
+                left = v; cur = v;
+            }
+        }
+        GF_WAVE_SYNC();
+    }
+}
+
+/* ------------------------------------------------------------------ the kernel */
+extern "C" __global__ __launch_bounds__(GPW) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
 void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__restrict__ results, uint32_t rowbuf_stride,
-                      uint64_t *__restrict__ timing)     /* optional: 16 phase timestamps per picture (100 MHz clock) */
+                      uint32_t use_flat, uint64_t *__restrict__ timing)     /* optional: 16 phase timestamps per picture (100 MHz clock) */
 {
 #define GP_STAMP(k) do { if (timing && tid == 0) timing[16 * blockIdx.x + (k)] = wall_clock64(); } while (0)
     extern __shared__ uint8_t s_rowbuf[];            /* 3 * rowbuf_stride */
     __shared__ GPic g;
-    __shared__ GCode codes[GC_COUNT];
+    GCode *codes = (GCode *)(gp_stage + GP_STAGE_DWORDS);              /* the six trees follow the staging slots */
 
     const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         /* uniform: chains are selected per wave */
+    /* which wave decodes: rotated over the pictures so that the decoders of a CU's 8 workgroups spread over its 4 SIMDs.
+     * Workgroup b runs on XCD b % 8; whether an XCD deals its workgroups b / 8 to its 32 CUs one each in turn or eight at a
+     * time, the sum below takes all four values among the workgroups that share a CU. */
+    const int role = (wave + (int)(((blockIdx.x >> 3) + (blockIdx.x >> 8)) & 3u)) & 3;
     const HvqParseJob *job = jobs + blockIdx.x;
+    int flat = (int)use_flat;
+    uint32_t retried = 0;
 
+again:
     GP_STAMP(0);
     if (wave == 0) {
         gp_setup(&g, job);
         if ((uint32_t)(g.pl[0].hb + 2) > rowbuf_stride) g.status |= GP_ST_BADARG;
         gp_sections(&g);
+        if (flat) { g.mtype.slot = GF_SIDE_SLOT; g.mproc.slot = GF_SIDE_SLOT + 1u; }     /* they run beside the rings */
+
         GP_ST(g.part[GP_MISC + 13], 0u); GP_ST(g.part[GP_MISC + 14], 0u);
     } else {   /* tree tables start from zero: a malformed tree must not steer a walk through stale LDS */
         uint32_t *w = (uint32_t *)codes;
-        for (int k = tid - 64; k < (int)(sizeof(codes) / 4); k += GPW - 64) w[k] = 0;
+        for (int k = tid - 64; k < (int)(GC_COUNT * sizeof(GCode) / 4); k += GPW - 64) w[k] = 0;
     }
     __syncthreads();
     gp_init_maps(&g, tid, GPW);
@@ -59,8 +431,175 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
     __syncthreads();
     if (wave == 0) gp_collect_tree_status(&g, ntrees);
     for (int c = 0; c < ntrees; ++c) gc_fill_lut(&codes[c], tid, GPW);
+    if (flat) gf_fill_xlut(&g, codes, tid, GPW);
     __syncthreads();
     GP_STAMP(1);
+
+    if (is_pb && !flat) {
+        if (wave == 0) gp_mbtypes(&g, codes);
+        else if (wave == 1) gp_mbprocs(&g, codes);
+        __syncthreads();
+        GP_STAMP(2);
+        gp_tags_count(&g, tid, GPW);
+        __syncthreads();
+        if (wave == 0) gp_tags_scan(&g, GPW);
+        __syncthreads();
+        gp_tags_assign(&g, tid, GPW);
+        __syncthreads();
+        if (wave == 0) gp_lists_scan(&g, GPW);
+        __syncthreads();
+        gp_lists_write(&g, tid, GPW);
+        __syncthreads();
+        GP_STAMP(12);
+    }
+
+    if (flat) {
+        if (wave == 0) {
+            gf_setup_lanes(&g);
+            if (lane < 16) {
+                const uint32_t p = lane < GF_LANES ? g.lane[lane].pos : 0u;
+                GF_ST(gf_pos_pub[lane], p); GF_ST(gf_avail_pub[lane], (p >> 9) << 9);
+            }
+            GF_ST(gf_done, 0u); GF_ST(gf_types_done, 0u);
+#ifdef GF_PROFILE
+            gf_slow_count = 0;
+#endif
+        }
+        __syncthreads();
+        /* all prefix-coded sections at once: one wave stages the bitstream, one decodes (I: two -- the DC sections, whose
+         * rare long codes would hold the other lanes up, have their own); P/B: the type and proc runs beside them */
+        if (!is_pb) {
+            const uint32_t dc_lanes = 7u << GF_DC0;
+            if (role == 0) { gf_decode_wave(&g, codes, lane, ~dc_lanes); if (timing && lane == 0) timing[16 * blockIdx.x + 5] = wall_clock64(); }
+            else if (role == 2) gf_decode_wave(&g, codes, lane, dc_lanes);
+            else if (role == 1) gf_stage_wave(&g, lane, 2u);
+        } else {
+            if (role == 0) { gf_decode_wave(&g, codes, lane, ~0u); if (timing && lane == 0) timing[16 * blockIdx.x + 5] = wall_clock64(); }
+            else if (role == 1) gf_stage_wave(&g, lane, 1u);
+            else {
+                /* the type runs, then the x components of the vectors (which need nothing but the type bytes); the proc runs,
+                 * then -- once the types are there -- the y components */
+                const int comp = role - 2;
+                if (comp == 0) {
+                    gp_mbtypes(&g, codes);
+                    if (timing && lane == 0) timing[16 * blockIdx.x + 2] = wall_clock64();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    GF_ST(gf_types_done, 1u);
+                } else {
+                    gp_mbprocs(&g, codes);
+                    for (uint32_t spin = 0; !GF_LD(gf_types_done) && spin < GF_SPIN_CAP; ++spin) __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                GBits *b = comp ? &g.mvv : &g.mvh;
+                b->slot = GF_SIDE_SLOT + (uint32_t)comp; b->base = ~0u;
+                const uint32_t f = gp_mvs(&g, codes, comp, GF_SIDE_SLOT + 2u + (uint32_t)comp);
+                GP_ST(g.part[GP_MISC + 13 + comp], f);
+                if (timing && lane == 0) timing[16 * blockIdx.x + (comp ? 15 : 11)] = wall_clock64();
+            }
+        }
+        __syncthreads();
+        GP_STAMP(13);
+        if (is_pb) {
+            gp_tags_count(&g, tid, GPW);
+            __syncthreads();
+            if (wave == 0) gp_tags_scan(&g, GPW);
+            __syncthreads();
+            gp_tags_assign(&g, tid, GPW);
+            __syncthreads();
+            if (wave == 0) gp_lists_scan(&g, GPW);
+            __syncthreads();
+            gp_lists_write(&g, tid, GPW);
+            __syncthreads();
+            GP_STAMP(12);
+        }
+        __syncthreads();
+        if (wave == 0) gf_fill_const_counts(&g, codes);
+        gf_fill_const(&g, codes, tid, GPW);
+        __syncthreads();
+        /* round 1: DC symbols -> value ends | kinds: zero tokens */
+        gf_dc_count(&g, tid, GPW);
+        gf_exp_zeros(&g, 0, 2, tid, GPW);
+        __syncthreads();
+        if (!g.retry && !g.status) {
+            for (int k = wave; k < 8; k += 4) {
+                if (k < 3) gfd_scan_add(&g, GF_I_TERM(k), lane, &g.nv[k]);
+                else if (k < 5) gfd_scan_add(&g, GF_I_ZERO(k - 3), lane, 0);
+                else gfd_scan_seg(&g, GF_I_DCF(k - 5), GF_I_DCV(k - 5), lane);
+            }
+        }
+        __syncthreads();
+        /* round 2: values | kinds: blocks covered */
+        gf_dc_values(&g, tid, GPW);
+        gf_exp_lens(&g, 0, 2, tid, GPW);
+        __syncthreads();
+        if (!g.retry && !g.status && wave < 2) gfd_scan_add(&g, GF_I_LEN(wave), lane, 0);
+        __syncthreads();
+        if (!is_pb) {
+            gf_exp_write(&g, 0, 2, tid, GPW);
+            gf_exp_zeros(&g, 2, 5, tid, GPW);
+            __syncthreads();
+            if (!g.retry && !g.status && wave < 3) gfd_scan_add(&g, GF_I_ZERO(2 + wave), lane, 0);
+            __syncthreads();
+            gf_exp_lens(&g, 2, 5, tid, GPW);
+            __syncthreads();
+            if (!g.retry && !g.status && wave < 3) gfd_scan_add(&g, GF_I_LEN(2 + wave), lane, 0);
+            __syncthreads();
+            gf_exp_write(&g, 2, 5, tid, GPW);
+            __syncthreads();
+            GP_STAMP(14);
+            if (wave < 3) gf_idc_predict_wave(&g, wave, s_rowbuf + wave * rowbuf_stride, gp_stage + 192 * wave, lane);
+            __syncthreads();
+            GP_STAMP(3);
+            if (!g.retry) gp_nest(&g, tid, GPW);
+        } else {
+            gf_exp_write(&g, 0, 2, tid, GPW);
+            gf_pbdc_sums(&g, tid, GPW);
+            __syncthreads();
+            if (!g.retry && !g.status && wave < 3) gfd_scan_seg(&g, GF_I_PBF(wave), GF_I_PBV(wave), lane);
+            __syncthreads();
+            gf_pbdc_write(&g, tid, GPW);
+            __syncthreads();
+            GP_STAMP(3);
+        }
+        if (!g.retry) {
+            gf_layout_sum(&g, tid, GPW);
+            __syncthreads();
+            GP_STAMP(4);
+            if (wave == 0) gfd_layout_finish(&g, lane);
+            __syncthreads();
+            GP_STAMP(8);
+            gf_layout_blocks(&g, tid, GPW);
+            __syncthreads();
+            GP_STAMP(9);
+            gf_emit_count(&g, tid, GPW);
+            __syncthreads();
+            GP_STAMP(10);
+            if (!g.status) {
+                for (int k = wave; k < 9; k += 4) {
+                    const int i = k / 3, what = k - 3 * i;
+                    gfd_scan_add(&g, what == 0 ? GF_I_FX(i) : (what == 1 ? GF_I_NB(i) : GF_I_PREDI(i)), lane, 0);
+                }
+            }
+            __syncthreads();
+            GP_STAMP(6);
+            gfd_emit_merge(&g, tid);
+            __syncthreads();
+        }
+        if (g.retry && !g.status) {                     /* uniform: every thread reads it after the barrier */
+            __syncthreads();
+            flat = 0; retried = 1;
+            goto again;
+        }
+        GP_STAMP(7);
+        if (tid == 0) {
+            gp_result(&g, (GP_G HvqParseResult *)(results + blockIdx.x), g.part[GP_MISC + 13] | g.part[GP_MISC + 14]);
+            results[blockIdx.x].pad[0] = retried; results[blockIdx.x].pad[1] = g.spins;
+#ifdef GF_PROFILE
+            if (timing) { timing[16 * blockIdx.x + 9] = g.prof[0]; timing[16 * blockIdx.x + 10] = g.prof[1]; timing[16 * blockIdx.x + 6] = g.prof[2]; }
+#endif
+        }
+        return;
+    }
 
     if (!is_pb) {
         if (wave < 2) gp_ikinds(&g, codes, wave);
@@ -86,21 +625,6 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         if (wave == 0) gp_payload(&g, codes, 0);
         else if (wave == 1) { gp_payload(&g, codes, 1); gp_payload(&g, codes, 2); }
     } else {
-        if (wave == 0) gp_mbtypes(&g, codes);
-        else if (wave == 1) gp_mbprocs(&g, codes);
-        __syncthreads();
-        GP_STAMP(2);
-        gp_tags_count(&g, tid, GPW);
-        __syncthreads();
-        if (wave == 0) gp_tags_scan(&g, GPW);
-        __syncthreads();
-        gp_tags_assign(&g, tid, GPW);
-        __syncthreads();
-        if (wave == 0) gp_lists_scan(&g, GPW);
-        __syncthreads();
-        gp_lists_write(&g, tid, GPW);
-        __syncthreads();
-        GP_STAMP(12);
         if (wave < 2) gp_pbkinds(&g, codes, wave);
         else if (wave == 2) gp_pbdc(&g, codes, 0);
         else { gp_pbdc(&g, codes, 1); gp_pbdc(&g, codes, 2); }
@@ -132,11 +656,11 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
         if (wave == 0) gp_payload(&g, codes, 0);
         else if (wave == 1) { gp_payload(&g, codes, 1); gp_payload(&g, codes, 2); gp_predi_params(&g, codes, 0); }
         else if (wave == 2) {
-            const uint32_t fx = gp_mvs(&g, codes, 0);
+            const uint32_t fx = gp_mvs(&g, codes, 0, 17u);
             GP_ST(g.part[GP_MISC + 13], fx);
             gp_predi_params(&g, codes, 1); gp_predi_params(&g, codes, 2);
         } else {
-            const uint32_t fy = gp_mvs(&g, codes, 1);
+            const uint32_t fy = gp_mvs(&g, codes, 1, 18u);
             GP_ST(g.part[GP_MISC + 14], fy);
         }
     }
@@ -145,7 +669,10 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
     gp_emit_merge(&g, tid, GPW);
     __syncthreads();
     GP_STAMP(7);
-    if (tid == 0) gp_result(&g, (GP_G HvqParseResult *)(results + blockIdx.x), g.part[GP_MISC + 13] | g.part[GP_MISC + 14]);
+    if (tid == 0) {
+        gp_result(&g, (GP_G HvqParseResult *)(results + blockIdx.x), g.part[GP_MISC + 13] | g.part[GP_MISC + 14]);
+        results[blockIdx.x].pad[0] = retried;
+    }
 #undef GP_STAMP
 }
 
@@ -160,11 +687,11 @@ void hvq_nest_commit_kernel(const uint64_t *__restrict__ pairs)
 }
 
 extern "C" hipError_t hvq_launch_parse(const HvqParseJob *jobs_dev, HvqParseResult *results_dev, uint32_t n,
-                                       uint32_t rowbuf_stride, uint64_t *timing_dev, hipStream_t stream)
+                                       uint32_t rowbuf_stride, uint32_t use_flat, uint64_t *timing_dev, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(hvq_parse_kernel, dim3(n), dim3(GPW), 3 * (size_t)rowbuf_stride, stream, jobs_dev, results_dev,
-                       rowbuf_stride, timing_dev);
+                       rowbuf_stride, use_flat, timing_dev);
     return hipGetLastError();
 }
 

@@ -95,13 +95,25 @@ typedef struct HvqParseResult {   /* what the host needs back to size and order 
  * instead of one per 4.  (Keeping look-ahead dwords in registers does not work: the compiler's register copies of a
  * freshly requested dword make it wait for the load on the spot.) */
 #define GP_BLK 32
-#define GP_SLOTS 19           /* 14 bitstream cursors + 5 list readers (GList) */
+#define GP_SLOTS 24           /* chains: 14 bitstream cursors + 5 list readers (GList), slots 0-18; 20-23: the chains that run
+                                 beside the flat path's rings, which lie over slots 0-19 */
+#define GP_STAGE_DWORDS (GP_SLOTS * GP_BLK)
+/* On the device the staging slots and the six trees (GCode, 640 dwords each) are ONE LDS block, trees behind the slots,
+ * so that the flat path (hvq_gparse_flat.h, hvq_gparse.hip) can lay its lanes' rings of 64 dwords over the slots
+ * (lanes 0-9) and, in an I picture, over the two trees an I picture does not have (lanes 10-12 in tree GC_MV), and give
+ * the vector chains that run beside the lanes of a P/B picture slots inside the tree GC_MCB, which is done with by then:
+ * slot s >= GP_SLOTS is 32 dwords at gp_stage + 32 s all the same. */
+#define GP_CODE_DWORDS 514u                                              /* sizeof(GCode) / 4 */
+#define GP_XLUT_BITS 9                                                   /* the coefficient tree's table for the flat path: 512 entries behind the trees */
+#define GP_XLUT_DWORD ((uint32_t)GP_STAGE_DWORDS + 6u * GP_CODE_DWORDS)
+#define GP_TREE_DWORD(t) ((uint32_t)GP_STAGE_DWORDS + GP_CODE_DWORDS * (uint32_t)(t))
+#define GP_TREE_SLOT(t) ((GP_TREE_DWORD(t) + 1u + 31u) / 32u)            /* first whole slot inside tree t, past its root */
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-__shared__ uint32_t gp_stage[GP_SLOTS * GP_BLK];
+__shared__ uint32_t gp_stage[GP_STAGE_DWORDS + 6 * GP_CODE_DWORDS + (1 << GP_XLUT_BITS)];
 #define GP_LANE() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
 #else
-static uint32_t gp_stage[GP_SLOTS * GP_BLK];
+static uint32_t gp_stage[GP_STAGE_DWORDS + 6 * GP_CODE_DWORDS + (1 << GP_XLUT_BITS)];
 #endif
 
 typedef struct {
@@ -188,30 +200,36 @@ GP_FN uint32_t gl_next(GList *l)
 /* ------------------------------------------------------------------ prefix trees (h4m:385-394, 604-651) */
 typedef struct {
     int root;
+    uint8_t sgn, scale, pad[2];         /* leaf byte -> value (h4m:613-617), gc_leaf */
     uint32_t lut[1 << GP_LUT_BITS];     /* [5:0] bits consumed, [7] leaf reached, [31:16] leaf VALUE (int16) or node id;
                                            one LDS read decodes a short code.  Doubles as the tree reader's stack. */
-    uint16_t kid[2][256];               /* children of node ids 256..511 */
-    int16_t leaf[256];
+    uint16_t kid[2][256];               /* children of node ids 256..511; a child below 256 is a leaf byte */
 } GCode;
+typedef char gp_code_size_check[sizeof(GCode) == 4u * GP_CODE_DWORDS ? 1 : -1];
+
+/* value of leaf byte `b`: int16 truncation of the shifted (signed) byte, h4m:613-617 */
+GP_FN int32_t gc_leaf(const GCode *c, int b)
+{
+    const int v = (c->sgn && b > 0x7F) ? b - 256 : b;
+    return (int16_t)((uint32_t)v << c->scale);
+}
 
 /* serial: read the tree that heads `carrier` (h4m:604-642); iterative form of hvq_parse.c code_node */
 GP_FN void gc_read(GCode *c, GBits *carrier, int is_signed, int scale, uint32_t *status, uint32_t *flags)
 {
-    c->root = 0;
-    if (!carrier->live) { c->leaf[0] = 0; (void)flags; return; }
+    c->root = 0; c->sgn = 0; c->scale = 0;        /* a tree from an empty section: leaf byte 0, value 0 */
+    if (!carrier->live) { (void)flags; return; }
+    c->sgn = (uint8_t)is_signed; c->scale = (uint8_t)scale;
     uint16_t *stk = (uint16_t *)c->lut;
     int sp = 0, next = 0x100;
     for (;;) {
         int val;
         if (gb_take(carrier, 1) == 0) {
-            const int byte = (int)gb_take(carrier, 8);
-            const int v = (is_signed && byte > 0x7F) ? byte - 256 : byte;
-            c->leaf[byte] = (int16_t)((uint32_t)v << scale);          /* int16 truncation: h4m:613-617 */
-            val = byte;
+            val = (int)gb_take(carrier, 8);
         } else {
             /* a tree over 256 leaf bytes has at most 255 inner nodes (ids 256..510) and so nests at most 255 deep;
              * anything more is malformed, and would let node 511 become its own child (an endless walk in gsym) */
-            if (next >= 511 || sp >= 256) { *status |= GP_ST_BADTREE; c->root = 0; return; }
+            if (next >= 511 || sp >= 256) { *status |= GP_ST_BADTREE; c->root = 0; c->sgn = 0; c->scale = 0; return; }
             const int id = next++;
             stk[sp++] = (uint16_t)id;
             continue;
@@ -228,16 +246,18 @@ GP_FN void gc_read(GCode *c, GBits *carrier, int is_signed, int scale, uint32_t 
     }
 }
 
-/* parallel: thread `tid` of `nthr` fills its share of the first-level table */
-GP_FN void gc_fill_lut(GCode *c, int tid, int nthr)
+/* parallel: thread `tid` of `nthr` fills its share of a first-level table of `bits` index bits */
+GP_FN void gc_fill_table(const GCode *c, uint32_t *tab, int bits, int tid, int nthr)
 {
     const int root = c->root;
-    for (int e = tid; e < (1 << GP_LUT_BITS); e += nthr) {
+    for (int e = tid; e < (1 << bits); e += nthr) {
         int node = root, d = 0;
-        while (node >= 256 && d < GP_LUT_BITS) { node = c->kid[(e >> (GP_LUT_BITS - 1 - d)) & 1][node - 256]; ++d; }
-        c->lut[e] = node < 256 ? ((uint32_t)d | 0x80u | ((uint32_t)(uint16_t)c->leaf[node] << 16)) : ((uint32_t)d | ((uint32_t)node << 16));
+        while (node >= 256 && d < bits) { node = c->kid[(e >> (bits - 1 - d)) & 1][node - 256]; ++d; }
+        tab[e] = node < 256 ? ((uint32_t)d | 0x80u | ((uint32_t)(uint16_t)gc_leaf(c, node) << 16)) : ((uint32_t)d | ((uint32_t)node << 16));
     }
 }
+
+GP_FN void gc_fill_lut(GCode *c, int tid, int nthr) { gc_fill_table(c, c->lut, GP_LUT_BITS, tid, nthr); }
 
 GP_FN int32_t gsym(const GCode *c, GBits *b)                                   /* h4m:644-651 */
 {
@@ -254,7 +274,7 @@ GP_FN int32_t gsym(const GCode *c, GBits *b)                                   /
         b->acc <<= 1;
         b->cnt--;
     }
-    return c->leaf[id];
+    return gc_leaf(c, id);
 }
 
 GP_FN int32_t gsym_sovf(const GCode *c, GBits *b, int32_t lo, int32_t hi)      /* h4m:654-664 */
@@ -275,6 +295,19 @@ GP_FN int32_t gsym_uovf(const GCode *c, GBits *b, int cap)                      
 }
 
 /* ------------------------------------------------------------------ per-picture state (LDS on the device) */
+/* one lane of the flat symbol decode (hvq_gparse_flat.h): a prefix-coded section decoded front to back into an
+ * int16 array, independently of every other section */
+#define GF_LANES 13
+#define GP_TOTS 32                 /* totals of the scan instances 16..47 (hvq_gparse_flat.h) */
+typedef struct {
+    uint32_t pos;                /* bit position of the next symbol, from the start of the picture */
+    uint32_t end;                /* decode while pos < end (heuristic: the next section's header; never past the data) */
+    uint32_t cap;                /* symbols the array can take (multiple of 8) */
+    uint32_t n;                  /* out: symbols decoded */
+    uint32_t tree;               /* GC_* */
+    uint32_t off;                /* first symbol in GPic.sym */
+} GLane;
+
 typedef struct {
     int hb, vb, stride;
     int bx_per, by_per, nblk;
@@ -319,11 +352,21 @@ typedef struct {
     uint32_t ncoded, ntype0;     /* entries of cmb / t0 */
     uint32_t nks[2];             /* coded kinds found by the kinds chains (luma, chroma) */
     GBits bn[2], bnr[2], dc[3], bt[3], rle[3], mvh, mvv, mtype, mproc;
+    /* flat path (hvq_gparse_flat.h) */
+    uint32_t sec_pay[17];        /* payload start (byte) of every section, for the lanes' end heuristics */
+    GLane lane[GF_LANES];
+    GP_G int16_t *sym;           /* the lanes' symbol arrays */
+    GP_G uint32_t *val;          /* grouped DC-buffer values, per plane at val_off[] */
+    uint32_t val_off[3], nv[3];
+    uint32_t tot[GP_TOTS];       /* totals of the scans */
+    uint32_t retry;              /* the flat path cannot serve this picture: decode it with the chains */
+    uint32_t spins;              /* development aid: rounds the decode wave waited for the staging wave */
+    uint32_t prof[3];
 } GPic;
 
 /* part[]: [0, 512) one word per thread, [512, 992) a second word per thread, [992, 1024) single-purpose slots,
  * [1024, 4096) GP_EP: per plane and thread, the partial sums of the payload emission */
-#define GP_PART 4096
+#define GP_PART 16384
 #define GP_PART2 512
 #define GP_MISC 992
 #define GP_EP(plane, which, tid) (1024 + ((plane) * 2 + (which)) * 512 + (tid))
@@ -340,10 +383,22 @@ GP_FN uint32_t gp_be32(const GPic *g, uint64_t off)
 
 GP_FN uint32_t gp_byte(const GPic *g, uint32_t off) { return (gp_be32(g, off & ~3u) >> (24 - 8 * (off & 3u))) & 0xFFu; }
 
+/* capacities of the flat path's arrays (symbols per lane, multiples of 8 so that every array starts 16-byte aligned):
+ * block kinds and their runs one per block, DC buffer three per block (P/B: one value per intra block, two per
+ * MC-residual block, and room for overflow symbols), coefficient symbols eight per block, DC runs one per block.
+ * A picture that needs more is decoded by the chains. */
+#define GP_CAP8(x) (((x) + 15u) & ~7u)
+#define GP_CAP_BN(nb)  GP_CAP8(nb)
+#define GP_CAP_DC(nb)  GP_CAP8(3u * (nb))
+#define GP_CAP_BT(nb)  GP_CAP8(8u * (nb))
+#define GP_SYM_TOTAL(tb) (14u * (tb) + 13u * 16u)
+#define GP_VAL_TOTAL(tb) (3u * (tb) + 3u * 16u)
+
 /* bytes of scratch one picture of this geometry needs */
 GP_FN uint32_t gp_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb)
 {
-    return GP_ALIGN16(4u * total_blocks) * 2u + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb + 16u) * 3u + GP_ALIGN16(4u * nmb + 16u) * 2u + 4u * GP_PART;
+    return GP_ALIGN16(4u * total_blocks) * 2u + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb + 16u) * 3u + GP_ALIGN16(4u * nmb + 16u) * 2u + 4u * GP_PART
+         + GP_ALIGN16(2u * GP_SYM_TOTAL(total_blocks)) + GP_ALIGN16(4u * GP_VAL_TOTAL(total_blocks));
 }
 
 /* serial (thread 0): geometry exactly as hvq_parser_create lays the blob out */
@@ -398,7 +453,10 @@ GP_FN void gp_setup(GPic *g, const HvqParseJob *job)
     g->mbtag = s;                        s += GP_ALIGN16(nmb + 16u);
     g->cmb = (GP_G uint32_t *)s;         s += GP_ALIGN16(4u * nmb + 16u);
     g->t0 = (GP_G uint32_t *)s;          s += GP_ALIGN16(4u * nmb + 16u);
-    g->part = (GP_G uint32_t *)s;
+    g->part = (GP_G uint32_t *)s;        s += 4u * GP_PART;
+    g->sym = (GP_G int16_t *)s;          s += GP_ALIGN16(2u * GP_SYM_TOTAL(blocks));
+    g->val = (GP_G uint32_t *)s;
+    g->retry = 0; g->ncoded = 0; g->ntype0 = 0; g->spins = 0;
     g->flags = 0; g->status = 0; g->max_items = 0; g->max_pairs = 0; g->pool_dwords = 0; g->total = 0;
     if (g->cap < g->fixed_bytes || g->len < 8 + 0x44 + 4) g->status |= GP_ST_BADARG;
 }
@@ -412,10 +470,11 @@ GP_FN uint64_t gp_section(const GPic *g, uint32_t data_off, uint32_t tab_off, in
     return s + 4;
 }
 
-GP_FN void gp_section_bits(const GPic *g, GBits *b, uint32_t data_off, uint32_t tab_off, int i, uint32_t slot)
+GP_FN void gp_section_bits(GPic *g, GBits *b, uint32_t data_off, uint32_t tab_off, int i, uint32_t slot)
 {
     int live;
     const uint64_t s = gp_section(g, data_off, tab_off, i, &live);
+    g->sec_pay[i] = (uint32_t)s;
     gb_init(b, g->d, g->nd, s, live, slot);
 }
 
@@ -426,6 +485,7 @@ GP_FN void gp_sections(GPic *g)
     g->dc_shift = (int)gp_byte(g, 0);
     g->unk_shift = (int)gp_byte(g, 1);
     const uint32_t tab = 8, data = g->is_pb ? 8 + 0x44 : 8 + 0x40;
+    for (int i = 0; i < 17; ++i) g->sec_pay[i] = g->len;
     if (g->is_pb) {
         g->res[0] = (uint8_t)gp_byte(g, 2); g->res[1] = (uint8_t)gp_byte(g, 4);
         g->res[2] = (uint8_t)gp_byte(g, 3); g->res[3] = (uint8_t)gp_byte(g, 5);
@@ -442,7 +502,7 @@ GP_FN void gp_sections(GPic *g)
     for (int k = 0; k < 3; ++k) {
         gp_section_bits(g, &g->dc[k], data, tab, 4 + 3 * k, 4u + (uint32_t)k);
         gp_section_bits(g, &g->bt[k], data, tab, 5 + 3 * k, 7u + (uint32_t)k);
-        { int live; g->fx_off[k] = gp_section(g, data, tab, 6 + 3 * k, &live); }
+        { int live; g->fx_off[k] = gp_section(g, data, tab, 6 + 3 * k, &live); g->sec_pay[6 + 3 * k] = (uint32_t)g->fx_off[k]; }
     }
     if (g->is_pb) {
         gp_section_bits(g, &g->mvh, data, tab, 13, 10u);
@@ -655,6 +715,8 @@ GP_FN void gp_layout_sum(GPic *g, int tid, int nthr)
     g->part[tid] = fl;
 }
 
+GP_FN void gp_layout_finish(GPic *g, uint32_t off, uint32_t fl, uint32_t mi, uint32_t mp);
+
 /* serial L2 (thread 0): exclusive scan of the runs, per-tile maxima, sizes, overflow check, header */
 GP_FN void gp_layout_scan(GPic *g, int nthr)
 {
@@ -673,6 +735,12 @@ GP_FN void gp_layout_scan(GPic *g, int nthr)
     }
     if (g->is_pb) { for (int t = 0; t < nthr; ++t) fl |= g->part[GP_PART2 + t]; }      /* HVQ_F_SELF_REF, gp_tags_assign */
     else fl |= g->part[GP_MISC + 2 * GC_COUNT];                                      /* nest origin clamp, gp_nest */
+    gp_layout_finish(g, off, fl, mi, mp);
+}
+
+/* serial (uniform): sizes, overflow check, header, from the totals of the layout */
+GP_FN void gp_layout_finish(GPic *g, uint32_t off, uint32_t fl, uint32_t mi, uint32_t mp)
+{
     g->flags |= fl;
     g->max_items = mi; g->max_pairs = mp; g->pool_dwords = off;
     uint64_t total = (uint64_t)g->fixed_bytes + 4u * (uint64_t)off;
@@ -1121,7 +1189,7 @@ GP_FN void gp_dc_scatter(GPic *g, int tid, int nthr)
 
 /* chain: one motion-vector component (comp 0: x from mvh, 1: y from mvv) of every inter macroblock
  * (h4m:1846-1860, 1943-1955); returns HVQ_F_CLAMPED when a target had to be clamped to int16 */
-GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp)
+GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
 {
     if (g->status) return 0;
     GBits b = comp ? g->mvv : g->mvh;
@@ -1131,7 +1199,7 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp)
     int32_t acc = 0;
     uint32_t fl = 0, m = 0, w4 = 0;
     GList types;                                                         /* the type bytes, four per entry */
-    gl_init(&types, (const GP_G uint32_t *)g->mbtype, ((uint32_t)g->mw * (uint32_t)g->mh + 3u) / 4u, comp ? 18u : 17u);
+    gl_init(&types, (const GP_G uint32_t *)g->mbtype, ((uint32_t)g->mw * (uint32_t)g->mh + 3u) / 4u, list_slot);
     for (int my = 0; my < g->mh; ++my)
         for (int mx = 0; mx < g->mw; ++mx, ++m) {
             if ((m & 3u) == 0) w4 = gl_next(&types);

@@ -36,7 +36,7 @@
 #include "hvq_gparse_core.h"
 
 extern "C" hipError_t hvq_launch_parse(const HvqParseJob *jobs_dev, HvqParseResult *results_dev, uint32_t n,
-                                       uint32_t rowbuf_stride, uint64_t *timing_dev, hipStream_t stream);
+                                       uint32_t rowbuf_stride, uint32_t use_flat, uint64_t *timing_dev, hipStream_t stream);
 extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t n, hipStream_t stream);
 extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
@@ -216,6 +216,7 @@ struct HvqContext {
     uint64_t *np_dev = nullptr;
     size_t pj_cap = 0;
     double gpu_parse_ms = 0;           /* device time of the parse kernel of the last flush */
+    uint32_t gpu_parse_retried = 0;    /* pictures of the last flush the flat parse path handed to the chains */
 };
 
 static int arena_reserve(HvqContext *c, size_t need)
@@ -600,7 +601,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
         if (lens[i] > 0x7FFFFFF0u) return fail(HVQ_E_ARG, "picture %d: the GPU parser needs the real picture length", i);
         if (c->streams[(size_t)streams[i]].parse_mode == 1)
             return fail(HVQ_E_STATE, "stream %d is parsed on the host; a stream keeps one parser for its lifetime", streams[i]);
-        need += align_up(lens[i] + 16, 256);
+        need += align_up(lens[i] + 32, 256);
     }
     if (n == 0) return HVQ_OK;
     { int rcr = check_resume_order(c, n, streams, frame_types); if (rcr) return rcr; }
@@ -622,7 +623,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
             HIPCHK(hipMemsetAsync(s.nest_keep, 0, 2 * GP_ALIGN16(HVQ_NESTP_BYTES), c->stream));
         }
         offs[(size_t)i] = c->arena_used;
-        c->arena_used += align_up(lens[i] + 16, 256);
+        c->arena_used += align_up(lens[i] + 32, 256);
         Pending q{};
         q.dev = true;
         q.blob_off = offs[(size_t)i]; q.blob_len = lens[i];
@@ -644,7 +645,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
     auto copy_range = [&](int lo, int hi) {
         for (int i = lo; i < hi; ++i) {
             uint8_t *dst = c->host_arena + offs[(size_t)i];
-            const size_t span = align_up(lens[i] + 16, 256);
+            const size_t span = align_up(lens[i] + 32, 256);
             memcpy(dst, pics[i], lens[i]);
             memset(dst + lens[i], 0, span - lens[i]);
         }
@@ -655,7 +656,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
     while (lo < n) {
         int hi = lo;
         size_t bytes = 0;
-        while (hi < n && bytes < chunk_bytes) { bytes += align_up(lens[hi] + 16, 256); ++hi; }
+        while (hi < n && bytes < chunk_bytes) { bytes += align_up(lens[hi] + 32, 256); ++hi; }
         static const int copy_threads = getenv("HVQM4_AMD_COPY_THREADS") ? std::max(1, atoi(getenv("HVQM4_AMD_COPY_THREADS"))) : 4;
         const int nt = bytes >= ((size_t)4 << 20) ? copy_threads : 1;
         if (nt == 1) copy_range(lo, hi);
@@ -723,7 +724,7 @@ static int device_parse_launch(HvqContext *c)
         j.blob = p.dev_blob;
         j.nest_out = p.dev_nest;
         j.len = (uint32_t)p.blob_len;
-        j.pic_dwords = (uint32_t)((p.blob_len + 16) / 4);
+        j.pic_dwords = (uint32_t)((p.blob_len + 32) / 4);     /* zero padding the flat parse path may look into (gf_setup_lanes) */
         j.cap = s.blob_cap;
         j.width = (uint16_t)p.w; j.height = (uint16_t)p.h;
         j.frame_type = (uint8_t)(p.kind == HVQ_PIC_I ? HVQ_FRAME_I : (p.kind == HVQ_PIC_P ? HVQ_FRAME_P : HVQ_FRAME_B));
@@ -739,7 +740,9 @@ static int device_parse_launch(HvqContext *c)
         HIPCHK(hipMalloc((void **)&c->timing_dev, jobs.size() * 16 * sizeof(uint64_t)));
         HIPCHK(hipMemsetAsync(c->timing_dev, 0, jobs.size() * 16 * sizeof(uint64_t), c->stream));
     }
-    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, c->timing_dev, c->stream));
+    /* HVQM4_AMD_PARSE_FLAT=0: round 1's chains only (the flat path falls back to them by itself where it has to) */
+    static const bool use_flat = !(getenv("HVQM4_AMD_PARSE_FLAT") && atoi(getenv("HVQM4_AMD_PARSE_FLAT")) == 0);
+    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, use_flat ? 1u : 0u, c->timing_dev, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(c->pr_host, c->pr_dev, idx.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev_parse, c->stream));
@@ -756,23 +759,27 @@ static int device_parse_finish(HvqContext *c)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->gpu_parse_ms = ms;
+    const bool want_timing_print = c->timing_dev != nullptr;
     if (c->timing_dev) {
         std::vector<uint64_t> tm(idx.size() * 16);
         HIPCHK(hipMemcpy(tm.data(), c->timing_dev, tm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
         HIPCHK(hipFree(c->timing_dev)); c->timing_dev = nullptr;
-        static const char *names[3][7] = {
-            { "setup+trees", "", "chains kinds/DC", "nest+run sums", "scan+entries", "chains coefficients", "merge words" },
-            { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains coefficients/MV", "merge words" },
-            { "setup+trees", "chain mb types", "tags + chains kinds/DC", "run sums", "scan+entries", "chains coefficients/MV", "merge words" } };
-        double sum[3][7] = {}; size_t cnt[3] = {}; uint64_t t_min = ~0ull, t_max = 0;
+        /* stamp k of hvq_parse_kernel (GP_STAMP): average time since the picture's start, in the order they happened */
+        static const char *label[16] = { "start", "trees", "mb types", "DC placed", "run sums", "chains ready or decoder", "coefficients/scans",
+                                         "merge", "run scan", "entries", "emit count", "emit scan or MV x", "tags+lists", "kinds/DC or lanes",
+                                         "expansions", "MV y" };
+        double sum[3][16] = {}; size_t cnt[3][16] = {}, pics[3] = {}; uint64_t t_min = ~0ull, t_max = 0;
+        uint64_t s_max = 0, d_min = ~0ull, d_max = 0, k_max[3] = { 0, 0, 0 }, k_end[3] = { 0, 0, 0 };
+        if (getenv("HVQM4_AMD_PARSE_PROF"))
+            for (size_t k = 0; k < idx.size() && k < 16; ++k)
+                fprintf(stderr, "prof picture %zu kind %d: wait part %llu  decode part %llu  rounds %llu (shader clocks)\n", k, (int)c->fl_pending[idx[k]].kind,
+                        (unsigned long long)tm[16 * k + 9], (unsigned long long)tm[16 * k + 10], (unsigned long long)tm[16 * k + 6]);
         for (size_t k = 0; k < idx.size(); ++k) {
             const uint64_t *t = &tm[16 * k];
             const int kind = (int)c->fl_pending[idx[k]].kind;
-            uint64_t prev = t[0];
-            for (int ph = 1; ph <= 7; ++ph) { if (!t[ph]) continue; sum[kind][ph - 1] += (double)(t[ph] - prev) * 0.01; prev = t[ph]; }
-            cnt[kind]++; t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[7]);
+            for (int ph = 1; ph < 16; ++ph) if (t[ph]) { sum[kind][ph] += (double)(t[ph] - t[0]) * 0.01; cnt[kind][ph]++; }
+            pics[kind]++; t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[7]);
         }
-        uint64_t s_max = 0, d_min = ~0ull, d_max = 0, k_max[3] = { 0, 0, 0 }, k_end[3] = { 0, 0, 0 };
         for (size_t k = 0; k < idx.size(); ++k) {
             const uint64_t *t = &tm[16 * k];
             const int kind = (int)c->fl_pending[idx[k]].kind;
@@ -786,26 +793,24 @@ static int device_parse_finish(HvqContext *c)
         fprintf(stderr, "hvqm4_amd parse timing: %zu pictures, kernel %.3f ms, first start -> last end %.3f ms, last start +%.3f ms, "
                 "per picture %.3f .. %.3f ms\n",
                 idx.size(), ms, (double)(t_max - t_min) * 1e-5, (double)(s_max - t_min) * 1e-5, (double)d_min * 1e-5, (double)d_max * 1e-5);
-        {   /* finer split of the P/B phases */
-            double d[8] = {}; size_t n = 0;
-            for (size_t k = 0; k < idx.size(); ++k) {
-                const uint64_t *t = &tm[16 * k];
-                if (c->fl_pending[idx[k]].kind == HVQ_PIC_I || !t[12]) continue;
-                d[0] += (double)(t[12] - t[2]); d[1] += (double)(t[13] - t[12]); d[2] += (double)(t[3] - t[13]);
-                d[3] += (double)(t[8] - t[4]); d[4] += (double)(t[9] - t[8]); d[5] += (double)(t[10] - t[9]);
-                d[6] += (double)(t[11] - t[10]); d[7] += (double)(t[5] - t[11]);
-                ++n;
-            }
-            if (n) fprintf(stderr, "  P/B detail: tags+lists %.1f | kinds/DC chains %.1f | scatter %.1f | run scan %.1f | entries %.1f | "
-                           "emit count %.1f | emit scan %.1f | compact %.1f us\n", d[0] * 0.01 / n, d[1] * 0.01 / n, d[2] * 0.01 / n,
-                           d[3] * 0.01 / n, d[4] * 0.01 / n, d[5] * 0.01 / n, d[6] * 0.01 / n, d[7] * 0.01 / n);
-        }
         for (int kind = 0; kind < 3; ++kind) {
-            if (!cnt[kind]) continue;
-            fprintf(stderr, "  %c pictures (%zu): ", "IPB"[kind], cnt[kind]);
-            for (int ph = 0; ph < 7; ++ph) if (names[kind][ph][0]) fprintf(stderr, "%s %.1f us | ", names[kind][ph], sum[kind][ph] / (double)cnt[kind]);
+            if (!pics[kind]) continue;
+            std::vector<std::pair<double, int>> ord;
+            for (int ph = 1; ph < 16; ++ph) if (cnt[kind][ph]) ord.push_back({ sum[kind][ph] / (double)cnt[kind][ph], ph });
+            std::sort(ord.begin(), ord.end());
+            fprintf(stderr, "  %c pictures (%zu), us since start:", "IPB"[kind], pics[kind]);
+            double prev = 0;
+            for (auto &o : ord) { fprintf(stderr, " %s %.0f (+%.0f) |", label[o.second], o.first, o.first - prev); prev = o.first; }
             fprintf(stderr, "\n");
         }
+    }
+    {
+        uint32_t retried = 0;
+        uint64_t spins = 0;
+        for (size_t k = 0; k < idx.size(); ++k) { retried += res[k].pad[0] != 0; spins += res[k].pad[1]; }
+        c->gpu_parse_retried = retried;
+        if (want_timing_print) fprintf(stderr, "hvqm4_amd parse: %u of %zu pictures handed to the chains; decode wave waited %.1f rounds per picture\n",
+                                       retried, idx.size(), (double)spins / (double)idx.size());
     }
     for (size_t k = 0; k < idx.size(); ++k) {
         Pending &p = c->fl_pending[idx[k]];
@@ -1061,6 +1066,7 @@ static int flush_end(HvqContext *c)
     st.launches = (uint32_t)c->launches.size();
     st.parse_seconds = c->parse_seconds;
     st.gpu_parse_ms = st.gpu_parsed ? c->gpu_parse_ms : 0.0;
+    st.gpu_parse_retried = st.gpu_parsed ? c->gpu_parse_retried : 0u;
     if (jobs.size() > c->jobs_cap) {
         if (c->jobs_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->jobs_dev)); }
         c->jobs_cap = jobs.size() * 2;

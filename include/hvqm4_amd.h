@@ -52,6 +52,9 @@ typedef struct HvqStats {
     uint32_t flags_or;          /* OR of all blob header flags (HVQ_F_*) */
     uint32_t gpu_parsed;        /* pictures of the batch whose bitstream was parsed on the GPU */
     double   gpu_parse_ms;      /* device time of that parse launch (HIP events) */
+    uint32_t gpu_parse_retried; /* of those, pictures the flat parse path handed to the chain decoder (unusual section layout,
+                                   capacities, overflow groups at the caps) -- same result, slower */
+    uint32_t reserved0;
 } HvqStats;
 
 int  hvq_context_create(int device, HvqContext **out);

@@ -28,12 +28,12 @@ class Result(C.Structure):
 @pytest.fixture(scope="module")
 def emul():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    deps = [SRC] + [os.path.join(HERE, "..", "hvqm4_amd", "csrc", f) for f in ("hvq_gparse_core.h", "hvq_desc.h")]
+    deps = [SRC] + [os.path.join(HERE, "..", "hvqm4_amd", "csrc", f) for f in ("hvq_gparse_core.h", "hvq_gparse_flat.h", "hvq_desc.h")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         subprocess.run(["gcc", "-O2", "-Wall", "-shared", "-fPIC", SRC, "-o", OUT], check=True)
     lib = C.CDLL(OUT)
-    lib.gparse_emul.restype = C.c_int
-    lib.gparse_emul.argtypes = [C.c_char_p, C.c_uint32] + [C.c_int] * 6 + [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Result)]
+    lib.gparse_emul2.restype = C.c_int
+    lib.gparse_emul2.argtypes = [C.c_char_p, C.c_uint32] + [C.c_int] * 6 + [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Result), C.c_int]
     return lib
 
 
@@ -50,7 +50,10 @@ def header(blob):
     return d
 
 
-def compare_clip(emul, clip):
+CHAINS, FLAT, FLAT_ONLY = 0, 1, 2      # gparse_emul2 modes: round 1's chains | flat path with fallback | flat path or fail
+
+
+def compare_clip(emul, clip, mode=FLAT_ONLY):
     from hvqm4_amd._lib import lib
     l = lib()
     is15 = 1 if clip.version == "1.5" else 0
@@ -66,8 +69,8 @@ def compare_clip(emul, clip):
         assert l.hvq_parse_picture(prs, ft, pic + b"\0" * 8, len(pic), a.ctypes.data, bound, C.byref(n)) == 0
         b[:] = 0xEE
         res = Result()
-        assert emul.gparse_emul(pic, len(pic), ft, clip.width, clip.height, clip.samp, clip.samp, is15,
-                                b.ctypes.data, bound, nest.ctypes.data, C.byref(res)) == 0
+        assert emul.gparse_emul2(pic, len(pic), ft, clip.width, clip.height, clip.samp, clip.samp, is15,
+                                 b.ctypes.data, bound, nest.ctypes.data, C.byref(res), mode) == 0, (idx, "flat path gave up")
         assert res.status == 0, (idx, res.status)
         ha, hb = header(a.tobytes()), header(b.tobytes())
         where = f"picture {idx} type {ft:#x}"
@@ -96,9 +99,10 @@ def compare_clip(emul, clip):
     l.hvq_parser_destroy(prs)
 
 
+@pytest.mark.parametrize("mode", [CHAINS, FLAT_ONLY], ids=["chains", "flat"])
 @pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM, ids=lambda c: c[0])
-def test_gpu_parse_core_matches_host_parser(emul, case):
-    compare_clip(emul, clips.get(case))
+def test_gpu_parse_core_matches_host_parser(emul, case, mode):
+    compare_clip(emul, clips.get(case), mode)
 
 
 def test_gpu_parse_core_random_geometries(emul):
@@ -117,3 +121,47 @@ def test_gpu_parse_core_random_geometries(emul):
 def test_gpu_parse_core_large_and_extreme_geometries(emul, w, h, samp):
     from hvqm4_amd.synth import SynthConfig, make_clip
     compare_clip(emul, make_clip(SynthConfig(width=w, height=h, gop="IPB", seed=w + h, sampling=samp, runoff_prob=0.2)))
+
+
+def test_flat_path_hands_unusual_pictures_to_the_chains(emul):
+    """Pictures the flat path cannot serve -- a one-leaf DC tree whose only value lies outside the overflow window (every
+    value runs to the chains' cap of 256 symbols), and sections truncated so that lanes run dry -- must come out of the
+    fallback exactly as the host parser decodes them, and the result must say that the chains did it."""
+    import copy
+    from hvqm4_amd.container import video_pictures
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    clip = make_clip(SynthConfig(width=96, height=64, gop="IPB", seed=5))
+    pics = []
+    for ft, _d, pic in video_pictures(clip.data):
+        p = bytearray(pic)
+        data = 8 + (0x40 if ft == 0x10 else 0x44)
+        off = data + struct.unpack_from(">I", p, 8 + 4 * 4)[0] + 4          # section 4 = DC buffer of the luma plane
+        p[0] = 0
+        p[off:off + 2] = b"\x3f\x80"                                         # tree = single leaf 0x7F
+        pics.append((ft, bytes(p)))
+    from hvqm4_amd._lib import lib
+    l = lib()
+    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp, clip.samp, 1 if clip.version == "1.5" else 0)
+    bound = l.hvq_parser_blob_bound(prs)
+    a = np.zeros(bound, dtype=np.uint8)
+    b = np.zeros(bound, dtype=np.uint8)
+    nest = np.zeros(NESTP, dtype=np.uint8)
+    retried = 0
+    for ft, pic in pics:
+        n = C.c_size_t(0)
+        rc = l.hvq_parse_picture(prs, ft, pic + b"\0" * 8, len(pic), a.ctypes.data, bound, C.byref(n))
+        res = Result()
+        assert emul.gparse_emul2(pic, len(pic), ft, clip.width, clip.height, clip.samp, clip.samp, 1 if clip.version == "1.5" else 0,
+                                 b.ctypes.data, bound, nest.ctypes.data, C.byref(res), FLAT) == 0
+        assert (rc == 0) == (res.status == 0)
+        if rc == 0:
+            ha = header(a.tobytes())
+            o, npool = ha["pool_off"], 4 * ha["pool_dwords"]
+            assert np.array_equal(a[o:o + npool], b[o:o + npool])
+            for i in range(3):
+                nmap = 2 * (ha["hb"][i] + 2) * (ha["vb"][i] + 2)
+                o = ha["map_off"][i]
+                assert np.array_equal(a[o:o + nmap], b[o:o + nmap])
+        retried += res.pad[0]
+    assert retried >= 1
+    l.hvq_parser_destroy(prs)
