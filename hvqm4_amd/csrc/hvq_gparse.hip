@@ -180,7 +180,9 @@ __device__ static void gf_stage_wave(GPic *g, int lane, uint32_t decoders)
         uint64_t mask = __builtin_amdgcn_ballot_w64(need);
         if (!mask) {
             if (done || ++idle > GF_SPIN_CAP) break;
-            __builtin_amdgcn_s_sleep(8);
+            /* a lane uses up a quarter in 8 rounds of its decoder, some 8 us; looking every 1-2 us is plenty, and every
+             * look costs the CU two dozen instructions */
+            __builtin_amdgcn_s_sleep(48);
             continue;
         }
         while (mask) {

@@ -1198,6 +1198,8 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
     int cur_ref = -1;
     int32_t acc = 0;
     uint32_t fl = 0, m = 0, w4 = 0;
+    /* residual bits per reference, in registers: a table read per vector is an LDS round trip on the chain's critical path */
+    const int rb0 = g->res[2 * comp] & 15, rb1 = g->res[2 * comp + 1] & 15, rb2 = g->res[2 * comp + 2] & 15;
     GList types;                                                         /* the type bytes, four per entry */
     gl_init(&types, (const GP_G uint32_t *)g->mbtype, ((uint32_t)g->mw * (uint32_t)g->mh + 3u) / 4u, list_slot);
     for (int my = 0; my < g->mh; ++my)
@@ -1207,7 +1209,7 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
             if (t == 0) continue;
             const int r = t - 1;
             if (r != cur_ref) { cur_ref = r; acc = 0; }
-            const int rbits = g->res[2 * comp + r] & 15;                  /* r = 2 only from a first type value of 3 */
+            const int rbits = r == 0 ? rb0 : (r == 1 ? rb1 : rb2);        /* r = 2 only from a first type value of 3 */
             const int32_t lim = (int32_t)(1u << (rbits + 5));
             int32_t v = (int32_t)((uint32_t)gsym(c, &b) << rbits);
             v += (int32_t)gb_take(&b, rbits);
