@@ -1,5 +1,7 @@
 """GPU: entropy parse ON the device (hvq_submit_many_device -> hvq_gparse.hip) followed by the reconstruction
 kernels must give the oracle's pictures bit for bit -- no host core parses a bit of these streams."""
+import os
+
 import numpy as np
 import pytest
 
@@ -26,6 +28,8 @@ def test_gpu_parsed_clip_matches_oracle(gpu_ctx, case):
     assert np.array_equal(got, want)
     st = gpu_ctx.stats()
     assert st.gpu_parsed == clip.n_pictures
+    if not os.environ.get("HVQM4_AMD_PARSE_FLAT") == "0":
+        assert st.gpu_parse_retried == 0, "the flat parse path handed a regular picture to the chains"
 
 
 @pytest.mark.parametrize("every", [1, 2, 5])
@@ -238,3 +242,33 @@ def test_a_rejected_picture_fails_the_flush_and_leaves_the_context_usable(gpu_ct
         gpu_ctx.flush_end()
     gpu_ctx.close_stream(sid)
     test_nest_of_the_last_I_picture_survives_flushes(gpu_ctx, 2)
+
+
+def test_a_picture_the_flat_path_cannot_serve_is_decoded_by_the_chains(gpu_ctx):
+    """A one-leaf DC tree whose value lies outside the overflow window makes every DC value run to the chains' cap of 256
+    symbols: the flat path hands such a picture over (HvqStats.gpu_parse_retried), and what comes out is what the host
+    parser's blob decodes to."""
+    import struct
+    from hvqm4_amd import batch
+    from hvqm4_amd.container import parse_header, video_pictures
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    clip = make_clip(SynthConfig(width=96, height=64, gop="I", seed=5))
+    hdr = parse_header(clip.data)
+    ft, _d, pic = next(iter(video_pictures(clip.data)))
+    p = bytearray(pic)
+    off = 8 + 0x40 + struct.unpack_from(">I", p, 8 + 4 * 4)[0] + 4          # section 4 = DC buffer of the luma plane
+    p[0] = 0
+    p[off:off + 2] = b"\x3f\x80"                                          # tree = single leaf 0x7F
+    got = {}
+    for gpu_parse in (False, True):
+        sid = gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, 4)
+        if gpu_parse:
+            gpu_ctx.submit_many_device([sid], [ft], [bytes(p)])
+        else:
+            gpu_ctx.submit(sid, ft, bytes(p))
+        gpu_ctx.flush()
+        if gpu_parse and os.environ.get("HVQM4_AMD_PARSE_FLAT") != "0":
+            assert gpu_ctx.stats().gpu_parse_retried == 1
+        got[gpu_parse] = gpu_ctx.read_picture(sid, 0).copy()
+        gpu_ctx.close_stream(sid)
+    assert np.array_equal(got[False], got[True])

@@ -22,3 +22,14 @@ def test_parity_suites_with_forced_tiles_per_workgroup(tiles):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert " passed" in r.stdout
+
+
+def test_gpu_parse_suite_with_the_chains_only():
+    """The device entropy parse has two ways to a blob: the flat path (all sections at once, scans) and round 1's chains,
+    which the flat path also falls back to per picture.  The default run exercises the flat path; here the GPU-parse suite
+    runs with HVQM4_AMD_PARSE_FLAT=0 so that the chains stay covered as a whole."""
+    env = dict(os.environ, HVQM4_AMD_PARSE_FLAT="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "tests/test_gpu_gparse.py"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert " passed" in r.stdout
