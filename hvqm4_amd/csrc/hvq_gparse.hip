@@ -1,25 +1,37 @@
 /*
- * hvq_gparse.hip -- gfx950 kernel around hvq_gparse_core.h: one workgroup (4 wavefronts) parses one picture's
- * bitstream into its descriptor blob, entirely on the GPU.
+ * hvq_gparse.hip -- gfx950 kernel around hvq_gparse_core.h / hvq_gparse_flat.h: one workgroup (4 wavefronts) parses one
+ * picture's bitstream into its descriptor blob, entirely on the GPU.
  *
- * Phase schedule (tests/native/gparse_emul.c runs the same order on the CPU):
- *   all pictures : setup + section cursors (thread 0) | maps/MVs/tree tables cleared (all threads) |
- *                  prefix trees read, one per wave (lane 0) | first-level tables filled (all threads)
- *   I picture    : 5 chains (kinds Y, kinds UV, DC Y, DC U, DC V) | nest + run sums (all) | run scan, header (thread 0) |
- *                  payload entries, fixed-length offsets, compaction (all) | 3 chains (coefficient symbols Y, U, V) |
- *                  basis words merged in, literal blocks copied (all)
- *   P/B picture  : 2 chains (macroblock types; proc runs) | inter ranks, tags, lists of coded / intra macroblocks (all, 5
- *                  steps) | 5 chains (kinds Y, kinds UV, DC Y, DC U, DC V: symbols only) | kinds and DC values placed in
- *                  the maps (all) | run sums (all) | run scan, header (thread 0) |
- *                  payload entries, fixed-length offsets, compaction (all) | 4 waves: coefficient symbols Y; U, V + DC-buffer
- *                  scalars of the MC-residual blocks Y; MV x + scalars U, V; MV y | basis words merged in, literal blocks copied (all)
- * A chain runs wave-uniform (all lanes compute the same values, so its cursors and counters live in scalar registers
- * and its logic runs on the scalar unit); the four waves of a workgroup run different
- * chains at the same time and 8 workgroups share a CU, so the serial bit-level work of thousands of pictures overlaps.
+ * Two ways to the same blob (tests/native/gparse_emul.c runs both on the CPU, phase by phase):
  *
- * LDS per workgroup: the picture state (cursors, geometry), six prefix trees (8-bit table whose entries hold the leaf
- * value, child and leaf tables: 2.5 KB each), 19 staging slots of 128 B (bitstream blocks and work lists) and the DC
- * chains' row buffers: 19.4 KB, 8 workgroups per CU.  At most 80 SGPRs: more costs a wave slot per SIMD on gfx950.
+ * the FLAT path (round 2, default): every prefix-coded section is decoded front to back into a flat symbol
+ * array, all sections at once -- the lanes of ONE wave are the sections -- and zero runs, overflow grouping, DC
+ * prediction and coefficient sums become scans by all threads.
+ *   all pictures : setup + section cursors (wave 0) | maps/MVs/tree tables cleared (all) | prefix trees read, one per wave |
+ *                  first-level tables + the coefficient tree's 9-bit table filled (all)
+ *   I picture    : { decode wave: kinds, coefficients, DC runs | decode wave: the three DC sections | staging wave } |
+ *                  5 scan rounds (values, zero runs -> blocks) | DC prediction as a wavefront, one wave per plane | nest, pool
+ *                  layout (tile sums, one wave scan, entries) | payload positions (scans) | merge (entries on consecutive lanes)
+ *   P/B picture  : { decode wave: all ten sections | staging wave | type runs then x vectors | proc runs then y vectors } |
+ *                  tags + lists | 4 scan rounds | layout | payload positions | merge
+ * A picture the flat path cannot serve (sections in an unusual order, array capacities, overflow groups at the chains' caps)
+ * sets `retry` and is decoded again by
+ *
+ * the CHAINS (round 1; HVQM4_AMD_PARSE_FLAT=0 runs them alone): the reference's loops cut into serial chains that own the
+ * cursors they read, three chain phases with parallel phases between them.
+ *   I picture    : 5 chains (kinds Y, kinds UV, DC Y, DC U, DC V) | nest + run sums (all) | run scan, header (wave 0) |
+ *                  payload entries, fixed-length offsets, compaction (all) | 3 chains (coefficient symbols Y, U, V) | merge (all)
+ *   P/B picture  : 2 chains (macroblock types; proc runs) | tags + lists (all, 5 steps) | 5 chains (kinds Y, kinds UV, DC Y,
+ *                  DC U, DC V: symbols only) | kinds and DC values placed in the maps (all) | run sums | run scan, header |
+ *                  payload entries, offsets, compaction | 4 waves: coefficient symbols Y; U, V + scalars Y; MV x + scalars U, V;
+ *                  MV y | merge (all)
+ * A chain runs wave-uniform (all lanes compute the same values, so its cursors and counters live in scalar registers and its
+ * logic runs on the scalar unit); 8 workgroups share a CU, so the serial bit-level work of thousands of pictures overlaps.
+ *
+ * LDS per workgroup: the picture state (cursors, lanes, geometry), 24 staging slots of 128 B (the chains' bitstream blocks and
+ * work lists; the flat path's rings of 256 B per lane lie over them), six prefix trees (8-bit table whose entries hold the leaf
+ * value + child table: 2 KB each), the 9-bit coefficient table (2 KB), the DC row buffers: 19.3 KB + 3 x (hb + 2), 8 workgroups
+ * per CU.  At most 80 SGPRs (more costs a wave slot per SIMD on gfx950) and 64 VGPRs.
  */
 #include <hip/hip_runtime.h>
 
