@@ -609,8 +609,28 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
     int rc = arena_reserve(c, need);
     if (rc) return rc;
     std::vector<size_t> offs((size_t)n);
+    /* Everything below changes stream and queue state before the last thing that can fail (allocation, upload): a failed
+     * call must leave the context as it found it, so the touched streams are saved and put back. */
+    std::vector<std::pair<int, Stream>> saved;
+    const size_t pend0 = c->pending.size(), used0 = c->arena_used;
+    auto rollback = [&]() {
+        for (auto &kv : saved) {
+            Stream &s = c->streams[(size_t)kv.first];
+            if (s.nest_keep && !kv.second.nest_keep) (void)hipFree(s.nest_keep);
+            s = kv.second;
+        }
+        c->pending.resize(pend0);
+        c->arena_used = used0;
+        if (c->arena_uploaded > used0) c->arena_uploaded = used0;
+    };
+#define HIPCHK_RB(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rollback(); return fail(HVQ_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
     for (int i = 0; i < n; ++i) {
         Stream &s = c->streams[(size_t)streams[i]];
+        {
+            bool have = false;
+            for (auto &kv : saved) have |= kv.first == streams[i];
+            if (!have) saved.emplace_back(streams[i], s);
+        }
         if (s.parse_mode == 0) {
             s.parse_mode = 2;
             hvq_parser_layout(s.parser, &s.layout);
@@ -619,8 +639,8 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
             for (int k = 0; k < 3; ++k) blocks += (uint32_t)s.layout.hb[k] * s.layout.vb[k];
             s.scratch_bytes = (uint32_t)align_up(hvq_gparse_scratch_bytes(blocks, s.layout.tile_first[3] * (HVQ_TILE_BLOCKS / 64),
                                                                           s.layout.mcb_w * s.layout.mcb_h), 256);
-            HIPCHK(hipMalloc((void **)&s.nest_keep, 2 * GP_ALIGN16(HVQ_NESTP_BYTES)));
-            HIPCHK(hipMemsetAsync(s.nest_keep, 0, 2 * GP_ALIGN16(HVQ_NESTP_BYTES), c->stream));
+            HIPCHK_RB(hipMalloc((void **)&s.nest_keep, 2 * GP_ALIGN16(HVQ_NESTP_BYTES)));
+            HIPCHK_RB(hipMemsetAsync(s.nest_keep, 0, 2 * GP_ALIGN16(HVQ_NESTP_BYTES), c->stream));
         }
         offs[(size_t)i] = c->arena_used;
         c->arena_used += align_up(lens[i] + 32, 256);
@@ -669,10 +689,11 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
         }
         if (early) {
             int rcu = arena_upload(c, hi < n ? offs[(size_t)hi] : c->arena_used);
-            if (rcu) return rcu;
+            if (rcu) { rollback(); return rcu; }
         }
         lo = hi;
     }
+#undef HIPCHK_RB
     return HVQ_OK;
 }
 
