@@ -347,7 +347,7 @@ def main():
                    "streaming_parse_kernel_ms": round(parse_ms_streaming, 3),
                    "parse_kernel_ms": round(min(parse_ms[1:]), 3), "pass_ms": [round(t * 1e3, 2) for t in t_pass],
                    "submit_flush_sync_ms": t_split,
-                   "host_copy_threads": int(os.environ.get("HVQM4_AMD_COPY_THREADS", "4")),
+                   "host_copy_threads": int(os.environ.get("HVQM4_AMD_COPY_THREADS", "8" if (os.cpu_count() or 1) >= 16 else "4")),
                    "pictures_checked_against_host_parsed": ok,
                    "what": "raw bitstreams in host memory -> H2D -> entropy parse kernel (one workgroup per picture) -> "
                            "reconstruction launches -> pictures in HBM; no host entropy parse; all ranks at once (sum over ranks, "
