@@ -194,7 +194,7 @@ __device__ static void gf_stage_wave(GPic *g, int lane, uint32_t decoders)
             if (done || ++idle > GF_SPIN_CAP) break;
             /* a lane uses up a quarter in 8 rounds of its decoder, some 8 us; looking every 1-2 us is plenty, and every
              * look costs the CU two dozen instructions */
-            __builtin_amdgcn_s_sleep(48);
+            __builtin_amdgcn_s_sleep(127);
             continue;
         }
         while (mask) {
@@ -403,11 +403,18 @@ __device__ static void gf_idc_predict_wave(GPic *g, int i, uint8_t *rowbuf, uint
 }
 
 /* ------------------------------------------------------------------ the kernel */
-extern "C" __global__ __launch_bounds__(GPW) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
-void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__restrict__ results, uint32_t rowbuf_stride,
-                      uint32_t use_flat, uint64_t *__restrict__ timing)     /* optional: 16 phase timestamps per picture (100 MHz clock) */
+/* Two kernels from one body: FLAT = the flat path, which hands a picture it cannot serve back to the host marked "redo"
+ * (HvqParseResult.pad[0] = 2); !FLAT = the chains, for those pictures (`redo` lists them) or, with HVQM4_AMD_PARSE_FLAT=0,
+ * for all.  One kernel with both paths costs the flat path 5 % (93 instead of 12 spilled SGPRs in the chains it shares,
+ * profiles/r02ak_*). */
+template <bool FLAT>
+__global__ __launch_bounds__(GPW) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
+void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__restrict__ results, uint32_t rowbuf_stride,
+                        const uint32_t *__restrict__ redo,           /* optional: the pictures to parse, one per workgroup */
+                        uint64_t *__restrict__ timing)               /* optional: 16 phase timestamps per picture (100 MHz clock) */
 {
-#define GP_STAMP(k) do { if (timing && tid == 0) timing[16 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+    const uint32_t pic = redo ? redo[blockIdx.x] : blockIdx.x;
+#define GP_STAMP(k) do { if (timing && tid == 0) timing[16 * pic + (k)] = wall_clock64(); } while (0)
     extern __shared__ uint8_t s_rowbuf[];            /* 3 * rowbuf_stride */
     __shared__ GPic g;
     GCode *codes = (GCode *)(gp_stage + GP_STAGE_DWORDS);              /* the six trees follow the staging slots */
@@ -419,11 +426,9 @@ void hvq_parse_kernel(const HvqParseJob *__restrict__ jobs, HvqParseResult *__re
      * Workgroup b runs on XCD b % 8; whether an XCD deals its workgroups b / 8 to its 32 CUs one each in turn or eight at a
      * time, the sum below takes all four values among the workgroups that share a CU. */
     const int role = (wave + (int)(((blockIdx.x >> 3) + (blockIdx.x >> 8)) & 3u)) & 3;
-    const HvqParseJob *job = jobs + blockIdx.x;
-    int flat = (int)use_flat;
-    uint32_t retried = 0;
+    const HvqParseJob *job = jobs + pic;
+    constexpr bool flat = FLAT;
 
-again:
     GP_STAMP(0);
     if (wave == 0) {
         gp_setup(&g, job);
@@ -484,11 +489,11 @@ again:
          * rare long codes would hold the other lanes up, have their own); P/B: the type and proc runs beside them */
         if (!is_pb) {
             const uint32_t dc_lanes = 7u << GF_DC0;
-            if (role == 0) { gf_decode_wave(&g, codes, lane, ~dc_lanes); if (timing && lane == 0) timing[16 * blockIdx.x + 5] = wall_clock64(); }
+            if (role == 0) { gf_decode_wave(&g, codes, lane, ~dc_lanes); if (timing && lane == 0) timing[16 * pic + 5] = wall_clock64(); }
             else if (role == 2) gf_decode_wave(&g, codes, lane, dc_lanes);
             else if (role == 1) gf_stage_wave(&g, lane, 2u);
         } else {
-            if (role == 0) { gf_decode_wave(&g, codes, lane, ~0u); if (timing && lane == 0) timing[16 * blockIdx.x + 5] = wall_clock64(); }
+            if (role == 0) { gf_decode_wave(&g, codes, lane, ~0u); if (timing && lane == 0) timing[16 * pic + 5] = wall_clock64(); }
             else if (role == 1) gf_stage_wave(&g, lane, 1u);
             else {
                 /* the type runs, then the x components of the vectors (which need nothing but the type bytes); the proc runs,
@@ -496,7 +501,7 @@ again:
                 const int comp = role - 2;
                 if (comp == 0) {
                     gp_mbtypes(&g, codes);
-                    if (timing && lane == 0) timing[16 * blockIdx.x + 2] = wall_clock64();
+                    if (timing && lane == 0) timing[16 * pic + 2] = wall_clock64();
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     GF_ST(gf_types_done, 1u);
                 } else {
@@ -508,7 +513,7 @@ again:
                 b->slot = GF_SIDE_SLOT + (uint32_t)comp; b->base = ~0u;
                 const uint32_t f = gp_mvs(&g, codes, comp, GF_SIDE_SLOT + 2u + (uint32_t)comp);
                 GP_ST(g.part[GP_MISC + 13 + comp], f);
-                if (timing && lane == 0) timing[16 * blockIdx.x + (comp ? 15 : 11)] = wall_clock64();
+                if (timing && lane == 0) timing[16 * pic + (comp ? 15 : 11)] = wall_clock64();
             }
         }
         __syncthreads();
@@ -599,17 +604,13 @@ again:
             gfd_emit_merge(&g, tid);
             __syncthreads();
         }
-        if (g.retry && !g.status) {                     /* uniform: every thread reads it after the barrier */
-            __syncthreads();
-            flat = 0; retried = 1;
-            goto again;
-        }
         GP_STAMP(7);
         if (tid == 0) {
-            gp_result(&g, (GP_G HvqParseResult *)(results + blockIdx.x), g.part[GP_MISC + 13] | g.part[GP_MISC + 14]);
-            results[blockIdx.x].pad[0] = retried; results[blockIdx.x].pad[1] = g.spins;
+            gp_result(&g, (GP_G HvqParseResult *)(results + pic), g.part[GP_MISC + 13] | g.part[GP_MISC + 14]);
+            results[pic].pad[0] = (g.retry && !g.status) ? 2u : 0u;       /* 2: not served, the host sends it to the chains */
+            results[pic].pad[1] = g.spins;
 #ifdef GF_PROFILE
-            if (timing) { timing[16 * blockIdx.x + 9] = g.prof[0]; timing[16 * blockIdx.x + 10] = g.prof[1]; timing[16 * blockIdx.x + 6] = g.prof[2]; }
+            if (timing) { timing[16 * pic + 9] = g.prof[0]; timing[16 * pic + 10] = g.prof[1]; timing[16 * pic + 6] = g.prof[2]; }
 #endif
         }
         return;
@@ -684,8 +685,8 @@ again:
     __syncthreads();
     GP_STAMP(7);
     if (tid == 0) {
-        gp_result(&g, (GP_G HvqParseResult *)(results + blockIdx.x), g.part[GP_MISC + 13] | g.part[GP_MISC + 14]);
-        results[blockIdx.x].pad[0] = retried;
+        gp_result(&g, (GP_G HvqParseResult *)(results + pic), g.part[GP_MISC + 13] | g.part[GP_MISC + 14]);
+        results[pic].pad[0] = 0;
     }
 #undef GP_STAMP
 }
@@ -701,11 +702,16 @@ void hvq_nest_commit_kernel(const uint64_t *__restrict__ pairs)
 }
 
 extern "C" hipError_t hvq_launch_parse(const HvqParseJob *jobs_dev, HvqParseResult *results_dev, uint32_t n,
-                                       uint32_t rowbuf_stride, uint32_t use_flat, uint64_t *timing_dev, hipStream_t stream)
+                                       uint32_t rowbuf_stride, uint32_t use_flat, const uint32_t *redo_dev, uint64_t *timing_dev,
+                                       hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(hvq_parse_kernel, dim3(n), dim3(GPW), 3 * (size_t)rowbuf_stride, stream, jobs_dev, results_dev,
-                       rowbuf_stride, use_flat, timing_dev);
+    if (use_flat)
+        hipLaunchKernelGGL(hvq_parse_kernel_t<true>, dim3(n), dim3(GPW), 3 * (size_t)rowbuf_stride, stream, jobs_dev, results_dev,
+                           rowbuf_stride, redo_dev, timing_dev);
+    else
+        hipLaunchKernelGGL(hvq_parse_kernel_t<false>, dim3(n), dim3(GPW), 3 * (size_t)rowbuf_stride, stream, jobs_dev, results_dev,
+                           rowbuf_stride, redo_dev, timing_dev);
     return hipGetLastError();
 }
 
@@ -719,7 +725,7 @@ extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride)
 {
     int n = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hvq_parse_kernel, GPW, 3 * (size_t)rowbuf_stride) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, hvq_parse_kernel_t<true>, GPW, 3 * (size_t)rowbuf_stride) != hipSuccess) return -1;
     return n;
 }
 

@@ -36,7 +36,8 @@
 #include "hvq_gparse_core.h"
 
 extern "C" hipError_t hvq_launch_parse(const HvqParseJob *jobs_dev, HvqParseResult *results_dev, uint32_t n,
-                                       uint32_t rowbuf_stride, uint32_t use_flat, uint64_t *timing_dev, hipStream_t stream);
+                                       uint32_t rowbuf_stride, uint32_t use_flat, const uint32_t *redo_dev, uint64_t *timing_dev,
+                                       hipStream_t stream);
 extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t n, hipStream_t stream);
 extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
@@ -217,6 +218,9 @@ struct HvqContext {
     size_t pj_cap = 0;
     double gpu_parse_ms = 0;           /* device time of the parse kernel of the last flush */
     uint32_t gpu_parse_retried = 0;    /* pictures of the last flush the flat parse path handed to the chains */
+    uint32_t *redo_dev = nullptr;      /* their indices, for the chains kernel */
+    size_t redo_cap = 0;
+    uint32_t fl_rowbuf = 0;
 };
 
 static int arena_reserve(HvqContext *c, size_t need)
@@ -325,6 +329,7 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->pr_dev) (void)hipFree(c->pr_dev);
     if (c->np_dev) (void)hipFree(c->np_dev);
     if (c->host_arena) (void)hipHostFree(c->host_arena);
+    if (c->redo_dev) (void)hipFree(c->redo_dev);
     if (c->dev_arena) (void)hipFree(c->dev_arena);
     if (c->host_arena_alt) (void)hipHostFree(c->host_arena_alt);
     if (c->dev_arena_alt) (void)hipFree(c->dev_arena_alt);
@@ -766,7 +771,8 @@ static int device_parse_launch(HvqContext *c)
     }
     /* HVQM4_AMD_PARSE_FLAT=0: round 1's chains only (the flat path falls back to them by itself where it has to) */
     static const bool use_flat = !(getenv("HVQM4_AMD_PARSE_FLAT") && atoi(getenv("HVQM4_AMD_PARSE_FLAT")) == 0);
-    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, use_flat ? 1u : 0u, c->timing_dev, c->stream));
+    c->fl_rowbuf = rowbuf;
+    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, use_flat ? 1u : 0u, nullptr, c->timing_dev, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(c->pr_host, c->pr_dev, idx.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev_parse, c->stream));
@@ -783,6 +789,25 @@ static int device_parse_finish(HvqContext *c)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->gpu_parse_ms = ms;
+    /* Pictures the flat parse path could not serve (sections in an unusual order, array capacities, overflow groups at
+     * the chains' caps) come back marked: the chains kernel parses those, same blobs as they would have been. */
+    uint32_t n_redo = 0;
+    {
+        std::vector<uint32_t> redo;
+        for (size_t k = 0; k < idx.size(); ++k) if (res[k].pad[0] == 2u) redo.push_back((uint32_t)k);
+        n_redo = (uint32_t)redo.size();
+        if (n_redo) {
+            if (redo.size() > c->redo_cap) {
+                if (c->redo_dev) { HIPCHK(hipFree(c->redo_dev)); c->redo_dev = nullptr; c->redo_cap = 0; }
+                HIPCHK(hipMalloc((void **)&c->redo_dev, redo.size() * 2 * sizeof(uint32_t)));
+                c->redo_cap = redo.size() * 2;
+            }
+            HIPCHK(hipMemcpyAsync(c->redo_dev, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, n_redo, c->fl_rowbuf, 0u, c->redo_dev, nullptr, c->stream));
+            HIPCHK(hipMemcpyAsync(c->pr_host, c->pr_dev, idx.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));       /* also keeps `redo` alive until its upload is done */
+        }
+    }
     const bool want_timing_print = c->timing_dev != nullptr;
     if (c->timing_dev) {
         std::vector<uint64_t> tm(idx.size() * 16);
@@ -829,9 +854,9 @@ static int device_parse_finish(HvqContext *c)
         }
     }
     {
-        uint32_t retried = 0;
+        const uint32_t retried = n_redo;
         uint64_t spins = 0;
-        for (size_t k = 0; k < idx.size(); ++k) { retried += res[k].pad[0] != 0; spins += res[k].pad[1]; }
+        for (size_t k = 0; k < idx.size(); ++k) spins += res[k].pad[1];
         c->gpu_parse_retried = retried;
         if (want_timing_print) fprintf(stderr, "hvqm4_amd parse: %u of %zu pictures handed to the chains; decode wave waited %.1f rounds per picture\n",
                                        retried, idx.size(), (double)spins / (double)idx.size());
