@@ -15,7 +15,7 @@
  *   P/B picture  : { decode wave: all ten sections | staging wave | type runs then x vectors | proc runs then y vectors } |
  *                  tags + lists | 4 scan rounds | layout | payload positions | merge
  * A picture the flat path cannot serve (sections in an unusual order, array capacities, overflow groups at the chains' caps)
- * sets `retry` and is decoded again by
+ * is handed back to the host (HvqParseResult.pad[0] = 2), which sends it to
  *
  * the CHAINS (round 1; HVQM4_AMD_PARSE_FLAT=0 runs them alone): the reference's loops cut into serial chains that own the
  * cursors they read, three chain phases with parallel phases between them.
