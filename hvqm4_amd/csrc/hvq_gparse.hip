@@ -315,17 +315,23 @@ __device__ static void gfd_emit_merge(GPic *g, int tid)
                 dst += 2;
             }
             uint32_t run = 0;
-            for (uint32_t k0 = 0; k0 < nb; k0 += 4) {
-                uint32_t w[4];
-                int32_t sv[4];
-                for (uint32_t j = 0; j < 4; ++j) {
-                    const int live = k0 + j < nb;
-                    w[j] = live ? gp_be16(g, my_fx + 2u * (k0 + j)) : 0u;
-                    sv[j] = live ? S[my_si + k0 + j] : 0;
-                }
-                for (uint32_t j = 0; j < 4; ++j) {
-                    run += (uint32_t)sv[j];
-                    if (k0 + j < nb) dst[k0 + j] = HVQ_BASIS(w[j], (run + ((w[j] >> 13) & 3u)) & 0x3FFFFu);
+            /* eight bases a time from two 16-byte loads (words and symbols lie consecutive; both arrays and the picture are
+             * padded far enough to read a full block): this loop is the largest single consumer of vector instructions in
+             * the kernel, the byte-wise form took three times as many */
+            for (uint32_t k0 = 0; k0 < nb; k0 += 8) {
+                const uint64_t wo = my_fx + 2u * k0;
+                uint32_t wq[4];
+                if (__builtin_expect(wo + 16u <= (uint64_t)g->nd * 4u, 1)) __builtin_memcpy(wq, (const GP_G uint8_t *)g->d + wo, 16);
+                else for (uint32_t j = 0; j < 4; ++j) wq[j] = __builtin_bswap32((gp_be16(g, wo + 4u * j) << 16) | gp_be16(g, wo + 4u * j + 2u));
+                uint32_t sq[4];
+                __builtin_memcpy(sq, S + my_si + k0, 16);
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) {
+                    if (k0 + j >= nb) break;
+                    const uint32_t half = (wq[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu;           /* bytes b0 b1 of the word, b0 low */
+                    const uint32_t w = ((half & 0xFFu) << 8) | (half >> 8);
+                    run += (uint32_t)(int32_t)(int16_t)(sq[j >> 1] >> (16u * (j & 1u)));
+                    dst[k0 + j] = HVQ_BASIS(w, (run + ((w >> 13) & 3u)) & 0x3FFFFu);
                 }
             }
         }
@@ -459,6 +465,8 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
         else if (wave == 1) gp_mbprocs(&g, codes);
         __syncthreads();
         GP_STAMP(2);
+        gp_runs_expand(&g, tid, GPW);
+        __syncthreads();
         gp_tags_count(&g, tid, GPW);
         __syncthreads();
         if (wave == 0) gp_tags_scan(&g, GPW);
@@ -519,6 +527,8 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
         __syncthreads();
         GP_STAMP(13);
         if (is_pb) {
+            gp_runs_expand(&g, tid, GPW);
+            __syncthreads();
             gp_tags_count(&g, tid, GPW);
             __syncthreads();
             if (wave == 0) gp_tags_scan(&g, GPW);

@@ -340,6 +340,8 @@ typedef struct {
     GP_G uint8_t *mbtag;         /* [mw*mh] (type << 5) | (proc << 4) */
     GP_G uint32_t *cmb;          /* [mw*mh] macroblocks whose block kinds are coded (all but proc 1), in order */
     GP_G uint32_t *t0;           /* [mw*mh] intra (type 0) macroblocks, in order */
+    GP_G uint32_t *trun;         /* [mw*mh] type runs: value << 24 | first macroblock */
+    GP_G uint32_t *prun;         /* [mw*mh] proc runs: value << 24 | first entry of procseq */
     GP_G uint32_t *part;         /* [GP_PART] partial counts of the parallel phases */
     /* picture */
     int dc_shift, unk_shift, nx, ny;
@@ -350,6 +352,7 @@ typedef struct {
     uint64_t fx_off[3];          /* byte offset of the fixed-length sections (basis words, literal blocks) */
     uint32_t nchain[3];          /* entries in clist per plane */
     uint32_t ncoded, ntype0;     /* entries of cmb / t0 */
+    uint32_t ntrun, nprun, pend; /* entries of trun / prun; procseq entries the proc runs cover */
     uint32_t nks[2];             /* coded kinds found by the kinds chains (luma, chroma) */
     GBits bn[2], bnr[2], dc[3], bt[3], rle[3], mvh, mvv, mtype, mproc;
     /* flat path (hvq_gparse_flat.h) */
@@ -397,7 +400,7 @@ GP_FN uint32_t gp_byte(const GPic *g, uint32_t off) { return (gp_be32(g, off & ~
 /* bytes of scratch one picture of this geometry needs */
 GP_FN uint32_t gp_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb)
 {
-    return GP_ALIGN16(4u * total_blocks) * 2u + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb + 16u) * 3u + GP_ALIGN16(4u * nmb + 16u) * 2u + 4u * GP_PART
+    return GP_ALIGN16(4u * total_blocks) * 2u + GP_ALIGN16(2u * total_runs) * 2u + GP_ALIGN16(nmb + 16u) * 3u + GP_ALIGN16(4u * nmb + 16u) * 4u + 4u * GP_PART
          + GP_ALIGN16(2u * GP_SYM_TOTAL(total_blocks)) + GP_ALIGN16(4u * GP_VAL_TOTAL(total_blocks));
 }
 
@@ -453,10 +456,12 @@ GP_FN void gp_setup(GPic *g, const HvqParseJob *job)
     g->mbtag = s;                        s += GP_ALIGN16(nmb + 16u);
     g->cmb = (GP_G uint32_t *)s;         s += GP_ALIGN16(4u * nmb + 16u);
     g->t0 = (GP_G uint32_t *)s;          s += GP_ALIGN16(4u * nmb + 16u);
+    g->trun = (GP_G uint32_t *)s;        s += GP_ALIGN16(4u * nmb + 16u);
+    g->prun = (GP_G uint32_t *)s;        s += GP_ALIGN16(4u * nmb + 16u);
     g->part = (GP_G uint32_t *)s;        s += 4u * GP_PART;
     g->sym = (GP_G int16_t *)s;          s += GP_ALIGN16(2u * GP_SYM_TOTAL(blocks));
     g->val = (GP_G uint32_t *)s;
-    g->retry = 0; g->ncoded = 0; g->ntype0 = 0; g->spins = 0;
+    g->retry = 0; g->ncoded = 0; g->ntype0 = 0; g->ntrun = 0; g->nprun = 0; g->pend = 0; g->spins = 0;
     g->flags = 0; g->status = 0; g->max_items = 0; g->max_pairs = 0; g->pool_dwords = 0; g->total = 0;
     if (g->cap < g->fixed_bytes || g->len < 8 + 0x44 + 4) g->status |= GP_ST_BADARG;
 }
@@ -560,12 +565,13 @@ GP_FN void gp_init_maps(const GPic *g, int tid, int nthr)
     for (int i = 0; i < 3; ++i) {
         const GPlane *q = &g->pl[i];
         GP_G uint16_t *m = (GP_G uint16_t *)(g->blob + q->map_off);
-        const uint32_t n = (uint32_t)q->stride * (uint32_t)(q->vb + 2);
-        for (uint32_t e = (uint32_t)tid; e < n; e += (uint32_t)nthr) {
-            const uint32_t r = e / (uint32_t)q->stride, c = e - r * (uint32_t)q->stride;
-            const int border = r == 0 || r == (uint32_t)q->vb + 1 || c == 0 || c == (uint32_t)q->stride - 1;
-            m[e] = border ? (uint16_t)0xFF7Fu : (uint16_t)0;
-        }
+        /* rows dealt to the waves, columns to the lanes: no division per entry (nthr is a multiple of 64) */
+        const uint32_t rows = (uint32_t)q->vb + 2u, stride = (uint32_t)q->stride;
+        for (uint32_t r = (uint32_t)tid >> 6; r < rows; r += (uint32_t)nthr >> 6)
+            for (uint32_t c = (uint32_t)tid & 63u; c < stride; c += 64u) {
+                const int border = r == 0 || r == rows - 1 || c == 0 || c == stride - 1;
+                m[r * stride + c] = border ? (uint16_t)0xFF7Fu : (uint16_t)0;
+            }
     }
     if (g->is_pb) {
         GP_G uint32_t *mv = (GP_G uint32_t *)(g->blob + g->mv_off);
@@ -973,7 +979,8 @@ GP_FN void gp_emit_merge(GPic *g, int tid, int nthr)
 }
 
 /* ------------------------------------------------------------------ P/B picture chains */
-/* chain: macroblock types from the mtype runs (h4m:1545-1622) */
+/* chain: macroblock types from the mtype runs (h4m:1545-1622).  The chain records the RUNS (value, first macroblock);
+ * all threads spread them over the type bytes afterwards (gp_runs_expand), and the vector chains walk the runs. */
 GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
 {
     if (g->status) return;
@@ -983,17 +990,21 @@ GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
     uint32_t value = 0, count = 0;
     if (b.live) { value = gb_take(&b, 2); count = (uint32_t)gsym_uovf(c, &b, cap); }
     const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
-    for (uint32_t m = 0; m < n; ++m) {
+    uint32_t m = 0, nr = 0;
+    while (m < n) {
         if (count == 0) {
             const uint32_t bit = gb_take(&b, 1);
             const uint32_t v = value & 3u;
             /* step table { {1,2,0,2}, {2,0,1,0} } of hvq_parse.c pb_pass1 */
             value = bit ? (v == 0 ? 2u : (v == 2 ? 1u : 0u)) : (v == 0 ? 1u : (v == 2 ? 0u : 2u));
             count = (uint32_t)gsym_uovf(c, &b, cap);
+            if (count == 0) count = n;            /* the reference's counter wraps below zero: the run never ends */
         }
-        --count;
-        GP_ST(g->mbtype[m], (uint8_t)value);
+        const uint32_t len = count < n - m ? count : n - m;
+        GP_ST(g->trun[nr], (value << 24) | m); ++nr;
+        m += len; count -= len;
     }
+    g->ntrun = nr;
 }
 
 /* chain, concurrent with gp_mbtypes: proc value of the n-th INTER macroblock from the mproc runs (h4m:1649-1668).
@@ -1009,14 +1020,33 @@ GP_FN void gp_mbprocs(GPic *g, const GCode *codes)
     uint32_t value = 0, count = 0;
     if (b.live) { value = gb_take(&b, 1); count = (uint32_t)gsym_uovf(c, &b, cap); }
     const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
-    for (uint32_t m = 0; m < n; ++m) {
+    uint32_t m = 0, nr = 0;
+    while (m < n) {
         if (count == 0) {
             if (b.idx > b.nd + 2u) break;
             value ^= 1u;
             count = (uint32_t)gsym_uovf(c, &b, cap);
+            if (count == 0) count = n;
         }
-        --count;
-        GP_ST(g->procseq[m], (uint8_t)value);
+        const uint32_t len = count < n - m ? count : n - m;
+        GP_ST(g->prun[nr], (value << 24) | m); ++nr;
+        m += len; count -= len;
+    }
+    g->nprun = nr; g->pend = m;
+}
+
+/* parallel, after the two chains: the runs spread over mbtype[] and procseq[] */
+GP_FN void gp_runs_expand(GPic *g, int tid, int nthr)
+{
+    if (g->status) return;
+    const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
+    for (uint32_t r = (uint32_t)tid; r < g->ntrun; r += (uint32_t)nthr) {
+        const uint32_t e = g->trun[r], m0 = e & 0xFFFFFFu, m1 = r + 1 < g->ntrun ? g->trun[r + 1] & 0xFFFFFFu : n;
+        for (uint32_t m = m0; m < m1; ++m) g->mbtype[m] = (uint8_t)(e >> 24);
+    }
+    for (uint32_t r = (uint32_t)tid; r < g->nprun; r += (uint32_t)nthr) {
+        const uint32_t e = g->prun[r], m0 = e & 0xFFFFFFu, m1 = r + 1 < g->nprun ? g->prun[r + 1] & 0xFFFFFFu : g->pend;
+        for (uint32_t m = m0; m < m1; ++m) g->procseq[m] = (uint8_t)(e >> 24);
     }
 }
 
@@ -1197,30 +1227,37 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
     GP_G int16_t *mvs = (GP_G int16_t *)(g->blob + g->mv_off);
     int cur_ref = -1;
     int32_t acc = 0;
-    uint32_t fl = 0, m = 0, w4 = 0;
+    uint32_t fl = 0;
     /* residual bits per reference, in registers: a table read per vector is an LDS round trip on the chain's critical path */
     const int rb0 = g->res[2 * comp] & 15, rb1 = g->res[2 * comp + 1] & 15, rb2 = g->res[2 * comp + 2] & 15;
-    GList types;                                                         /* the type bytes, four per entry */
-    gl_init(&types, (const GP_G uint32_t *)g->mbtype, ((uint32_t)g->mw * (uint32_t)g->mh + 3u) / 4u, list_slot);
-    for (int my = 0; my < g->mh; ++my)
-        for (int mx = 0; mx < g->mw; ++mx, ++m) {
-            if ((m & 3u) == 0) w4 = gl_next(&types);
-            const int t = (int)((w4 >> (8u * (m & 3u))) & 0xFFu);
-            if (t == 0) continue;
-            const int r = t - 1;
-            if (r != cur_ref) { cur_ref = r; acc = 0; }
-            const int rbits = r == 0 ? rb0 : (r == 1 ? rb1 : rb2);        /* r = 2 only from a first type value of 3 */
-            const int32_t lim = (int32_t)(1u << (rbits + 5));
+    const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh, nr = g->ntrun, mw = (uint32_t)g->mw;
+    GList runs;                                                          /* the type runs (gp_mbtypes) */
+    gl_init(&runs, g->trun, nr, list_slot);
+    uint32_t e = nr ? gl_next(&runs) : 0u;
+    for (uint32_t r = 0; r < nr; ++r) {
+        const uint32_t nx = r + 1 < nr ? gl_next(&runs) : n;
+        const uint32_t m0 = e & 0xFFFFFFu, m1 = r + 1 < nr ? nx & 0xFFFFFFu : n;
+        const int t = (int)(e >> 24);
+        e = nx;
+        if (t == 0) continue;                                             /* a run of intra macroblocks */
+        const int ref = t - 1;
+        if (ref != cur_ref) { cur_ref = ref; acc = 0; }
+        const int rbits = ref == 0 ? rb0 : (ref == 1 ? rb1 : rb2);        /* ref = 2 only from a first type value of 3 */
+        const int32_t lim = (int32_t)(1u << (rbits + 5));
+        uint32_t my = m0 / mw, mx = m0 - my * mw;
+        for (uint32_t m = m0; m < m1; ++m) {
             int32_t v = (int32_t)((uint32_t)gsym(c, &b) << rbits);
             v += (int32_t)gb_take(&b, rbits);
             acc += v;
             if (acc >= lim) acc -= lim << 1;
             else if (acc < -lim) acc += lim << 1;
-            int32_t pos = (comp ? my : mx) * 16 + acc;
+            int32_t pos = (int32_t)(comp ? my : mx) * 16 + acc;
             if (pos > 32767) { pos = 32767; fl |= HVQ_F_CLAMPED; }
             if (pos < -32768) { pos = -32768; fl |= HVQ_F_CLAMPED; }
             GP_ST(mvs[2 * m + (uint32_t)comp], (int16_t)pos);
+            if (++mx == mw) { mx = 0; ++my; }
         }
+    }
     return fl;
 }
 

@@ -349,7 +349,8 @@ GP_FN void gf_exp_put(const GPic *g, int x, uint32_t at, uint32_t tok)
     int by, bx;
     uint32_t tag = 0;
     if (g->is_pb) {
-        const uint32_t r = at / (uint32_t)q->nblk, j = at - r * (uint32_t)q->nblk;
+        const uint32_t sh = q->nblk == 4 ? 2u : 0u;             /* nblk is 1 or 4 */
+        const uint32_t r = q->nblk == 4 || q->nblk == 1 ? at >> sh : at / (uint32_t)q->nblk, j = at - r * (uint32_t)q->nblk;
         const uint32_t m = g->cmb[r];
         tag = g->mbtag[m];
         const int my = (int)(m / (uint32_t)g->mw), mx = (int)(m - (uint32_t)my * (uint32_t)g->mw);
@@ -531,9 +532,9 @@ GP_FN void gf_layout_blocks(GPic *g, int tid, int nthr)
             if (n) ent = kind == 6 ? GP_ENT(off, 0, GP_MODE_LITERAL)
                        : (inter ? GP_ENT(off, kind - 1, GP_MODE_PREDI) : GP_ENT(off, kind, GP_MODE_BASES));
             uint32_t at = b;
-            if (g->is_pb) {
-                const uint32_t dy = by % (uint32_t)q->by_per, dx = bx % (uint32_t)q->bx_per;
-                const uint32_t mb = (by / (uint32_t)q->by_per) * (uint32_t)g->mw + bx / (uint32_t)q->bx_per;
+            if (g->is_pb) {                                   /* by_per, bx_per are 1 or 2: no divisions in this loop */
+                const uint32_t dy = by & (uint32_t)(q->by_per - 1), dx = bx & (uint32_t)(q->bx_per - 1);
+                const uint32_t mb = (by >> (q->by_per >> 1)) * (uint32_t)g->mw + (bx >> (q->bx_per >> 1));
                 at = mb * (uint32_t)q->nblk + (dx ? (dy ? 2u : 3u) : (dy ? 1u : 0u));
                 if (q->nblk == 1) at = mb;
             }

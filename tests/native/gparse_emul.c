@@ -85,6 +85,7 @@ again:
     if (g->is_pb) {
         gp_mbtypes(g, codes);
         gp_mbprocs(g, codes);
+        for (int t = 0; t < NTHR; ++t) gp_runs_expand(g, t, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_tags_count(g, t, NTHR);
         gp_tags_scan(g, NTHR);
         for (int t = 0; t < NTHR; ++t) gp_tags_assign(g, t, NTHR);
