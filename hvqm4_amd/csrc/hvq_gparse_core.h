@@ -49,6 +49,14 @@
  * lanes with the same address and value -- measured 8 % faster than masking them down to one lane, which costs five
  * more instructions per store in a chain whose speed is its instruction count. */
 #define GP_ST(lvalue, value) do { (lvalue) = (value); } while (0)
+/* a value every lane holds alike, said so: what was read from LDS counts as divergent for the compiler, and a chain whose
+ * loop bounds come from there is compiled for the vector units with exec masking (measured: slower, the vector units are
+ * what the kernel is short of) */
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define GP_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define GP_UNI(x) ((uint32_t)(x))
+#endif
 
 #define GP_LUT_BITS 8
 /* caps of the overflow-symbol loops (the reference has none: h4m:654-677 loop for as long as the stream says).  A
@@ -1229,13 +1237,13 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
     int32_t acc = 0;
     uint32_t fl = 0;
     /* residual bits per reference, in registers: a table read per vector is an LDS round trip on the chain's critical path */
-    const int rb0 = g->res[2 * comp] & 15, rb1 = g->res[2 * comp + 1] & 15, rb2 = g->res[2 * comp + 2] & 15;
-    const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh, nr = g->ntrun, mw = (uint32_t)g->mw;
+    const int rb0 = (int)GP_UNI(g->res[2 * comp] & 15), rb1 = (int)GP_UNI(g->res[2 * comp + 1] & 15), rb2 = (int)GP_UNI(g->res[2 * comp + 2] & 15);
+    const uint32_t mw = GP_UNI(g->mw), n = mw * GP_UNI(g->mh), nr = GP_UNI(g->ntrun);
     GList runs;                                                          /* the type runs (gp_mbtypes) */
     gl_init(&runs, g->trun, nr, list_slot);
-    uint32_t e = nr ? gl_next(&runs) : 0u;
+    uint32_t e = nr ? GP_UNI(gl_next(&runs)) : 0u;
     for (uint32_t r = 0; r < nr; ++r) {
-        const uint32_t nx = r + 1 < nr ? gl_next(&runs) : n;
+        const uint32_t nx = r + 1 < nr ? GP_UNI(gl_next(&runs)) : n;
         const uint32_t m0 = e & 0xFFFFFFu, m1 = r + 1 < nr ? nx & 0xFFFFFFu : n;
         const int t = (int)(e >> 24);
         e = nx;
