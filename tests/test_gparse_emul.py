@@ -165,3 +165,44 @@ def test_flat_path_hands_unusual_pictures_to_the_chains(emul):
         retried += res.pad[0]
     assert retried >= 1
     l.hvq_parser_destroy(prs)
+
+
+def test_flat_path_equals_the_chains_on_corrupted_pictures(emul):
+    """"Same blob either way" must also hold where no golden exists: bit flips, truncations and garbage spliced into
+    pictures of four geometries and presets -- the flat path (with its hand-over to the chains) and the chains alone must
+    agree on status, result record, the whole blob and the nest, byte for byte."""
+    from hvqm4_amd.container import video_pictures
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    rng = np.random.default_rng(5)
+    cap = 4 << 20
+    a = np.zeros(cap, dtype=np.uint8); b = np.zeros(cap, dtype=np.uint8)
+    na = np.zeros(2048, dtype=np.uint8); nb = np.zeros(2048, dtype=np.uint8)
+    total = fell_back = 0
+    for seed, (w, h) in enumerate([(96, 64), (64, 96), (160, 128), (48, 48)]):
+        clip = make_clip(SynthConfig(width=w, height=h, gop="IPBB", seed=seed + 1, preset=["dense", "natural", "realistic", "flat"][seed % 4]))
+        is15 = 1 if clip.version == "1.5" else 0
+        for ft, _d, pic in video_pictures(clip.data):
+            p = bytes(pic)
+            for v in range(24):
+                q = bytearray(p)
+                if v % 3 == 0:
+                    for _ in range(int(rng.integers(1, 12))):
+                        q[int(rng.integers(8, len(q)))] ^= 1 << int(rng.integers(0, 8))
+                elif v % 3 == 1:
+                    q = q[:int(rng.integers(0x60, len(q)))]
+                else:
+                    o = int(rng.integers(0x50, len(q) - 8))
+                    q[o:o + 8] = bytes(rng.integers(0, 256, 8, dtype=np.uint8))
+                q = bytes(q)
+                a[:] = 0; b[:] = 0; na[:] = 0; nb[:] = 0
+                ra, rb = Result(), Result()
+                assert emul.gparse_emul2(q, len(q), ft, w, h, clip.samp, clip.samp, is15, a.ctypes.data, cap, na.ctypes.data, C.byref(ra), CHAINS) == 0
+                assert emul.gparse_emul2(q, len(q), ft, w, h, clip.samp, clip.samp, is15, b.ctypes.data, cap, nb.ctypes.data, C.byref(rb), FLAT) == 0
+                total += 1; fell_back += rb.pad[0]
+                assert ra.status == rb.status, (seed, hex(ft), v)
+                if ra.status == 0:
+                    assert (ra.flags, ra.total_bytes, ra.max_items, ra.max_pairs, ra.pool_dwords) == \
+                           (rb.flags, rb.total_bytes, rb.max_items, rb.max_pairs, rb.pool_dwords), (seed, hex(ft), v)
+                    assert np.array_equal(a[:ra.total_bytes], b[:rb.total_bytes]), (seed, hex(ft), v, "blob")
+                    assert np.array_equal(na, nb), (seed, hex(ft), v, "nest")
+    assert total == 4 * 4 * 24 and fell_back > 0

@@ -33,3 +33,18 @@ def test_gpu_parse_suite_with_the_chains_only():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert " passed" in r.stdout
+
+
+def test_flat_parse_kernel_and_chains_kernel_agree_on_corrupted_pictures():
+    """108 corrupted pictures (bit flips, truncations, spliced garbage) behind intact ones: the flat parse kernel (with its
+    hand-over) and the chains kernel must reject the same ones with the same error and decode the others to the same
+    pictures."""
+    outs = []
+    for flat in ("1", "0"):
+        env = dict(os.environ, HVQM4_AMD_PARSE_FLAT=flat, PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "corrupt_hashes.py")], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        outs.append(r.stdout.strip().splitlines())
+    assert len(outs[0]) == 3 * 3 * 12
+    assert outs[0] == outs[1], [(a, b) for a, b in zip(outs[0], outs[1]) if a != b][:5]
