@@ -232,9 +232,13 @@ GP_FN void gc_read(GCode *c, GBits *carrier, int is_signed, int scale, uint32_t 
     int sp = 0, next = 0x100;
     for (;;) {
         int val;
-        if (gb_take(carrier, 1) == 0) {
-            val = (int)gb_take(carrier, 8);
+        gb_refill(carrier);                                 /* at least 33 bits: a leaf is '0' + its byte, looked at in one go */
+        const uint32_t nine = (uint32_t)(carrier->acc >> 55);
+        if (!(nine & 0x100u)) {
+            val = (int)(nine & 0xFFu);
+            carrier->acc <<= 9; carrier->cnt -= 9;
         } else {
+            carrier->acc <<= 1; carrier->cnt -= 1;
             /* a tree over 256 leaf bytes has at most 255 inner nodes (ids 256..510) and so nests at most 255 deep;
              * anything more is malformed, and would let node 511 become its own child (an endless walk in gsym) */
             if (next >= 511 || sp >= 256) { *status |= GP_ST_BADTREE; c->root = 0; c->sgn = 0; c->scale = 0; return; }
@@ -1252,18 +1256,28 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
         if (ref != cur_ref) { cur_ref = ref; acc = 0; }
         const int rbits = ref == 0 ? rb0 : (ref == 1 ? rb1 : rb2);        /* ref = 2 only from a first type value of 3 */
         const int32_t lim = (int32_t)(1u << (rbits + 5));
-        uint32_t my = m0 / mw, mx = m0 - my * mw;
+        const uint32_t my0 = m0 / mw;
+        uint32_t mx = m0 - my0 * mw;
+        int32_t at = (int32_t)(comp ? my0 : mx) * 16;                     /* 16 x the macroblock's row resp. column */
+        GP_G int16_t *out = mvs + 2 * m0 + (uint32_t)comp;
         for (uint32_t m = m0; m < m1; ++m) {
+            /* symbol and residual bits from one refill: a code from the table is at most 8 bits, the residual at most 15 */
             int32_t v = (int32_t)((uint32_t)gsym(c, &b) << rbits);
-            v += (int32_t)gb_take(&b, rbits);
+            if (rbits) {
+                if (b.cnt < rbits) gb_refill(&b);
+                v += (int32_t)(uint32_t)(b.acc >> (64 - rbits));
+                b.acc <<= rbits; b.cnt -= rbits;
+            }
             acc += v;
             if (acc >= lim) acc -= lim << 1;
             else if (acc < -lim) acc += lim << 1;
-            int32_t pos = (int32_t)(comp ? my : mx) * 16 + acc;
+            int32_t pos = at + acc;
             if (pos > 32767) { pos = 32767; fl |= HVQ_F_CLAMPED; }
             if (pos < -32768) { pos = -32768; fl |= HVQ_F_CLAMPED; }
-            GP_ST(mvs[2 * m + (uint32_t)comp], (int16_t)pos);
-            if (++mx == mw) { mx = 0; ++my; }
+            GP_ST(*out, (int16_t)pos);
+            out += 2;
+            if (comp == 0) at += 16;
+            if (++mx == mw) { mx = 0; at = comp ? at + 16 : 0; }
         }
     }
     return fl;

@@ -473,11 +473,13 @@ GP_FN void gf_layout_sum(GPic *g, int tid, int nthr)
             const uint32_t b0 = (r - q->run_first) * 64u;
             uint32_t sum = 0;
             uint32_t by = b0 / (uint32_t)q->hb, bx = b0 - by * (uint32_t)q->hb;
+            const GP_G uint8_t *tp8 = gp_map_ent(g, i, (int)by, (int)bx) + 1;      /* type bytes: 2 apart, 4 more over the border */
             for (uint32_t b = b0; b < b0 + 64u && b < q->nblocks; ++b) {
                 uint32_t n, it, pr, f;
-                gp_type_info(ctx, gp_map_ent(g, i, (int)by, (int)bx)[1], &n, &it, &pr, &f);
+                gp_type_info(ctx, *tp8, &n, &it, &pr, &f);
                 sum += n; ti += it; tp += pr; fl |= f;
-                if (++bx == (uint32_t)q->hb) { bx = 0; ++by; }
+                tp8 += 2;
+                if (++bx == (uint32_t)q->hb) { bx = 0; tp8 += 4; }
             }
             wave_base[r] = run;
             run += sum;
@@ -522,8 +524,9 @@ GP_FN void gf_layout_blocks(GPic *g, int tid, int nthr)
         uint32_t off = wave_base[r] + g->part[GF_P(GF_I_LS, (r / (HVQ_TILE_BLOCKS / 64)) / per)];
         wave_base[r] = off;
         uint32_t by = b0 / (uint32_t)q->hb, bx = b0 - by * (uint32_t)q->hb;
+        const GP_G uint8_t *tp8 = gp_map_ent(g, i, (int)by, (int)bx) + 1;
         for (uint32_t b = b0; b < b0 + 64u && b < q->nblocks; ++b) {
-            const uint32_t t = gp_map_ent(g, i, (int)by, (int)bx)[1];
+            const uint32_t t = *tp8;
             uint32_t n, it, pr, f;
             gp_type_info(ctx, t, &n, &it, &pr, &f);
             const uint32_t kind = ctx == 0 ? t : (t & 0xFu);
@@ -540,7 +543,8 @@ GP_FN void gf_layout_blocks(GPic *g, int tid, int nthr)
             }
             g->pinfo[q->blk_first + at] = ent;
             off += n;
-            if (++bx == (uint32_t)q->hb) { bx = 0; ++by; }
+            tp8 += 2;
+            if (++bx == (uint32_t)q->hb) { bx = 0; ++by; tp8 += 4; }
         }
     }
 }
