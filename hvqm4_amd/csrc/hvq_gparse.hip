@@ -70,12 +70,6 @@ __device__ static inline uint32_t *gf_ring(int l)
 
 __device__ static inline uint32_t gf_ring_dword(const uint32_t *ring, uint32_t i) { return __builtin_bswap32(ring[i & (GF_RING - 1u)]); }
 
-__device__ static inline uint64_t gf_ring_window(const uint32_t *ring, uint32_t pos)       /* at least 33 valid bits */
-{
-    const uint32_t i = pos >> 5;
-    return (((uint64_t)gf_ring_dword(ring, i) << 32) | gf_ring_dword(ring, i + 1)) << (pos & 31u);
-}
-
 __device__ static inline uint64_t gf_ring_window64(const uint32_t *ring, uint32_t pos)       /* 64 valid bits */
 {
     const uint32_t i = pos >> 5, sh = pos & 31u;
