@@ -130,21 +130,26 @@ typedef struct HvqPlaneRec {       /* per-plane part (32 bytes) */
 } HvqPlaneRec;
 
 typedef struct HvqJob {
-    uint64_t ref0;                 /* "past"   (macroblock type 1) */
-    uint64_t ref1;                 /* "future" (macroblock type 2) */
+    uint64_t ring;                 /* the stream's picture slots: every reference read is ring + 32-bit offset (one SGPR base) */
+    uint32_t ref0_off;             /* "past"   (macroblock type 1): byte offset of its slot inside the ring */
+    uint32_t ref1_off;             /* "future" (macroblock type 2) */
     uint64_t pool;                 /* device addresses of the blob sections */
     uint64_t mv;
-    uint64_t wave_base;
+    uint64_t tq;                   /* tile queues of the picture (HvqTileQ[total_tiles]), built by hvq_tileq_kernel */
     uint64_t nest;                 /* nibble-packed nest (HVQ_NESTP_BYTES), 0 when absent */
-    uint32_t slot_bytes;           /* readable bytes at ref0/ref1 (>= pic_bytes + 8) */
+    uint32_t slot_bytes;           /* readable bytes of a slot (>= pic_bytes + 8) */
     uint32_t flags;                /* HVQ_F_* | picture kind << 16 | unk_shift << 20 */
     uint32_t width;                /* luma samples per row */
     uint32_t mcb_w;
     uint32_t pool_dwords;          /* payload pool size */
     uint32_t total_tiles;          /* 0: picture dropped by the flush, its workgroups exit */
-    uint32_t pad1[2];
+    uint32_t q_lits_off;           /* byte offsets from `tq` of the picture's literal, item and pair lists */
+    uint32_t q_items_off;
     HvqPlaneRec plane[3];
-    uint32_t pad2[8];
+    uint32_t q_pairs_off;
+    uint32_t q_caps;               /* list entries reserved per tile: items | pairs << 16 (literals: HVQ_TILE_BLOCKS) */
+    uint64_t wave_base;            /* blob section: pool offset of every run of 64 blocks (read by hvq_tileq_kernel only) */
+    uint32_t pad2[4];
 } HvqJob;
 #define HVQ_JOB_KIND_SHIFT  16
 #define HVQ_JOB_UNK_SHIFT   20
@@ -156,6 +161,34 @@ static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
 _Static_assert(sizeof(HvqPlaneRec) == 32, "HvqPlaneRec must be 32 bytes");
 _Static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
 #endif
+
+/*
+ * Tile queues (round 3).  Which blocks of a tile need the AOT machinery, in which order, with which bases -- all of it
+ * follows from the type bytes alone, so it is worked out ONCE per picture when its descriptors arrive (hvq_tileq_kernel,
+ * part of the parse stage) instead of by every reconstruction launch: the reconstruction kernel no longer classifies,
+ * ballots, scans or builds lists, and its AOT phase does not wait for its per-block phase.
+ *   HvqTileQ   per tile: counts
+ *   literals   u32 per literal block: owner (lane of the tile) | pool offset << 8
+ *   items      16 bytes per queued block (intra AOT first, then MC residual): owner | map entry << 8, pool offset of the
+ *              payload, the two scalars of an MC-residual block (h4m:1405-1406)
+ *   pairs      8 bytes per (item, basis), items in order, fully decoded (h4m:683-731 / 738-772):
+ *              w0 = [17:0] coefficient sum + offset, [18] negate, [19] sample stride 2, [20] row stride 2, [21] MC residual,
+ *                   [31:23] item of the tile
+ *              w1 = intra: nest index of sample (0,0) (nibble units); MC residual: ring offset of sample (0,0) of the
+ *                   70x38 window (origin of h4m:1865-1868 + basis offset, clamped into the slot)
+ */
+typedef struct HvqTileQ {
+    uint32_t w0;                   /* pairs | items << 16 | HVQ_TQ_* */
+    uint32_t w1;                   /* literal blocks */
+} HvqTileQ;
+#define HVQ_TQ_INTRA   (1u << 26)  /* the tile has intra AOT items: the nest is staged */
+#define HVQ_TQ_SERIAL  (1u << 27)  /* more pairs than the picture's list reserves: no pair list, items loop over their bases */
+#define HVQ_PAIR_CAP_MAX 2048u     /* pairs per tile a list may reserve */
+#define HVQ_PQ_NEG     (1u << 18)
+#define HVQ_PQ_X2      (1u << 19)
+#define HVQ_PQ_Y2      (1u << 20)
+#define HVQ_PQ_MC      (1u << 21)
+#define HVQ_PQ_ITEM_SHIFT 23
 
 /* Block classification by map type byte, one dword per (context, type): context 0 = I-picture luma (kind = whole byte,
  * h4m:1093), 1 = I-picture chroma, 2 = P/B picture.  Filled by hvq_type_class() on the host, read by the kernel. */

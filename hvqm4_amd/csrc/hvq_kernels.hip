@@ -340,11 +340,6 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 }
 
 #define HVQ_NW (HVQ_WG / 64)
-/* ablation builds only (tools/variant.sh <name> -DHVQ_ABL=n; outputs are wrong, only the time matters):
- * 1 = no phase-B2 arithmetic, 2 = no phase-B1 pair work, 3 = no phase-A arithmetic (MC loads kept), 4 = 2 + 1 */
-#ifndef HVQ_ABL
-#define HVQ_ABL 0
-#endif
 
 /* Diagnostic build only (-DHVQ_STAMPS, tools/variant.sh): s_memtime stamps of wave phases into a buffer of their own
  * (64 x u64 per workgroup: [wave][16]); the shipped kernel executes no stamp.  VM = also wait for the wave's
@@ -362,7 +357,7 @@ extern "C" __attribute__((visibility("default"))) void hvq_set_stamps(unsigned l
 #define STAMP(i, VM) do { } while (0)
 #endif
 
-/* block classes by type byte (hvq_type_class): one load replaces ~25 compare/select instructions per lane */
+/* block classes by type byte (hvq_type_class), read by hvq_tileq_kernel */
 __device__ u32 g_type_class[3 * 256];
 
 extern "C" hipError_t hvq_upload_tables(void)
@@ -373,56 +368,206 @@ extern "C" hipError_t hvq_upload_tables(void)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_type_class), t, sizeof t);
 }
 
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+#define HVQ_PIN(x) do { x = (u32)__builtin_amdgcn_readfirstlane((int)(x)); asm volatile("" : "+s"(x)); } while (0)
+
+/* ------------------------------------------------------------------------------------------------------
+ * Tile queues (hvq_desc.h): once per picture, when its descriptors arrive -- part of the parse stage, not of the
+ * reconstruction launches.  One workgroup = one tile; lane = block.  Everything the reconstruction kernel used to derive
+ * from the type bytes on every launch (class, payload offset by prefix scan, queue slot by ballot, pair slot by a second
+ * scan, the basis word's decode, the window origin of an MC-residual block) is done here and left in three lists.
+ */
+__global__ __launch_bounds__(HVQ_WG)
+void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
+{
+    __shared__ u32 s_cnt[HVQ_NW][5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const HvqJob *__restrict__ J = jobs + first_job + blockIdx.y;
+    const u32 tile = blockIdx.x;
+    if (tile >= J->total_tiles) return;
+    const int p = (tile >= J->plane[1].tile_first) + (tile >= J->plane[2].tile_first);
+    const u32 flags = J->flags;
+    const bool is_pb = ((flags >> HVQ_JOB_KIND_SHIFT) & 3u) != HVQ_PIC_I;
+    const bool landscape = flags & HVQ_F_LANDSCAPE;
+    const u32 hbvb = J->plane[p].hbvb, pw_sub = J->plane[p].pw_sub;
+    const i32 hb = (i32)(hbvb & 0xFFFFu);
+    const u32 nblocks = (u32)hb * (hbvb >> 16);
+    const i32 ws = (i32)((pw_sub >> 16) & 0xFFu), hs = (i32)(pw_sub >> 24);
+    const i32 lw = (i32)J->width, slot = (i32)J->slot_bytes;
+    const u32 b = (tile - J->plane[p].tile_first) * HVQ_TILE_BLOCKS + (u32)tid;
+    const bool valid = b < nblocks;
+    i32 bx, by;
+    block_coords(valid ? b : 0u, hb, 1.0f / (float)hb, bx, by);
+    const GLB uint8_t *map = (const GLB uint8_t *)J->plane[p].map;
+    const u32 e16 = *(const GLB uint16_t *)(map + 2 * ((by + 1) * (hb + 2) + bx + 1));
+    const u32 T = e16 >> 8;
+    const u32 tc = valid ? g_type_class[(is_pb ? 512 : p == 0 ? 0 : 256) + T] : 0u;
+    const u32 npay = HVQ_TC_NPAY(tc), cls = HVQ_TC_CLS(tc), nb = HVQ_TC_NB(tc);
+    const bool lit = tc & HVQ_TC_LIT;
+    const GLB u32 *__restrict__ pool = (const GLB u32 *)J->pool;
+    const u32 off = ((const GLB u32 *)J->wave_base)[tile * HVQ_NW + (u32)wave] + wave_incl_scan(npay) - npay;
+    /* queue order: intra AOT items first, then MC-residual items, each in block order; pairs follow their items */
+    const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), ml = __ballot(lit);
+    const u32 sc1 = wave_incl_scan(cls == 1 ? nb : 0u), sc2 = wave_incl_scan(cls == 2 ? nb : 0u);
+    if (lane == 63) {
+        s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = sc1; s_cnt[wave][3] = sc2;
+        s_cnt[wave][4] = (u32)__popcll(ml);
+    }
+    __syncthreads();
+    u32 tot[5] = { 0, 0, 0, 0, 0 }, mine[5] = { 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int v = 0; v < HVQ_NW; ++v)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const u32 c = s_cnt[v][k]; tot[k] += c; if (v < wave) mine[k] += c; }
+    const u32 nI = tot[0], nitems = tot[0] + tot[1], npairs = tot[2] + tot[3], nlit = tot[4];
+    const u32 cap_items = J->q_caps & 0xFFFFu, cap_pairs = J->q_caps >> 16;
+    const bool serial = npairs > cap_pairs;
+    GLB uint8_t *q = (GLB uint8_t *)J->tq;
+    if (tid == 0) {
+        GLB HvqTileQ *t = (GLB HvqTileQ *)q + tile;
+        t->w0 = (serial ? 0u : npairs) | (nitems << 16) | (nI ? HVQ_TQ_INTRA : 0u) | (serial ? HVQ_TQ_SERIAL : 0u);
+        t->w1 = nlit;
+    }
+    if (lit) ((GLB u32 *)(q + J->q_lits_off))[(size_t)tile * HVQ_TILE_BLOCKS + mine[4] + lanes_below(ml)] = (u32)tid | (off << 8);
+    if (cls) {
+        const u32 it = cls == 1 ? mine[0] + lanes_below(m1) : nI + mine[1] + lanes_below(m2);
+        u32 p0 = 0, p1 = 0;
+        if (cls == 2) { p0 = pool[off]; p1 = pool[off + 1]; }
+        if (it < cap_items) {                           /* always: the cap is the picture's largest tile queue */
+            typedef u32 u32x4q __attribute__((ext_vector_type(4)));
+            const u32x4q rec = { (u32)tid | (e16 << 8), off, p0, p1 };
+            ((GLB u32x4q *)(q + J->q_items_off))[(size_t)tile * cap_items + it] = rec;
+        }
+        if (!serial && it < cap_items) {
+            const u32 pstart = cls == 1 ? mine[2] + sc1 - nb : tot[2] + mine[3] + sc2 - nb;
+            GLB u32x2 *dst = (GLB u32x2 *)(q + J->q_pairs_off) + (size_t)tile * cap_pairs + pstart;
+            const GLB u32 *bases = pool + off + (cls == 2 ? 2u : 0u);
+            i32 origin = 0;
+            u32 ref_off = 0;
+            if (cls == 2) {
+                const u32 mvw = ((const GLB u32 *)J->mv)[(by >> (1 - hs)) * (i32)J->mcb_w + (bx >> (1 - ws))];
+                const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+                origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;   /* h4m:1865-1868 */
+                ref_off = ((T >> 5) & 3u) == 1u ? J->ref0_off : J->ref1_off;
+            }
+            for (u32 k = 0; k < nb; ++k) {
+                const u32 d = bases[k];
+                const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;                       /* h4m:683-711 */
+                const u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
+                const u32 x2 = landscape ? sl : ss, y2 = landscape ? ss : sl;
+                u32 w0 = (d >> 14) | ((d & 0x2000u) ? HVQ_PQ_NEG : 0u) | (x2 ? HVQ_PQ_X2 : 0u) | (y2 ? HVQ_PQ_Y2 : 0u) | (it << HVQ_PQ_ITEM_SHIFT);
+                u32 w1;
+                if (cls == 1) {
+                    const i32 stride = landscape ? 70 : 38;
+                    w1 = (u32)(landscape ? stride * os + ol : stride * ol + os);
+                } else {
+                    const i32 o = landscape ? lw * os + ol : lw * ol + os;
+                    const i32 ys = lw << y2;
+                    w1 = ref_off + (u32)clampi(origin + o, 0, slot - 8 - 3 * ys);     /* one clamp: legal windows lie inside the slot */
+                    w0 |= HVQ_PQ_MC;
+                }
+                const u32x2 pw01 = { w0, w1 };
+                dst[k] = pw01;
+            }
+        }
+    }
+}
+
+extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, hipStream_t stream)
+{
+    if (njobs == 0 || max_tiles == 0) return hipSuccess;
+    for (uint32_t at = 0; at < njobs; at += 32768u) {
+        const uint32_t n = njobs - at < 32768u ? njobs - at : 32768u;
+        hipLaunchKernelGGL(hvq_tileq_kernel, dim3(max_tiles, n), dim3(HVQ_WG), 0, stream, jobs_dev, first_job + at);
+    }
+    return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------------------------------------------
  * Reconstruction.
  *
- * What bounds this kernel is VALU issue (profiles/r02b, r02c: ~700 vector instructions per wave at 4.2-4.7 clocks
- * each keep a SIMD with 8 waves busy for ~85 % of a wave's lifetime; removing memory round trips and barriers did
- * not shorten it), so the structure is chosen for the fewest vector instructions per block and the fullest lanes:
+ * What bounds this kernel is vector-instruction issue and, on vector-heavy streams, the per-lane address rate of the
+ * memory path, so the structure is chosen for the fewest vector instructions per block:
  *
- * Grid = (picture slots of the launch, tiles); workgroup = tile of 256 consecutive blocks of one plane.
- *   phase A   every lane owns one block: the picture's job record comes through the scalar cache (all tiles of a picture
- *             read the same one); descriptors are fetched with
- *             independent loads (own map entry, four neighbours, macroblock vector); the block's class comes from a
- *             256-entry table; cheap kinds (flat, weighted-DC, literal, plain MC) and the MC part of MC-residual
- *             blocks are reconstructed at once into the LDS tile; AOT blocks are queued for the WHOLE workgroup
- *             (intra items first, then MC-residual items; entries carry what the owner fetched) and every basis of
- *             every queued block becomes one (item, basis) pair.
- *   phase B1  one lane per PAIR, pooled over the workgroup: nest gather, min/max, gain, 16 products -> ds_add into
- *             the item's accumulators.  The serial per-block basis loop of the reference (h4m:782-788) becomes one
- *             parallel step; lane utilisation is independent of how basis counts are distributed.
- *   phase B2  one lane per queued block: accumulators -> samples (h4m:1367-1376 / 1385-1419).
+ * Grid = (picture slots of the launch, tiles); workgroup = TPW tiles of 256 consecutive blocks of one plane.
+ *   prologue  the picture's job record and the tiles' queue records come through the scalar cache; every lane requests, at
+ *             once, its block's map entry with both horizontal neighbours (ONE 8-byte load), the vertical neighbours, the
+ *             macroblock vector, its (item, basis) pair, its literal entry and its share of the nest.
+ *   phase A   every lane owns one block of each tile: flat, weighted-DC and motion-compensated blocks (and the MC part of
+ *             MC-residual blocks) are reconstructed into the LDS tile; the action follows from the type byte with a few
+ *             compares.  Literal blocks are copied by the lanes that hold the tile's literal list.
+ *   phase B1  one lane per PAIR of the tiles' pair lists (fully decoded by hvq_tileq_kernel): nest or window gather,
+ *             min/max, gain, 16 products -> ds_add into the item's accumulators.  Does not depend on phase A.
+ *   phase B2  one lane per ITEM: accumulators -> samples (h4m:1367-1376 / 1385-1419).
  *   phase C   the finished tile leaves LDS as 16-byte row segments: one store instruction of a wave
  *             writes four complete 256-byte runs of the destination plane (full lines, written once).
- * ITEMS_CAP = accumulator rows per launch (the most queued blocks of any tile of the launch, rounded up): a compile-time
+ * ITEMS_CAP = accumulator rows (the most items of any workgroup of the launch, rounded up): a compile-time
  * stride puts every accumulator address into the instruction's offset field.
+ * TPW = tiles per workgroup (1 or 2): two tiles double the memory-level parallelism of a wave -- what streams with few AOT
+ * blocks are short of -- but also the pooled accumulators (profiles/r02o_ab_two_tiles.txt).
  */
-/* TPW = tiles per workgroup (1 or 2): every lane owns one block of each, and everything of both is requested before anything
- * is used.  Two tiles double the memory-level parallelism of a wave -- what streams with few AOT blocks are short of (natural
- * preset +17 %) -- but also the LDS of the pooled queue, which costs AOT-dense streams their occupancy (dense preset -7 %):
- * hvq_launch_recon picks per launch (profiles/r02o_ab_two_tiles.txt). */
+__device__ __forceinline__ u32 gain_q(u32 w0, u32 lo, u32 hi)
+{
+    const u32 q = udiv_small(256u, (hi - lo) & 15u);                /* divTable[max - min] = 16 * (256 / r), h4m:265-271 */
+    const u32 g = (w0 & 0x3FFFFu) * (q << 4);
+    return (w0 & HVQ_PQ_NEG) ? 0u - g : g;
+}
+
+/* nest gather of one decoded pair, intra (h4m:713-725): o = index of sample (0,0), ys = row stride, both in 4-bit units */
+__device__ __forceinline__ void gather_nest_q(i32 o, bool x2, i32 ys, const uint8_t *s_nest, u32 e[16], u32 &lo, u32 &hi)
+{
+    const u32 sh = x2 ? 8u : 4u;
+    lo = 255; hi = 0;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        const i32 n = o + y * ys;
+        uint64_t q = *(const u64u *)(s_nest + (n >> 1));
+        q >>= 4 * (n & 1);
+        const u32 w0 = (u32)q;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            u32 v = (w0 >> (sh * x)) & 15u;
+            e[4 * y + x] = v;
+            lo = min(lo, v);
+            hi = max(hi, v);
+        }
+    }
+}
+
+/* window gather of one decoded pair, MC residual (h4m:734-765): voff = ring offset of sample (0,0), ys = row stride */
+__device__ __forceinline__ void gather_window_q(const GLB uint8_t *ring, u32 voff, bool x2, u32 ys, u32 e[16], u32 &lo, u32 &hi)
+{
+    const u32 sel = x2 ? 0x06040200u : 0x03020100u;
+    uint64_t q[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(voff + (u32)y * ys));
+    lo = 255; hi = 0;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        u32 w = __builtin_amdgcn_perm((u32)(q[y] >> 32), (u32)q[y], sel);
+        w = (w >> 4) & 0x0F0F0F0Fu;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            u32 v = (w >> (8 * x)) & 0xFFu;
+            e[4 * y + x] = v;
+            lo = min(lo, v);
+            hi = max(hi, v);
+        }
+    }
+}
+
 template <int ITEMS_CAP, int TPW>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
-void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ pics, u32 pair_cap HVQ_STAMP_ARG)
+void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ pics HVQ_STAMP_ARG)
 {
-    extern __shared__ __attribute__((aligned(16))) u32 s_pair[];      /* item | payload index of the basis << 9, [pair_cap] */
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];   /* nest packed two 4-bit values per byte */
     __shared__ __attribute__((aligned(16))) u32 s_out[TPW][4][HVQ_WG];   /* [tile][sample row][block] packed dwords */
-    __shared__ __attribute__((aligned(16))) u32 s_acc[16 * ITEMS_CAP];   /* AOT accumulators, [sample][queued block]: lanes of
-                                              one ds_add hit consecutive banks (a [block][16] layout is a 32-way conflict) */
-    constexpr u32 items_cap = ITEMS_CAP;
-    __shared__ u32 s_item0[ITEMS_CAP];  /* owner (tile-of-the-pair * 256 + lane) | payload offset << 10 */
-    __shared__ u32 s_item1[ITEMS_CAP];  /* map entry {value, type} */
-    __shared__ u32 s_item2[ITEMS_CAP];  /* MC-residual items: origin of the 70x38 window in the reference picture (h4m:1865-1868) */
-    __shared__ u32 s_cnt[TPW * HVQ_NW][3];
-    __shared__ u32 s_class[256];        /* block class by type byte for this plane's context (hvq_type_class) */
-
+    __shared__ __attribute__((aligned(16))) u32 s_acc[16 * ITEMS_CAP];   /* AOT accumulators, [sample][item]: lanes of
+                                              one ds_add hit consecutive banks (an [item][16] layout is a 32-way conflict) */
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
     STAMP(0, 0);
-    /* ---- the picture's job record (hot: shared by all workgroups of the picture) ---- */
-    /* grid = (8 pictures, tile pairs, groups of 8): workgroup ids run over the 8 pictures of a group first (one per XCD), then
-     * over tile pairs, then over groups -- eight pictures are in flight at a time, so their reference pictures stay in the L2s */
+    /* grid = (8 pictures, workgroups, groups of 8): workgroup ids run over the 8 pictures of a group first (one per XCD), then
+     * over a picture's workgroups, then over groups -- eight pictures are in flight at a time, so their reference pictures stay in the L2s */
     const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
     const u32 job_id = pics[slot_id].job;
     const u32 wg = blockIdx.y;
@@ -431,22 +576,22 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     /* The per-plane part of the record is read for ALL THREE planes at once and selected in registers: the empty asm pins
      * every word in a scalar register here.  Written as `p = ...; x = J->plane[p].x` the compiler selects the ADDRESS and
      * loads afterwards -- a chain of four dependent scalar loads instead of one. */
-#define HVQ_PIN(x) do { x = (u32)__builtin_amdgcn_readfirstlane((int)(x)); asm volatile("" : "+s"(x)); } while (0)
     const u32 *__restrict__ PW = (const u32 *)&J->plane[0];
     u32 w0[8], w1[8], w2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { w0[i] = PW[i]; w1[i] = PW[8 + i]; w2[i] = PW[16 + i]; }
-    u32 total_tiles = J->total_tiles;
-    /* the picture-wide part too (words 0..15 of the record: six addresses, slot size, flags, widths) */
+    /* the picture-wide part too (words 0..19 and 44, 45 of the record) */
     const u32 *__restrict__ CW = (const u32 *)J;
-    u32 cw[16];
+    u32 cw[20];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) cw[i] = CW[i];
+    for (int i = 0; i < 20; ++i) cw[i] = CW[i];
+    u32 q_pairs_off = CW[44], q_caps = CW[45];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { HVQ_PIN(w0[i]); HVQ_PIN(w1[i]); HVQ_PIN(w2[i]); }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) HVQ_PIN(cw[i]);
-    HVQ_PIN(total_tiles);
+    for (int i = 0; i < 20; ++i) HVQ_PIN(cw[i]);
+    HVQ_PIN(q_pairs_off); HVQ_PIN(q_caps);
+    const u32 total_tiles = cw[17];
     /* words of HvqPlaneRec: 0,1 map; 2,3 dst; 4 plane_off; 5 tile_first; 6 hbvb; 7 pw_sub.
      * Workgroup wg of the picture -> plane and the TPW consecutive tiles of that plane it owns (the last group may be short) */
     const u32 n0 = w1[5] - w0[5], n1 = w2[5] - w1[5], n2 = total_tiles - w2[5];
@@ -468,7 +613,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const u32 flags = cw[13];
     const u32 pic_kind = (flags >> HVQ_JOB_KIND_SHIFT) & 3u;
     const i32 unk = (i32)((flags >> HVQ_JOB_UNK_SHIFT) & 31u);
-    const int plane_id = p;
     const bool is_pb = pic_kind != HVQ_PIC_I;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
@@ -480,228 +624,212 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const float rhb = 1.0f / (float)hb;
     const GLB uint8_t *map = (const GLB uint8_t *)map_a;
 #define HVQ_W64(i) ((uint64_t)cw[i] | ((uint64_t)cw[(i) + 1] << 32))
-    const GLB uint8_t *ref0 = (const GLB uint8_t *)HVQ_W64(0), *ref1 = (const GLB uint8_t *)HVQ_W64(2);
+    const GLB uint8_t *ring = (const GLB uint8_t *)HVQ_W64(0);
+    const u32 ref0_off = cw[2], ref1_off = cw[3];
     const GLB u32 *__restrict__ pool = (const GLB u32 *)HVQ_W64(4);
     const GLB u32 *__restrict__ mvs = (const GLB u32 *)HVQ_W64(6);
-    const GLB u32 *__restrict__ wave_base = (const GLB u32 *)HVQ_W64(8);
+    const GLB uint8_t *__restrict__ qb = (const GLB uint8_t *)HVQ_W64(8);
     const GLB u32 *__restrict__ nestp = (const GLB u32 *)HVQ_W64(10);
     GLB uint8_t *plane = (GLB uint8_t *)dst_a;
     const i32 slot = (i32)cw[12];
     const i32 lw = (i32)cw[14];
     const i32 mcb_w = (i32)cw[15];
-    const GLB u32 *__restrict__ tclass = (const GLB u32 *)g_type_class + (is_pb ? 512 : plane_id == 0 ? 0 : 256);
+    const u32 q_lits_off = cw[18], q_items_off = cw[19];
+    const u32 cap_items = q_caps & 0xFFFFu, cap_pairs = q_caps >> 16;
+    /* ---- the tiles' queue records (scalar loads) ---- */
+    u32 np[TPW], ni[TPW], nl[TPW], qf = 0;
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        u32 a = 0, b = 0;
+        if (h < ntl) { const GLB u32 *__restrict__ t = (const GLB u32 *)(HVQ_W64(8) + 8u * (uint64_t)(tile0 + (u32)h)); a = t[0]; b = t[1]; }
+        HVQ_PIN(a); HVQ_PIN(b);
+        np[h] = a & 0xFFFFu; ni[h] = (a >> 16) & 0x3FFu; nl[h] = b; qf |= a;
+    }
+    const u32 npairs = TPW == 2 ? np[0] + np[TPW - 1] : np[0];
+    const u32 nitems = TPW == 2 ? ni[0] + ni[TPW - 1] : ni[0];
+    const u32 nlits = TPW == 2 ? nl[0] + nl[TPW - 1] : nl[0];
     STAMP(1, 0);
 
-    /* ---- phase A: one block of each of the two tiles per lane; everything of both is requested before anything is used ---- */
+    /* ---- every request of the prologue goes out before anything is used ---- */
     bool valid[TPW];
     i32 bx[TPW], by[TPW];
-    u32 e16[TPW], nt[TPW], nbt[TPW], nl[TPW], nr[TPW], mvw[TPW], wbase[TPW];
+    u32 e16[TPW], nt[TPW], nbt[TPW], nlf[TPW], nr[TPW], mvw[TPW];
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
         const u32 b = b0 + (u32)(h * HVQ_TILE_BLOCKS + tid);
         valid[h] = b < nblocks;
         block_coords(valid[h] ? b : 0u, hb, rhb, bx[h], by[h]);
         const GLB uint8_t *ent = map + 2 * ((by[h] + 1) * mstride + bx[h] + 1);
-        /* independent loads first: own entry, four neighbours, vector */
-        e16[h] = *(const GLB uint16_t *)ent;
+        /* left neighbour, own entry and right neighbour are six consecutive bytes of the map: one load */
+        const uint64_t m8 = *(const GLB u64u *)(ent - 2);
+        nlf[h] = (u32)m8 & 0xFFFFu; e16[h] = ((u32)m8 >> 16); nr[h] = (u32)(m8 >> 32) & 0xFFFFu;
         nt[h] = *(const GLB uint16_t *)(ent - 2 * mstride); nbt[h] = *(const GLB uint16_t *)(ent + 2 * mstride);
-        nl[h] = *(const GLB uint16_t *)(ent - 2); nr[h] = *(const GLB uint16_t *)(ent + 2);
         mvw[h] = 0;
         if (is_pb) mvw[h] = mvs[(by[h] >> (1 - hs)) * mcb_w + (bx[h] >> (1 - ws))];
-        wbase[h] = h < ntl ? wave_base[(tile0 + (u32)h) * HVQ_NW + (u32)__builtin_amdgcn_readfirstlane(wave)] : 0u;   /* scalar load */
     }
-    /* the class table travels with the descriptor loads (same round trip) and is looked up in LDS: a lookup in HBM would
-     * put one more dependent memory access in front of everything else */
-    s_class[tid] = tclass[tid];
-    __syncthreads();
-
-    u32 tc[TPW], off[TPW], pincl[TPW], nb[TPW], cls[TPW];
-    unsigned long long m1[TPW], m2[TPW];
+    /* first round of the pair list (pooled over the tiles: tile 0's pairs, then tile 1's) */
+    const GLB u32x2 *__restrict__ qpairs = (const GLB u32x2 *)(qb + q_pairs_off);
+    auto pair_at = [&](u32 pi) -> u32x2 {
+        const bool second = TPW == 2 && pi >= np[0];
+        u32x2 v = qpairs[(size_t)(tile0 + (second ? 1u : 0u)) * cap_pairs + (pi - (second ? np[0] : 0u))];
+        if (second) v.x += ni[0] << HVQ_PQ_ITEM_SHIFT;                     /* item numbers of the pooled accumulators */
+        return v;
+    };
+    u32x2 pr = { 0u, 0u };
+    if ((u32)tid < npairs) pr = pair_at((u32)tid);
+    u32 lit = 0;
+    const bool has_lit = (u32)tid < nlits;
+    if (has_lit) {
+        const bool second = TPW == 2 && (u32)tid >= nl[0];
+        lit = ((const GLB u32 *)(qb + q_lits_off))[(size_t)(tile0 + (second ? 1u : 0u)) * HVQ_TILE_BLOCKS + ((u32)tid - (second ? nl[0] : 0u))];
+        if (second) lit |= 0x80000000u;
+    }
+    const bool nest_second = tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4;
+    u32 nq0 = 0, nq1 = 0;
+    if (qf & HVQ_TQ_INTRA) { nq0 = nestp[tid]; if (nest_second) nq1 = nestp[tid + HVQ_WG]; }       /* already nibble-packed by the parser */
+    if (nitems) {
+        /* 16 * ITEMS_CAP dwords, ITEMS_CAP a multiple of 32: 16-byte stores */
+        typedef u32 u32x4z __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        tc[h] = valid[h] ? s_class[e16[h] >> 8] : 0u;
-        const u32 npay = HVQ_TC_NPAY(tc[h]);
-        /* class: 0 cheap (done in place), 1 intra AOT, 2 MC + AOT residual; nb = bases */
-        cls[h] = HVQ_TC_CLS(tc[h]);
-        nb[h] = HVQ_TC_NB(tc[h]);
-        /* payload offset / pair slot: prefix sums over the wave, skipped when the wave carries no payload at all */
-        off[h] = wbase[h]; pincl[h] = 0;
-        if (__ballot(npay != 0)) { off[h] += wave_incl_scan(npay) - npay; pincl[h] = wave_incl_scan(nb[h]); }
-        m1[h] = __ballot(cls[h] == 1); m2[h] = __ballot(cls[h] == 2);
-        if (lane == 63) { s_cnt[h * HVQ_NW + wave][0] = (u32)__popcll(m1[h]); s_cnt[h * HVQ_NW + wave][1] = (u32)__popcll(m2[h]); s_cnt[h * HVQ_NW + wave][2] = pincl[h]; }
+        for (u32 i = (u32)tid; i < 4u * ITEMS_CAP; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
     }
     STAMP(2, 1);
 
-    /* motion-compensation rows of both blocks go out before either is filtered */
+    /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
+    const u32 kmask = (is_pb || p != 0) ? 0xFu : 0xFFu;                  /* I-picture luma: the kind is the whole byte (h4m:1093) */
     McRows rows[TPW];
     int hxy[TPW];
+    bool act_mc[TPW];
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
+        const u32 T = e16[h] >> 8;
+        /* motion compensated: inter macroblock, anything but a literal block (h4m:1862-1910, 1327-1355) */
+        act_mc[h] = valid[h] && is_pb && (T & 0x60u) && (T & 0x1Fu) != 6u;
         hxy[h] = 0;
-        if (tc[h] & HVQ_TC_MC) {
+        if (act_mc[h]) {
             /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
-            const u32 T = e16[h] >> 8;
             const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFF), ry = (i32)(int16_t)(mvw[h] >> 16);
-            const GLB uint8_t *ref = (((T >> 5) & 3u) == 1u) ? ref0 : ref1;
+            const u32 roff = (((T >> 5) & 3u) == 1u) ? ref0_off : ref1_off;
             const i32 pdx = rx >> ws, pdy = ry >> hs;
             const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
             i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by[h] & (1 - hs)) * 4 * pw + (bx[h] & (1 - ws)) * 4;
             /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
             a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
-            rows[h] = mc_load(ref, a, pw, hy);
+            const u32 vo = roff + (u32)a;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(y * pw)));
+            rows[h].q[4] = 0;
+            if (hy) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(4 * pw)));
             hxy[h] = hx | (hy << 1);
         }
     }
+    if (qf & HVQ_TQ_INTRA) {
+        ((u32 *)s_nest)[tid] = nq0;
+        if (nest_second) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
+    }
+    /* literal blocks (h4m:543-549): the lanes that hold the literal list copy them into the tile */
+    if (has_lit) {
+        typedef u32 u32x4l __attribute__((ext_vector_type(4), aligned(4)));
+        const u32x4l v = *(const GLB u32x4l *)(pool + ((lit & 0x7FFFFFFFu) >> 8));
+        u32 *so = &s_out[TPW == 2 ? (lit >> 31) : 0][0][lit & 0xFFu];
+        so[0] = v.x; so[HVQ_WG] = v.y; so[2 * HVQ_WG] = v.z; so[3 * HVQ_WG] = v.w;
+    }
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
-        if (valid[h] && cls[h] != 1) {
-            Blk o;
-            const i32 V = e16[h] & 0xFF;
-            if (tc[h] & HVQ_TC_MC) {
-                if (HVQ_ABL == 3) { o.r[0] = (u32)rows[h].q[0]; o.r[1] = (u32)rows[h].q[1]; o.r[2] = (u32)rows[h].q[2]; o.r[3] = (u32)(rows[h].q[3] ^ rows[h].q[4]); }
-                else o = mc_filter(rows[h], hxy[h] & 1, hxy[h] >> 1);
-            } else if (tc[h] & HVQ_TC_WDC) {
-                /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
-                 * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
-                i32 Tt = (nt[h] & 0x7700u) ? V : (i32)(nt[h] & 0xFF);
-                i32 Bb = (nbt[h] & 0x7700u) ? V : (i32)(nbt[h] & 0xFF);
-                i32 Rr = (nr[h] & 0x7700u) ? V : (i32)(nr[h] & 0xFF);
-                bool lexp = is_pb ? !(nl[h] & 0x7700u) : ((nl[h] >> 8) == 0 || (nl[h] >> 8) == 8);
-                i32 Ll = lexp ? (i32)(nl[h] & 0xFF) : V;
-                if (HVQ_ABL == 3) { o.r[0] = (u32)Tt; o.r[1] = (u32)Bb; o.r[2] = (u32)Rr; o.r[3] = (u32)Ll; }
-                else o = weight_block(V, Tt, Bb, Ll, Rr);
-            } else {
-                /* flat DC (h4m:281-286) or literal (h4m:543-549) */
-                const u32 v = (u32)V * 0x01010101u;
-                o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
-                if (tc[h] & HVQ_TC_LIT) { const GLB u32 *pay = pool + off[h]; o.r[0] = pay[0]; o.r[1] = pay[1]; o.r[2] = pay[2]; o.r[3] = pay[3]; }
-            }
+        const u32 T = e16[h] >> 8, k = T & kmask;
+        const i32 V = e16[h] & 0xFF;
+        const bool intra = !(is_pb && (T & 0x60u));
+        Blk o;
+        if (act_mc[h]) {
+            o = mc_filter(rows[h], hxy[h] & 1, hxy[h] >> 1);
+        } else if (valid[h] && intra && k == 0u) {
+            /* weighted DC (h4m:299-383): neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442,
+             * 1811-1814).  I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
+            i32 Tt = (nt[h] & 0x7700u) ? V : (i32)(nt[h] & 0xFF);
+            i32 Bb = (nbt[h] & 0x7700u) ? V : (i32)(nbt[h] & 0xFF);
+            i32 Rr = (nr[h] & 0x7700u) ? V : (i32)(nr[h] & 0xFF);
+            bool lexp = is_pb ? !(nlf[h] & 0x7700u) : ((nlf[h] >> 8) == 0 || (nlf[h] >> 8) == 8);
+            i32 Ll = lexp ? (i32)(nlf[h] & 0xFF) : V;
+            o = weight_block(V, Tt, Bb, Ll, Rr);
+        } else if (valid[h] && intra && k == 8u) {
+            const u32 v = (u32)V * 0x01010101u;                               /* flat DC (h4m:281-286) */
+            o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
+        } else continue;                                                       /* literal or AOT: the lists do it */
 #pragma unroll
-            for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
-        }
+        for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
     }
     STAMP(3, 1);
-
-    __syncthreads();                                                           /* barrier 1: queue counts */
+    if (nitems) __syncthreads();                                              /* barrier 1: nest staged, accumulators zero */
     STAMP(4, 0);
-    /* the queue is pooled over both tiles: intra items first, then MC-residual items, each in (tile, wave, lane) order */
-    u32 nI = 0, nP = 0, npairs = 0, myI[TPW], myP[TPW], pbefore[TPW];
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) { myI[h] = 0; myP[h] = 0; pbefore[h] = 0; }
-#pragma unroll
-    for (int v = 0; v < TPW * HVQ_NW; ++v) {
-        const u32 ci = s_cnt[v][0], cp = s_cnt[v][1], cb = s_cnt[v][2];
-#pragma unroll
-        for (int h = 0; h < TPW; ++h)
-            if (v < h * HVQ_NW + wave) { myI[h] += ci; myP[h] += cp; pbefore[h] += cb; }
-        nI += ci; nP += cp; npairs += cb;
-    }
-    const u32 total = min(nI + nP, items_cap);         /* items_cap covers every tile pair of the launch (flush_end) */
-    const bool parallel = npairs <= pair_cap && nI + nP <= items_cap;
-    if (total && parallel) {
-        /* 16 * items_cap dwords, items_cap a multiple of 32: 16-byte stores */
-        typedef u32 u32x4z __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (u32 i = (u32)tid; i < 4u * items_cap; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
-    }
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        if (cls[h]) {
-            const u32 slotq = cls[h] == 1 ? myI[h] + lanes_below(m1[h]) : nI + myP[h] + lanes_below(m2[h]);
-            if (slotq < items_cap) {
-                s_item0[slotq] = (u32)(h * HVQ_WG + tid) | (off[h] << 10);
-                s_item1[slotq] = e16[h];
-                if (cls[h] == 2) {
-                    const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFF), ry = (i32)(int16_t)(mvw[h] >> 16);
-                    s_item2[slotq] = (u32)(landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16);
-                }
-                if (parallel) {
-                    const u32 pstart = pbefore[h] + pincl[h] - nb[h], bidx = off[h] + (cls[h] == 2 ? 2u : 0u);
-                    u32 ent = slotq | (bidx << 9);
-                    u32 *dst = s_pair + pstart;
-#pragma clang loop unroll(disable) vectorize(disable)
-                    for (u32 k = 0; k < nb[h]; ++k, ent += 1u << 9) dst[k] = ent;      /* 1..15 entries: keep the loop as written */
-                }
-            }
-        }
-    }
-    if (nI) {
-        const GLB u32 *src = nestp;                                   /* already nibble-packed by the host */
-        const bool second = tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4;
-        const u32 q0 = src[tid], q1 = second ? src[tid + HVQ_WG] : 0u;               /* both loads in flight together */
-        ((u32 *)s_nest)[tid] = q0;
-        if (second) ((u32 *)s_nest)[tid + HVQ_WG] = q1;
-    }
-    STAMP(5, 1);
-    if (total) __syncthreads();                                                /* barrier 2: queue + nest staged */
-    STAMP(6, 0);
 
-    if (total) {
-        if (parallel) {
-            /* ---- phase B1: one lane per (item, basis) pair ---- */
-            for (u32 pi = (u32)tid; pi < ((HVQ_ABL == 2 || HVQ_ABL == 4) ? 0u : npairs); pi += HVQ_WG) {
-                const u32 pr = s_pair[pi];
-                const u32 it = pr & 511u;
-                const u32 d = pool[pr >> 9];
-                u32 e[16], lo, hi;
-                if (it < nI) {
-                    gather_nest(d, landscape, s_nest, e, lo, hi);
-                } else {
-                    const u32 t16 = s_item1[it];
-                    const i32 origin = (i32)s_item2[it];
-                    const GLB uint8_t *ref = ((t16 >> 13) & 3u) == 1u ? ref0 : ref1;
-                    gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
-                }
-#if defined(HVQ_ABL) && HVQ_ABL == 8             /* ablation: gathers kept, gain / products / adds replaced by one add */
-                __hip_atomic_fetch_add(s_acc + it, e[0] ^ e[5] ^ e[10] ^ e[15] ^ lo ^ hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-                basis_scatter<ITEMS_CAP>(basis_gain(d, lo, hi), e, s_acc + it);
-#endif
-            }
-            STAMP(7, 1);
-            __syncthreads();                                                   /* barrier 3: accumulators complete */
-            STAMP(8, 0);
+    if (nitems) {
+        /* ---- phase B1: one lane per (item, basis) pair ---- */
+        const i32 nstride = landscape ? 70 : 38;
+        for (u32 pi = (u32)tid; pi < npairs; ) {
+            const u32 it = pr.x >> HVQ_PQ_ITEM_SHIFT;
+            const bool x2 = pr.x & HVQ_PQ_X2;
+            u32 e[16], lo, hi;
+            if (pr.x & HVQ_PQ_MC) gather_window_q(ring, pr.y, x2, (u32)lw << ((pr.x >> 20) & 1u), e, lo, hi);
+            else gather_nest_q((i32)pr.y, x2, nstride << ((pr.x >> 20) & 1u), s_nest, e, lo, hi);
+            basis_scatter<ITEMS_CAP>(gain_q(pr.x, lo, hi), e, s_acc + it);
+            pi += HVQ_WG;
+            if (pi < npairs) pr = pair_at(pi);
         }
-        /* ---- phase B2: one lane per queued block (two rounds when the pair of tiles queued more than 256) ---- */
-        for (u32 it = (u32)tid; it < total; it += HVQ_WG) {
-            const u32 item = s_item0[it];
-            const u32 owner = item & 1023u;
-            const GLB u32 *__restrict__ qpay = pool + (item >> 10);
-            const u32 q16 = s_item1[it];
-            const bool item_mc = it >= nI;
-            u32 p0 = 0, p1 = 0;
-            if (item_mc) { p0 = qpay[0]; p1 = qpay[1]; }
+        STAMP(7, 1);
+        /* ---- phase B2: one lane per item (two rounds when a pair of tiles queued more than 256) ---- */
+        typedef u32 u32x4i __attribute__((ext_vector_type(4)));
+        const GLB u32x4i *__restrict__ qitems = (const GLB u32x4i *)(qb + q_items_off);
+        auto item_at = [&](u32 it) -> u32x4i {
+            const bool second = TPW == 2 && it >= ni[0];
+            return qitems[(size_t)(tile0 + (second ? 1u : 0u)) * cap_items + (it - (second ? ni[0] : 0u))];
+        };
+        u32x4i rec = (u32x4i)(0u);
+        if ((u32)tid < nitems) rec = item_at((u32)tid);                        /* travels while the barrier is waited for */
+        __syncthreads();                                                       /* barrier 2: accumulators complete */
+        STAMP(8, 0);
+        for (u32 it = (u32)tid; it < nitems; it += HVQ_WG) {
+            const bool second = TPW == 2 && it >= ni[0];
+            if (it != (u32)tid) rec = item_at(it);
+            const u32 owner = rec.x & 0xFFu, q16 = (rec.x >> 8) & 0xFFFFu;
+            const bool item_mc = is_pb && (q16 & 0x6000u);
             u32 r[16];
-            if (parallel) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) r[i] = s_acc[i * ITEMS_CAP + it];
-            } else {
-                /* serial fallback for tile pairs whose pair list exceeds the launch's LDS sizing (pathological streams) */
+            for (int i = 0; i < 16; ++i) r[i] = s_acc[i * ITEMS_CAP + it];
+            if (qf & HVQ_TQ_SERIAL) {
+                /* a tile whose pair list exceeds what the picture reserves (pathological streams): the item walks its bases */
+                const bool ser = (second ? np[TPW - 1] : np[0]) == 0u;          /* a serial tile has no pair list */
+                const u32 kind = (q16 >> 8) & kmask;
+                const u32 n = item_mc ? (kind & 0xFu) - 1u : kind;
+                if (ser) {
+                    const GLB u32 *bases = pool + rec.y + (item_mc ? 2u : 0u);
+                    i32 origin = 0;
+                    u32 roff = 0;
+                    if (item_mc) {
+                        i32 ox, oy;
+                        block_coords(b0 + (second ? HVQ_TILE_BLOCKS : 0u) + owner, hb, rhb, ox, oy);
+                        const u32 mv = mvs[(oy >> (1 - hs)) * mcb_w + (ox >> (1 - ws))];
+                        const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
+                        origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
+                        roff = ((q16 >> 13) & 3u) == 1u ? ref0_off : ref1_off;
+                    }
+                    for (u32 k = 0; k < n; ++k) {
+                        const u32 d = bases[k];
+                        u32 e[16], lo, hi;
+                        if (!item_mc) gather_nest(d, landscape, s_nest, e, lo, hi);
+                        else gather_window(d, landscape, ring + roff, origin, lw, slot, e, lo, hi);
+                        const u32 g = basis_gain(d, lo, hi);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) r[i] = 0;
-                const u32 n = HVQ_TC_NB(s_class[q16 >> 8]);
-                const GLB u32 *bases = qpay + (item_mc ? 2 : 0);
-                const i32 origin = (i32)s_item2[it];
-                const GLB uint8_t *ref = ((q16 >> 13) & 3u) == 1u ? ref0 : ref1;
-                for (u32 k = 0; k < n; ++k) {
-                    const u32 d = bases[k];
-                    u32 e[16], lo, hi;
-                    if (!item_mc) gather_nest(d, landscape, s_nest, e, lo, hi);
-                    else gather_window(d, landscape, ref, origin, lw, slot, e, lo, hi);
-                    const u32 g = basis_gain(d, lo, hi);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) r[i] += g * e[i];
+                        for (int i = 0; i < 16; ++i) r[i] += g * e[i];
+                    }
                 }
             }
-            u32 *so = &s_out[0][0][0] + (owner >> 8) * (4 * HVQ_WG) + (owner & 255u);
+            u32 *so = &s_out[second ? TPW - 1 : 0][0][owner];
             Blk o;
-            if (HVQ_ABL == 1 || HVQ_ABL == 4) {
-                o.r[0] = r[0] ^ p0; o.r[1] = r[5] ^ p1; o.r[2] = r[10]; o.r[3] = r[15] ^ q16;
-            } else if (item_mc) {
+            if (item_mc) {
                 Blk m;                                       /* the owner left the MC block in the tile */
 #pragma unroll
                 for (int y = 0; y < 4; ++y) m.r[y] = so[y * HVQ_WG];
-                o = predi_finish(r, m, p0, p1, unk);
+                o = predi_finish(r, m, rec.z, rec.w, unk);
             } else {
                 o = intra_finish(r, (i32)(q16 & 0xFF), unk);
             }
@@ -709,12 +837,12 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             for (int y = 0; y < 4; ++y) so[y * HVQ_WG] = o.r[y];
         }
         STAMP(9, 1);
-        __syncthreads();                                                       /* barrier 4: tiles complete in LDS */
-        STAMP(10, 0);
     }
+    __syncthreads();                                                           /* barrier 3: tiles complete in LDS */
+    STAMP(10, 0);
 
     /* ---- phase C: tiles -> HBM ---- */
-    STAMP(11, 0);
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
         if ((hb & 3) == 0) {
@@ -744,41 +872,39 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 }
 
 template <int ITEMS_CAP, int TPW>
-static void launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs, uint32_t pair_cap,
-                         hipStream_t stream)
+static void launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs, hipStream_t stream)
 {
     const dim3 grid = nslots >= 8 ? dim3(8, max_wgs, nslots / 8) : dim3(nslots, max_wgs, 1);     /* nslots is a multiple of 8 then */
 #ifdef HVQ_STAMPS
-    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 4u * pair_cap, stream, jobs_dev, pics_dev, pair_cap, g_stamps);
+    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, pics_dev, g_stamps);
 #else
-    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 4u * pair_cap, stream, jobs_dev, pics_dev, pair_cap);
+    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, pics_dev);
 #endif
 }
 
 /* pics_dev: the launch's picture slots {job, tiles} (count a multiple of 8 when there are at least 8 pictures);
  * tiles_per_wg: 1 or 2; max_wgs: the most workgroups of any picture of the launch at that setting;
- * items_cap: the most queued blocks of any workgroup of the launch (it selects the instantiation with the next larger
- * accumulator array); pair_cap: the most (block, basis) pairs of any workgroup (dynamic LDS, beyond it the serial fallback) */
+ * items_cap: the most items of any workgroup of the launch (it selects the instantiation with the next larger accumulator array) */
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs,
-                                       uint32_t tiles_per_wg, uint32_t items_cap, uint32_t pair_cap, hipStream_t stream)
+                                       uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream)
 {
     if (nslots == 0 || max_wgs == 0) return hipSuccess;
     if (tiles_per_wg >= 2) {
-        if (items_cap <= 32) launch_recon<32, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 64) launch_recon<64, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 96) launch_recon<96, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 128) launch_recon<128, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 192) launch_recon<192, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 256) launch_recon<256, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 384) launch_recon<384, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else launch_recon<512, 2>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        if (items_cap <= 32) launch_recon<32, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 64) launch_recon<64, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 96) launch_recon<96, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 128) launch_recon<128, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 192) launch_recon<192, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 256) launch_recon<256, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 384) launch_recon<384, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else launch_recon<512, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
     } else {
-        if (items_cap <= 32) launch_recon<32, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 64) launch_recon<64, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 96) launch_recon<96, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 128) launch_recon<128, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else if (items_cap <= 192) launch_recon<192, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
-        else launch_recon<256, 1>(jobs_dev, pics_dev, nslots, max_wgs, pair_cap, stream);
+        if (items_cap <= 32) launch_recon<32, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 64) launch_recon<64, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 96) launch_recon<96, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 128) launch_recon<128, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else if (items_cap <= 192) launch_recon<192, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        else launch_recon<256, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
     }
     return hipGetLastError();
 }

@@ -43,7 +43,8 @@ extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t tot
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs,
-                                       uint32_t tiles_per_wg, uint32_t items_cap, uint32_t pair_cap, hipStream_t stream);
+                                       uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream);
+extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, hipStream_t stream);
 extern "C" hipError_t hvq_upload_tables(void);
 
 #ifdef HVQ_STAMPS
@@ -157,7 +158,7 @@ struct Launch {
     uint32_t max_tiles, workgroups;    /* grid = (8, max_tiles, slots / 8) at the chosen tiles per workgroup; workgroups that do work */
     uint32_t max_wg[2], wgs[2];        /* the same for one / two tiles per workgroup (chosen at flush_end, when the queues are known) */
     uint32_t tpw;
-    uint32_t items_cap, pair_cap;      /* LDS sizing of the launch: max over its pictures */
+    uint32_t items_cap;                /* LDS sizing of the launch: max over its pictures */
 };
 
 struct HvqContext {
@@ -201,6 +202,8 @@ struct HvqContext {
     HvqJob *jobs_dev = nullptr;
     HvqTileRef *tiles_dev = nullptr;
     size_t jobs_cap = 0, tiles_cap = 0;
+    uint8_t *tq_dev = nullptr;         /* tile queues of the resident batch (hvq_tileq_kernel), read by every (re)play */
+    size_t tq_cap = 0;
     std::vector<Launch> launches;
     std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
     HvqStats stats{};
@@ -341,6 +344,7 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tiles_dev) (void)hipFree(c->tiles_dev);
+    if (c->tq_dev) (void)hipFree(c->tq_dev);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
     if (c->rgb_jobs_dev) (void)hipFree(c->rgb_jobs_dev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -882,7 +886,7 @@ static int run_launches(HvqContext *c)
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     for (auto &L : c->launches)
-        HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap,
+        HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap,
                                 L.queue ? c->stream2 : c->stream));
     if (two) {
         HIPCHK(hipEventRecord(c->ev_join, c->stream2));
@@ -1043,6 +1047,9 @@ static int flush_end(HvqContext *c)
     /* 2. job table (the tile table went up at begin) */
     std::vector<HvqJob> &jobs = c->jobs_host;
     jobs.assign(c->fl_pending.size(), HvqJob{});
+    std::vector<size_t> tq_off(c->fl_pending.size(), 0);
+    size_t tq_bytes = 0;
+    uint32_t max_tiles = 0;
     HvqStats st{};
     for (size_t i = 0; i < c->fl_pending.size(); ++i) {
         const Pending &p = c->fl_pending[i];
@@ -1059,8 +1066,9 @@ static int flush_end(HvqContext *c)
         const HvqPicHeader *hd = p.dev ? &hdev : (const HvqPicHeader *)(c->fl_host + p.blob_off);
         const uint64_t blob = p.dev ? p.dev_blob : (uint64_t)(uintptr_t)(c->fl_dev + p.blob_off);
         const uint64_t dst = (uint64_t)(uintptr_t)s.slot_ptr(p.dst);
-        j.ref0 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref0);
-        j.ref1 = (uint64_t)(uintptr_t)s.slot_ptr(p.ref1);
+        j.ring = (uint64_t)(uintptr_t)s.dev;                 /* every reference read is ring + a 32-bit offset */
+        j.ref0_off = (uint32_t)(s.slot_ptr(p.ref0) - s.dev);
+        j.ref1_off = (uint32_t)(s.slot_ptr(p.ref1) - s.dev);
         j.pool = blob + hd->pool_off;
         j.mv = blob + hd->mv_off;
         j.wave_base = blob + hd->wave_base_off;
@@ -1073,6 +1081,19 @@ static int flush_end(HvqContext *c)
         j.pool_dwords = p.dev ? p.pool_dwords : hd->pool_dwords;
         j.total_tiles = p.dropped ? 0u : hd->tile_first[3];          /* 0: the tile records of this picture become padding entries */
         if (p.dropped) continue;
+        {   /* the picture's tile queues: per tile a record, a literal list, and item and pair lists sized for its fullest tile */
+            const uint32_t nt = hd->tile_first[3];
+            const uint32_t cap_items = std::min(256u, (uint32_t)p.max_items), cap_pairs = std::min(HVQ_PAIR_CAP_MAX, p.max_pairs);
+            tq_bytes = align_up(tq_bytes, 256);
+            tq_off[i] = tq_bytes;
+            const size_t lits = align_up((size_t)nt * sizeof(HvqTileQ), 16), items = lits + (size_t)nt * HVQ_TILE_BLOCKS * 4,
+                         pairs = items + (size_t)nt * cap_items * 16, end = pairs + (size_t)nt * cap_pairs * 8;
+            if (end >= ((size_t)1 << 32)) return fail(HVQ_E_OVERFLOW, "stream %d picture %d: tile queues exceed 4 GiB", p.stream, p.ordinal);
+            j.q_lits_off = (uint32_t)lits; j.q_items_off = (uint32_t)items; j.q_pairs_off = (uint32_t)pairs;
+            j.q_caps = cap_items | (cap_pairs << 16);
+            tq_bytes += end;
+            max_tiles = std::max(max_tiles, nt);
+        }
         for (int k = 0; k < 3; ++k) {
             HvqPlaneRec &r = j.plane[k];
             r.map = blob + hd->map_off[k];
@@ -1107,7 +1128,7 @@ static int flush_end(HvqContext *c)
         /* the AOT density of the launch decides: payload dwords per tile (dense synthetic stream ~220, realistic ~35, flat ~1) */
         L.tpw = force_tpw ? (force_tpw >= 2 ? 2u : 1u) : (payload < 128u * std::max<uint64_t>(ntl, 1) ? 2u : 1u);
         L.items_cap = std::min(256u * L.tpw, std::max(32u, L.tpw * mi));
-        L.pair_cap = std::min(1024u * L.tpw, (L.tpw * mp + 63u) & ~63u);
+        (void)mp;
         L.max_tiles = L.max_wg[L.tpw - 1]; L.workgroups = L.wgs[L.tpw - 1];
         st.workgroups += L.workgroups;
     }
@@ -1121,8 +1142,18 @@ static int flush_end(HvqContext *c)
         c->jobs_cap = jobs.size() * 2;
         HIPCHK(hipMalloc((void **)&c->jobs_dev, c->jobs_cap * sizeof(HvqJob)));
     }
+    if (tq_bytes > c->tq_cap) {
+        if (c->tq_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tq_dev)); c->tq_dev = nullptr; c->tq_cap = 0; }
+        const size_t ncap = align_up(tq_bytes + tq_bytes / 4, 4096);
+        HIPCHK(hipMalloc((void **)&c->tq_dev, ncap));
+        c->tq_cap = ncap;
+    }
+    for (size_t i = 0; i < jobs.size(); ++i)
+        if (jobs[i].total_tiles) jobs[i].tq = (uint64_t)(uintptr_t)(c->tq_dev + tq_off[i]);
     /* stream-ordered after whatever still reads the previous table */
     { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return rcu; }
+    /* 2b. tile queues: once per picture, from the descriptors (type bytes, vectors, basis words) that are now all in HBM */
+    HIPCHK(hvq_launch_tileq(c->jobs_dev, 0, (uint32_t)jobs.size(), max_tiles, c->stream));
     /* 3. one launch per level */
     { int rc = run_launches(c); if (rc) return rc; }
     if (!c->fl_nest_pairs.empty()) {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
@@ -1186,7 +1217,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
             HIPCHK(hipMalloc((void **)&d, n * 8));
             HIPCHK(hipMemsetAsync(d, 0, n * 8, c->stream));
             hvq_set_stamps(d);
-            HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, c->stream));
+            HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, c->stream));
             hvq_set_stamps(nullptr);
             std::vector<unsigned long long> h(n);
             HIPCHK(hipStreamSynchronize(c->stream));

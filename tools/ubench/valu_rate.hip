@@ -50,6 +50,37 @@ KERNEL(sad_u8,       V3("v_sad_u8"))
             asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r4) : "v"(a)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r5) : "v"(a)); \
             asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r6) : "v"(a)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r7) : "v"(a));
 KERNEL(cndmask, CND)
+/* round 3: the 21.7-clock figure of `cndmask` above is an artefact of that test, not of the instruction: its asm reads VCC
+ * without declaring it, so nothing in the kernel ever writes VCC and the selects return r0 unchanged -- but each one still
+ * names the SAME register as source and destination in a chain of 4 per register per iteration with no other work between
+ * them, and the implicit VCC read makes every select wait for the loop's s_cmp/s_cbranch pair.  The two tests below hold the
+ * mask in an SGPR pair written once before the loop (what compiled code does: v_cmp -> s[..] -> v_cndmask). */
+__global__ __launch_bounds__(256, 8) void k_cndmask_sgpr(uint32_t *out, int iters, uint32_t seed)
+{
+    uint32_t r0 = threadIdx.x + seed, r1 = r0 * 3 + 1, r2 = r0 * 5 + 2, r3 = r0 * 7 + 3,
+             r4 = r0 * 11 + 4, r5 = r0 * 13 + 5, r6 = r0 * 17 + 6, r7 = r0 * 19 + 7;
+    uint32_t a = seed | 1;
+    unsigned long long m = __ballot((threadIdx.x * 2654435761u + seed) & 0x10000u);
+    for (int i = 0; i < iters; ++i) {
+#define CS(r) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(r) : "v"(a), "s"(m));
+#define CSB CS(r0) CS(r1) CS(r2) CS(r3) CS(r4) CS(r5) CS(r6) CS(r7)
+        CSB CSB CSB CSB
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+}
+/* compare + select pairs as rgb_clamp / clampi compile them: v_cmp_gt_u32 -> SGPR pair, v_cndmask on it (2 instructions) */
+__global__ __launch_bounds__(256, 8) void k_cmp_cndmask(uint32_t *out, int iters, uint32_t seed)
+{
+    uint32_t r0 = threadIdx.x + seed, r1 = r0 * 3 + 1, r2 = r0 * 5 + 2, r3 = r0 * 7 + 3,
+             r4 = r0 * 11 + 4, r5 = r0 * 13 + 5, r6 = r0 * 17 + 6, r7 = r0 * 19 + 7;
+    uint32_t a = seed | 1;
+    for (int i = 0; i < iters; ++i) {
+#define CC(r) { unsigned long long m_; asm volatile("v_cmp_gt_u32 %1, %0, %2\n\tv_cndmask_b32 %0, %0, %2, %1" : "+v"(r), "=&s"(m_) : "v"(a)); }
+#define CCB CC(r0) CC(r1) CC(r2) CC(r3) CC(r4) CC(r5) CC(r6) CC(r7)
+        CCB CCB
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+}
 #define DPP asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r0)); asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r1)); \
             asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r2)); asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r3)); \
             asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r4)); asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r5)); \
@@ -143,7 +174,7 @@ int main()
 #define RUN(n) run(k_##n, #n, out, 32.0)
     RUN(add_u32); RUN(and_b32); RUN(lshrrev_b32); RUN(mul_i32_i24); RUN(mul_lo_u32); RUN(min_u32); RUN(pk_add_u16);
     RUN(mad_i32_i24); RUN(bfe_u32); RUN(min3_u32); RUN(perm_b32); RUN(lerp_u8); RUN(add3_u32); RUN(lshl_add_u32); RUN(sad_u8);
-    RUN(cndmask); RUN(add_dpp); RUN(lshrrev_b64);
+    RUN(cndmask); RUN(cndmask_sgpr); RUN(cmp_cndmask); RUN(add_dpp); RUN(lshrrev_b64);
     run(k_s_add_u32, "s_add_u32", out, 32.0);
     run(k_ds_add, "ds_add_u32", out, 32.0);
     run(k_ds_add_same4, "ds_add_u32 x4same", out, 32.0);
