@@ -369,7 +369,8 @@ extern "C" hipError_t hvq_upload_tables(void)
 }
 
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-#define HVQ_PIN(x) do { x = (u32)__builtin_amdgcn_readfirstlane((int)(x)); asm volatile("" : "+s"(x)); } while (0)
+/* not `volatile`: a volatile asm counts as a store to anything, and every scalar load after it would become a vector load */
+#define HVQ_PIN(x) do { x = (u32)__builtin_amdgcn_readfirstlane((int)(x)); asm("" : "+s"(x)); } while (0)
 
 /* ------------------------------------------------------------------------------------------------------
  * Tile queues (hvq_desc.h): once per picture, when its descriptors arrive -- part of the parse stage, not of the
@@ -558,7 +559,7 @@ __device__ __forceinline__ void gather_window_q(const GLB uint8_t *ring, u32 vof
 
 template <int ITEMS_CAP, int TPW>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
-void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ pics HVQ_STAMP_ARG)
+void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ pics, const HvqTileQ *__restrict__ tq_all HVQ_STAMP_ARG)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];   /* nest packed two 4-bit values per byte */
     __shared__ __attribute__((aligned(16))) u32 s_out[TPW][4][HVQ_WG];   /* [tile][sample row][block] packed dwords */
@@ -636,12 +637,15 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const i32 mcb_w = (i32)cw[15];
     const u32 q_lits_off = cw[18], q_items_off = cw[19];
     const u32 cap_items = q_caps & 0xFFFFu, cap_pairs = q_caps >> 16;
-    /* ---- the tiles' queue records (scalar loads) ---- */
+    /* ---- the tiles' queue records.  Scalar loads: they are addressed through the kernel argument (the batch's queue buffer,
+     * which holds the job's `tq`), because only a load the compiler can prove read-only becomes s_load -- through an address
+     * taken from the job record it is a vector load with a full wait in front of everything else ---- */
+    const u32 tq_idx = (u32)((HVQ_W64(8) - (uint64_t)(uintptr_t)tq_all) >> 3) + tile0;
     u32 np[TPW], ni[TPW], nl[TPW], qf = 0;
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
         u32 a = 0, b = 0;
-        if (h < ntl) { const GLB u32 *__restrict__ t = (const GLB u32 *)(HVQ_W64(8) + 8u * (uint64_t)(tile0 + (u32)h)); a = t[0]; b = t[1]; }
+        if (h < ntl) { a = tq_all[tq_idx + (u32)h].w0; b = tq_all[tq_idx + (u32)h].w1; }
         HVQ_PIN(a); HVQ_PIN(b);
         np[h] = a & 0xFFFFu; ni[h] = (a >> 16) & 0x3FFu; nl[h] = b; qf |= a;
     }
@@ -669,21 +673,18 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     }
     /* first round of the pair list (pooled over the tiles: tile 0's pairs, then tile 1's) */
     const GLB u32x2 *__restrict__ qpairs = (const GLB u32x2 *)(qb + q_pairs_off);
-    auto pair_at = [&](u32 pi) -> u32x2 {
+    auto pair_at = [&](u32 pi) -> u32x2 {                                   /* nothing here may USE the loaded words: that would wait for them */
         const bool second = TPW == 2 && pi >= np[0];
-        u32x2 v = qpairs[(size_t)(tile0 + (second ? 1u : 0u)) * cap_pairs + (pi - (second ? np[0] : 0u))];
-        if (second) v.x += ni[0] << HVQ_PQ_ITEM_SHIFT;                     /* item numbers of the pooled accumulators */
-        return v;
+        return qpairs[(size_t)(tile0 + (second ? 1u : 0u)) * cap_pairs + (pi - (second ? np[0] : 0u))];
     };
     u32x2 pr = { 0u, 0u };
     if ((u32)tid < npairs) pr = pair_at((u32)tid);
+    /* the literal list is held by the LAST lanes of the workgroup: the first waves already carry the pair and item lists */
     u32 lit = 0;
-    const bool has_lit = (u32)tid < nlits;
-    if (has_lit) {
-        const bool second = TPW == 2 && (u32)tid >= nl[0];
-        lit = ((const GLB u32 *)(qb + q_lits_off))[(size_t)(tile0 + (second ? 1u : 0u)) * HVQ_TILE_BLOCKS + ((u32)tid - (second ? nl[0] : 0u))];
-        if (second) lit |= 0x80000000u;
-    }
+    const u32 li = (u32)(HVQ_WG - 1 - tid);
+    const bool has_lit = li < nlits;
+    const bool lit_second = TPW == 2 && li >= nl[0];
+    if (has_lit) lit = ((const GLB u32 *)(qb + q_lits_off))[(size_t)(tile0 + (lit_second ? 1u : 0u)) * HVQ_TILE_BLOCKS + (li - (lit_second ? nl[0] : 0u))];
     const bool nest_second = tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4;
     u32 nq0 = 0, nq1 = 0;
     if (qf & HVQ_TQ_INTRA) { nq0 = nestp[tid]; if (nest_second) nq1 = nestp[tid + HVQ_WG]; }       /* already nibble-packed by the parser */
@@ -692,6 +693,15 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         typedef u32 u32x4z __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (u32 i = (u32)tid; i < 4u * ITEMS_CAP; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
+    }
+    /* literal blocks (h4m:543-549): second hop right behind the prologue's loads, in front of the motion-compensation rows */
+    typedef u32 u32x4l __attribute__((ext_vector_type(4), aligned(4)));
+    u32x4l litv = { 0u, 0u, 0u, 0u };
+    if (has_lit) litv = *(const GLB u32x4l *)(pool + (lit >> 8));
+    /* the nest goes to LDS here: behind the conditional fifth row load below the compiler can only wait for ALL loads */
+    if (qf & HVQ_TQ_INTRA) {
+        ((u32 *)s_nest)[tid] = nq0;
+        if (nest_second) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
     }
     STAMP(2, 1);
 
@@ -723,17 +733,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             hxy[h] = hx | (hy << 1);
         }
     }
-    if (qf & HVQ_TQ_INTRA) {
-        ((u32 *)s_nest)[tid] = nq0;
-        if (nest_second) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
-    }
-    /* literal blocks (h4m:543-549): the lanes that hold the literal list copy them into the tile */
-    if (has_lit) {
-        typedef u32 u32x4l __attribute__((ext_vector_type(4), aligned(4)));
-        const u32x4l v = *(const GLB u32x4l *)(pool + ((lit & 0x7FFFFFFFu) >> 8));
-        u32 *so = &s_out[TPW == 2 ? (lit >> 31) : 0][0][lit & 0xFFu];
-        so[0] = v.x; so[HVQ_WG] = v.y; so[2 * HVQ_WG] = v.z; so[3 * HVQ_WG] = v.w;
-    }
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
         const u32 T = e16[h] >> 8, k = T & kmask;
@@ -758,6 +757,10 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 #pragma unroll
         for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
     }
+    if (has_lit) {                                                            /* the lanes that hold the literal list copy the blocks into the tile */
+        u32 *so = &s_out[lit_second ? TPW - 1 : 0][0][lit & 0xFFu];
+        so[0] = litv.x; so[HVQ_WG] = litv.y; so[2 * HVQ_WG] = litv.z; so[3 * HVQ_WG] = litv.w;
+    }
     STAMP(3, 1);
     if (nitems) __syncthreads();                                              /* barrier 1: nest staged, accumulators zero */
     STAMP(4, 0);
@@ -766,7 +769,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         /* ---- phase B1: one lane per (item, basis) pair ---- */
         const i32 nstride = landscape ? 70 : 38;
         for (u32 pi = (u32)tid; pi < npairs; ) {
-            const u32 it = pr.x >> HVQ_PQ_ITEM_SHIFT;
+            const u32 it = (pr.x >> HVQ_PQ_ITEM_SHIFT) + ((TPW == 2 && pi >= np[0]) ? ni[0] : 0u);   /* pooled accumulators */
             const bool x2 = pr.x & HVQ_PQ_X2;
             u32 e[16], lo, hi;
             if (pr.x & HVQ_PQ_MC) gather_window_q(ring, pr.y, x2, (u32)lw << ((pr.x >> 20) & 1u), e, lo, hi);
@@ -872,39 +875,40 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 }
 
 template <int ITEMS_CAP, int TPW>
-static void launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs, hipStream_t stream)
+static void launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, const HvqTileQ *tq_all, uint32_t nslots, uint32_t max_wgs, hipStream_t stream)
 {
     const dim3 grid = nslots >= 8 ? dim3(8, max_wgs, nslots / 8) : dim3(nslots, max_wgs, 1);     /* nslots is a multiple of 8 then */
 #ifdef HVQ_STAMPS
-    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, pics_dev, g_stamps);
+    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, pics_dev, tq_all, g_stamps);
 #else
-    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, pics_dev);
+    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, pics_dev, tq_all);
 #endif
 }
 
 /* pics_dev: the launch's picture slots {job, tiles} (count a multiple of 8 when there are at least 8 pictures);
  * tiles_per_wg: 1 or 2; max_wgs: the most workgroups of any picture of the launch at that setting;
  * items_cap: the most items of any workgroup of the launch (it selects the instantiation with the next larger accumulator array) */
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs,
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
                                        uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream)
 {
     if (nslots == 0 || max_wgs == 0) return hipSuccess;
+    const HvqTileQ *tq_all = (const HvqTileQ *)tq_buffer;       /* the buffer every job's `tq` points into (8-byte aligned offsets) */
     if (tiles_per_wg >= 2) {
-        if (items_cap <= 32) launch_recon<32, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 64) launch_recon<64, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 96) launch_recon<96, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 128) launch_recon<128, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 192) launch_recon<192, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 256) launch_recon<256, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 384) launch_recon<384, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else launch_recon<512, 2>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        if (items_cap <= 32) launch_recon<32, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 64) launch_recon<64, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 96) launch_recon<96, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 128) launch_recon<128, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 192) launch_recon<192, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 256) launch_recon<256, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 384) launch_recon<384, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else launch_recon<512, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
     } else {
-        if (items_cap <= 32) launch_recon<32, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 64) launch_recon<64, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 96) launch_recon<96, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 128) launch_recon<128, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else if (items_cap <= 192) launch_recon<192, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
-        else launch_recon<256, 1>(jobs_dev, pics_dev, nslots, max_wgs, stream);
+        if (items_cap <= 32) launch_recon<32, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 64) launch_recon<64, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 96) launch_recon<96, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 128) launch_recon<128, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 192) launch_recon<192, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        else launch_recon<256, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
     }
     return hipGetLastError();
 }

@@ -42,7 +42,7 @@ extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t
 extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, uint32_t nslots, uint32_t max_wgs,
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
                                        uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream);
 extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, hipStream_t stream);
 extern "C" hipError_t hvq_upload_tables(void);
@@ -886,7 +886,7 @@ static int run_launches(HvqContext *c)
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     for (auto &L : c->launches)
-        HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap,
+        HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap,
                                 L.queue ? c->stream2 : c->stream));
     if (two) {
         HIPCHK(hipEventRecord(c->ev_join, c->stream2));
@@ -1217,7 +1217,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
             HIPCHK(hipMalloc((void **)&d, n * 8));
             HIPCHK(hipMemsetAsync(d, 0, n * 8, c->stream));
             hvq_set_stamps(d);
-            HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, c->stream));
+            HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, c->stream));
             hvq_set_stamps(nullptr);
             std::vector<unsigned long long> h(n);
             HIPCHK(hipStreamSynchronize(c->stream));
