@@ -1207,10 +1207,10 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
 #ifdef HVQ_STAMPS
     if (getenv("HVQM4_AMD_STAMPS")) {
         /* diagnostic build: one more pass with phase stamps, per-launch mean segment lengths on stderr */
-        static const char *seg[13] = { "tile record", "issue descriptor loads + classify", "descriptor loads land", "phase A (MC,cheap)", "barrier1",
-                                       "queue+nest", "barrier2", "B1 pairs", "barrier3", "B2 finish", "barrier4", "store issue", "stores land" };
-        static const int from[13] = { 0, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12 }, to[13] = { 1, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13 };
-        const int NS = 13, LAST = 13;
+        static const char *seg[10] = { "job + queue records", "prologue loads issue + land", "phase A (MC rows, cheap kinds, literals)", "barrier 1",
+                                       "B1 pairs", "barrier 2 (item record in flight)", "B2 items", "barrier 3", "store issue", "stores land" };
+        static const int from[10] = { 0, 1, 2, 3, 4, 7, 8, 9, 10, 12 }, to[10] = { 1, 2, 3, 4, 7, 8, 9, 10, 12, 13 };
+        const int NS = 10, LAST = 13;
         for (auto &L : c->launches) {
             unsigned long long *d = nullptr;
             const size_t n = (size_t)L.ntiles * L.max_tiles * 64;
@@ -1223,7 +1223,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost));
             HIPCHK(hipFree(d));
-            double sum[13] = {}, life = 0; size_t cnt[13] = {}, nw = 0;
+            double sum[10] = {}, life = 0; size_t cnt[10] = {}, nw = 0;
             for (size_t t = 0; t < (size_t)L.ntiles * L.max_tiles; ++t)
                 for (int w = 0; w < 4; ++w) {
                     const unsigned long long *q = &h[t * 64 + w * 16];
