@@ -536,12 +536,15 @@ __device__ __forceinline__ void gather_nest_q(i32 o, bool x2, i32 ys, const uint
 }
 
 /* window gather of one decoded pair, MC residual (h4m:734-765): voff = ring offset of sample (0,0), ys = row stride */
-__device__ __forceinline__ void gather_window_q(const GLB uint8_t *ring, u32 voff, bool x2, u32 ys, u32 e[16], u32 &lo, u32 &hi)
+__device__ __forceinline__ void window_load(const GLB uint8_t *ring, u32 voff, u32 ys, uint64_t q[4])
 {
-    const u32 sel = x2 ? 0x06040200u : 0x03020100u;
-    uint64_t q[4];
 #pragma unroll
     for (int y = 0; y < 4; ++y) q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(voff + (u32)y * ys));
+}
+
+__device__ __forceinline__ void window_finish(const uint64_t q[4], bool x2, u32 e[16], u32 &lo, u32 &hi)
+{
+    const u32 sel = x2 ? 0x06040200u : 0x03020100u;
     lo = 255; hi = 0;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
@@ -559,7 +562,7 @@ __device__ __forceinline__ void gather_window_q(const GLB uint8_t *ring, u32 vof
 
 template <int ITEMS_CAP, int TPW>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
-void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restrict__ pics, const HvqTileQ *__restrict__ tq_all HVQ_STAMP_ARG)
+void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restrict__ tq_all HVQ_STAMP_ARG)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];   /* nest packed two 4-bit values per byte */
     __shared__ __attribute__((aligned(16))) u32 s_out[TPW][4][HVQ_WG];   /* [tile][sample row][block] packed dwords */
@@ -570,10 +573,10 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     /* grid = (8 pictures, workgroups, groups of 8): workgroup ids run over the 8 pictures of a group first (one per XCD), then
      * over a picture's workgroups, then over groups -- eight pictures are in flight at a time, so their reference pictures stay in the L2s */
     const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
-    const u32 job_id = pics[slot_id].job;
     const u32 wg = blockIdx.y;
-    if (job_id == 0xFFFFFFFFu || wg >= pics[slot_id].tile) return;          /* padding slot / picture with fewer tiles (uniform) */
-    const HvqJob *__restrict__ J = jobs + job_id;
+    /* the job table is in launch-slot order: no indirection between the grid position and the record (one scalar round trip
+     * less at the head of every wave's life) */
+    const HvqJob *__restrict__ J = jobs + slot_id;
     /* The per-plane part of the record is read for ALL THREE planes at once and selected in registers: the empty asm pins
      * every word in a scalar register here.  Written as `p = ...; x = J->plane[p].x` the compiler selects the ADDRESS and
      * loads afterwards -- a chain of four dependent scalar loads instead of one. */
@@ -637,24 +640,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
     const i32 mcb_w = (i32)cw[15];
     const u32 q_lits_off = cw[18], q_items_off = cw[19];
     const u32 cap_items = q_caps & 0xFFFFu, cap_pairs = q_caps >> 16;
-    /* ---- the tiles' queue records.  Scalar loads: they are addressed through the kernel argument (the batch's queue buffer,
-     * which holds the job's `tq`), because only a load the compiler can prove read-only becomes s_load -- through an address
-     * taken from the job record it is a vector load with a full wait in front of everything else ---- */
-    const u32 tq_idx = (u32)((HVQ_W64(8) - (uint64_t)(uintptr_t)tq_all) >> 3) + tile0;
-    u32 np[TPW], ni[TPW], nl[TPW], qf = 0;
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        u32 a = 0, b = 0;
-        if (h < ntl) { a = tq_all[tq_idx + (u32)h].w0; b = tq_all[tq_idx + (u32)h].w1; }
-        HVQ_PIN(a); HVQ_PIN(b);
-        np[h] = a & 0xFFFFu; ni[h] = (a >> 16) & 0x3FFu; nl[h] = b; qf |= a;
-    }
-    const u32 npairs = TPW == 2 ? np[0] + np[TPW - 1] : np[0];
-    const u32 nitems = TPW == 2 ? ni[0] + ni[TPW - 1] : ni[0];
-    const u32 nlits = TPW == 2 ? nl[0] + nl[TPW - 1] : nl[0];
-    STAMP(1, 0);
-
-    /* ---- every request of the prologue goes out before anything is used ---- */
+    /* ---- the block's own requests go out first: they need the job record only ---- */
     bool valid[TPW];
     i32 bx[TPW], by[TPW];
     u32 e16[TPW], nt[TPW], nbt[TPW], nlf[TPW], nr[TPW], mvw[TPW];
@@ -671,6 +657,22 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         mvw[h] = 0;
         if (is_pb) mvw[h] = mvs[(by[h] >> (1 - hs)) * mcb_w + (bx[h] >> (1 - ws))];
     }
+    /* ---- the tiles' queue records.  Scalar loads: they are addressed through the kernel argument (the batch's queue buffer,
+     * which holds the job's `tq`), because only a load the compiler can prove read-only becomes s_load -- through an address
+     * taken from the job record it is a vector load with a full wait in front of everything else ---- */
+    const u32 tq_idx = (u32)((HVQ_W64(8) - (uint64_t)(uintptr_t)tq_all) >> 3) + tile0;
+    u32 np[TPW], ni[TPW], nl[TPW], qf = 0;
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        u32 a = 0, b = 0;
+        if (h < ntl) { a = tq_all[tq_idx + (u32)h].w0; b = tq_all[tq_idx + (u32)h].w1; }
+        HVQ_PIN(a); HVQ_PIN(b);
+        np[h] = a & 0xFFFFu; ni[h] = (a >> 16) & 0x3FFu; nl[h] = b; qf |= a;
+    }
+    const u32 npairs = TPW == 2 ? np[0] + np[TPW - 1] : np[0];
+    const u32 nitems = TPW == 2 ? ni[0] + ni[TPW - 1] : ni[0];
+    const u32 nlits = TPW == 2 ? nl[0] + nl[TPW - 1] : nl[0];
+    STAMP(1, 0);
     /* first round of the pair list (pooled over the tiles: tile 0's pairs, then tile 1's) */
     const GLB u32x2 *__restrict__ qpairs = (const GLB u32x2 *)(qb + q_pairs_off);
     auto pair_at = [&](u32 pi) -> u32x2 {                                   /* nothing here may USE the loaded words: that would wait for them */
@@ -694,18 +696,22 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 #pragma unroll
         for (u32 i = (u32)tid; i < 4u * ITEMS_CAP; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
     }
-    /* literal blocks (h4m:543-549): second hop right behind the prologue's loads, in front of the motion-compensation rows */
+    /* literal blocks (h4m:543-549): second hop right behind the prologue's loads */
     typedef u32 u32x4l __attribute__((ext_vector_type(4), aligned(4)));
     u32x4l litv = { 0u, 0u, 0u, 0u };
     if (has_lit) litv = *(const GLB u32x4l *)(pool + (lit >> 8));
-    /* the nest goes to LDS here: behind the conditional fifth row load below the compiler can only wait for ALL loads */
     if (qf & HVQ_TQ_INTRA) {
         ((u32 *)s_nest)[tid] = nq0;
         if (nest_second) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
     }
     STAMP(2, 1);
+    /* barrier 1 -- nest staged, accumulators zero -- sits HERE, where every wave has just waited for the same round trip and
+     * nothing has been computed yet: behind it the pair phase no longer depends on the block phase, so the window rows of the
+     * MC-residual pairs travel together with the motion-compensation rows */
+    if (nitems) __syncthreads();
+    STAMP(3, 0);
 
-    /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
+    /* ---- second round trip: motion-compensation rows (lane = block) and window rows (lane = pair) ---- */
     const u32 kmask = (is_pb || p != 0) ? 0xFu : 0xFFu;                  /* I-picture luma: the kind is the whole byte (h4m:1093) */
     McRows rows[TPW];
     int hxy[TPW];
@@ -733,6 +739,12 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             hxy[h] = hx | (hy << 1);
         }
     }
+    /* one tile per workgroup: registers allow the first round's window rows to be in flight beside the rows above */
+    constexpr bool EARLY = TPW == 1;
+    uint64_t wq[4] = { 0, 0, 0, 0 };
+    if (EARLY && (u32)tid < npairs && (pr.x & HVQ_PQ_MC)) window_load(ring, pr.y, (u32)lw << ((pr.x >> 20) & 1u), wq);
+
+    /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
         const u32 T = e16[h] >> 8, k = T & kmask;
@@ -761,9 +773,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
         u32 *so = &s_out[lit_second ? TPW - 1 : 0][0][lit & 0xFFu];
         so[0] = litv.x; so[HVQ_WG] = litv.y; so[2 * HVQ_WG] = litv.z; so[3 * HVQ_WG] = litv.w;
     }
-    STAMP(3, 1);
-    if (nitems) __syncthreads();                                              /* barrier 1: nest staged, accumulators zero */
-    STAMP(4, 0);
+    STAMP(4, 1);
 
     if (nitems) {
         /* ---- phase B1: one lane per (item, basis) pair ---- */
@@ -772,8 +782,10 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
             const u32 it = (pr.x >> HVQ_PQ_ITEM_SHIFT) + ((TPW == 2 && pi >= np[0]) ? ni[0] : 0u);   /* pooled accumulators */
             const bool x2 = pr.x & HVQ_PQ_X2;
             u32 e[16], lo, hi;
-            if (pr.x & HVQ_PQ_MC) gather_window_q(ring, pr.y, x2, (u32)lw << ((pr.x >> 20) & 1u), e, lo, hi);
-            else gather_nest_q((i32)pr.y, x2, nstride << ((pr.x >> 20) & 1u), s_nest, e, lo, hi);
+            if (pr.x & HVQ_PQ_MC) {
+                if (!EARLY || pi != (u32)tid) window_load(ring, pr.y, (u32)lw << ((pr.x >> 20) & 1u), wq);
+                window_finish(wq, x2, e, lo, hi);
+            } else gather_nest_q((i32)pr.y, x2, nstride << ((pr.x >> 20) & 1u), s_nest, e, lo, hi);
             basis_scatter<ITEMS_CAP>(gain_q(pr.x, lo, hi), e, s_acc + it);
             pi += HVQ_WG;
             if (pi < npairs) pr = pair_at(pi);
@@ -875,40 +887,40 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileRef *__restr
 }
 
 template <int ITEMS_CAP, int TPW>
-static void launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, const HvqTileQ *tq_all, uint32_t nslots, uint32_t max_wgs, hipStream_t stream)
+static void launch_recon(const HvqJob *jobs_dev, const HvqTileQ *tq_all, uint32_t nslots, uint32_t max_wgs, hipStream_t stream)
 {
     const dim3 grid = nslots >= 8 ? dim3(8, max_wgs, nslots / 8) : dim3(nslots, max_wgs, 1);     /* nslots is a multiple of 8 then */
 #ifdef HVQ_STAMPS
-    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, pics_dev, tq_all, g_stamps);
+    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, tq_all, g_stamps);
 #else
-    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, pics_dev, tq_all);
+    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, tq_all);
 #endif
 }
 
-/* pics_dev: the launch's picture slots {job, tiles} (count a multiple of 8 when there are at least 8 pictures);
+/* jobs_dev: the launch's picture slots, one job each (count a multiple of 8 when there are at least 8 pictures; padding: total_tiles 0);
  * tiles_per_wg: 1 or 2; max_wgs: the most workgroups of any picture of the launch at that setting;
  * items_cap: the most items of any workgroup of the launch (it selects the instantiation with the next larger accumulator array) */
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
                                        uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream)
 {
     if (nslots == 0 || max_wgs == 0) return hipSuccess;
     const HvqTileQ *tq_all = (const HvqTileQ *)tq_buffer;       /* the buffer every job's `tq` points into (8-byte aligned offsets) */
     if (tiles_per_wg >= 2) {
-        if (items_cap <= 32) launch_recon<32, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 64) launch_recon<64, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 96) launch_recon<96, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 128) launch_recon<128, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 192) launch_recon<192, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 256) launch_recon<256, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 384) launch_recon<384, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else launch_recon<512, 2>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        if (items_cap <= 32) launch_recon<32, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 64) launch_recon<64, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 96) launch_recon<96, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 128) launch_recon<128, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 192) launch_recon<192, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 256) launch_recon<256, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 384) launch_recon<384, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else launch_recon<512, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
     } else {
-        if (items_cap <= 32) launch_recon<32, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 64) launch_recon<64, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 96) launch_recon<96, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 128) launch_recon<128, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 192) launch_recon<192, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
-        else launch_recon<256, 1>(jobs_dev, pics_dev, tq_all, nslots, max_wgs, stream);
+        if (items_cap <= 32) launch_recon<32, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 64) launch_recon<64, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 96) launch_recon<96, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 128) launch_recon<128, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else if (items_cap <= 192) launch_recon<192, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
+        else launch_recon<256, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
     }
     return hipGetLastError();
 }

@@ -42,7 +42,7 @@ extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t
 extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const HvqTileRef *pics_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
+extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
                                        uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream);
 extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, hipStream_t stream);
 extern "C" hipError_t hvq_upload_tables(void);
@@ -199,9 +199,8 @@ struct HvqContext {
     std::vector<HvqTileRef> tiles_host;
     std::vector<HvqParseJob> pjobs_host;
     /* last flushed batch (kept resident for hvq_replay) */
-    HvqJob *jobs_dev = nullptr;
-    HvqTileRef *tiles_dev = nullptr;
-    size_t jobs_cap = 0, tiles_cap = 0;
+    HvqJob *jobs_dev = nullptr;        /* one job per launch slot, in launch order (padding slots: total_tiles = 0) */
+    size_t jobs_cap = 0;
     uint8_t *tq_dev = nullptr;         /* tile queues of the resident batch (hvq_tileq_kernel), read by every (re)play */
     size_t tq_cap = 0;
     std::vector<Launch> launches;
@@ -343,7 +342,6 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     for (auto e : c->ev_arena_free) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
-    if (c->tiles_dev) (void)hipFree(c->tiles_dev);
     if (c->tq_dev) (void)hipFree(c->tq_dev);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
     if (c->rgb_jobs_dev) (void)hipFree(c->rgb_jobs_dev);
@@ -886,7 +884,7 @@ static int run_launches(HvqContext *c)
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
     for (auto &L : c->launches)
-        HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap,
+        HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap,
                                 L.queue ? c->stream2 : c->stream));
     if (two) {
         HIPCHK(hipEventRecord(c->ev_join, c->stream2));
@@ -934,12 +932,7 @@ static int build_tiles(HvqContext *c)
         c->fl_launches.push_back(L);
       }
     c->fl_nq = nq;
-    if (tiles.size() > c->tiles_cap) {
-        if (c->tiles_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tiles_dev)); }
-        c->tiles_cap = tiles.size() * 2;
-        HIPCHK(hipMalloc((void **)&c->tiles_dev, c->tiles_cap * sizeof(HvqTileRef)));
-    }
-    return staged_upload(c, c->fl_arena_id, 1, c->tiles_dev, tiles.data(), tiles.size() * sizeof(HvqTileRef));
+    return HVQ_OK;                     /* the slots become the ORDER of the job table (flush_end): a workgroup finds its job by its grid position */
 }
 
 /* First half of a flush: everything that can be queued without waiting for the GPU.  The pending batch becomes the
@@ -1046,16 +1039,21 @@ static int flush_end(HvqContext *c)
     }
     /* 2. job table (the tile table went up at begin) */
     std::vector<HvqJob> &jobs = c->jobs_host;
-    jobs.assign(c->fl_pending.size(), HvqJob{});
-    std::vector<size_t> tq_off(c->fl_pending.size(), 0);
+    const std::vector<HvqTileRef> &slots = c->tiles_host;          /* launch slots in launch order (build_tiles) */
+    jobs.assign(slots.size(), HvqJob{});
+    std::vector<size_t> tq_off(slots.size(), 0);
+    std::vector<uint32_t> slot_of(c->fl_pending.size(), 0);
     size_t tq_bytes = 0;
     uint32_t max_tiles = 0;
     HvqStats st{};
-    for (size_t i = 0; i < c->fl_pending.size(); ++i) {
+    for (size_t k = 0; k < slots.size(); ++k) {
+        HvqJob &j = jobs[k];
+        memset(&j, 0, sizeof j);
+        if (slots[k].job == 0xFFFFFFFFu) continue;                  /* padding slot: total_tiles = 0, its workgroups exit at once */
+        const size_t i = slots[k].job;
+        slot_of[i] = (uint32_t)k;
         const Pending &p = c->fl_pending[i];
         const Stream &s = c->streams[(size_t)p.stream];
-        HvqJob &j = jobs[i];
-        memset(&j, 0, sizeof j);
         HvqPicHeader hdev;
         if (p.dev) {                                   /* geometry from the stream, per-picture fields from the parse result */
             hdev = s.layout;
@@ -1085,7 +1083,7 @@ static int flush_end(HvqContext *c)
             const uint32_t nt = hd->tile_first[3];
             const uint32_t cap_items = std::min(256u, (uint32_t)p.max_items), cap_pairs = std::min(HVQ_PAIR_CAP_MAX, p.max_pairs);
             tq_bytes = align_up(tq_bytes, 256);
-            tq_off[i] = tq_bytes;
+            tq_off[k] = tq_bytes;
             const size_t lits = align_up((size_t)nt * sizeof(HvqTileQ), 16), items = lits + (size_t)nt * HVQ_TILE_BLOCKS * 4,
                          pairs = items + (size_t)nt * cap_items * 16, end = pairs + (size_t)nt * cap_pairs * 8;
             if (end >= ((size_t)1 << 32)) return fail(HVQ_E_OVERFLOW, "stream %d picture %d: tile queues exceed 4 GiB", p.stream, p.ordinal);
@@ -1120,7 +1118,7 @@ static int flush_end(HvqContext *c)
             const Pending &p = c->fl_pending[i];
             if (p.dropped || p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
             mi = std::max(mi, p.max_items); mp = std::max(mp, p.max_pairs);
-            payload += jobs[i].pool_dwords; ntl += p.ntiles;
+            payload += jobs[slot_of[i]].pool_dwords; ntl += p.ntiles;
         }
         /* Two tiles per workgroup (pooled queue, twice the loads in flight per wave) while the pooled accumulators still leave
          * 8 workgroups per CU; AOT-dense launches keep one tile per workgroup (profiles/r02o_ab_two_tiles.txt). */
@@ -1148,8 +1146,8 @@ static int flush_end(HvqContext *c)
         HIPCHK(hipMalloc((void **)&c->tq_dev, ncap));
         c->tq_cap = ncap;
     }
-    for (size_t i = 0; i < jobs.size(); ++i)
-        if (jobs[i].total_tiles) jobs[i].tq = (uint64_t)(uintptr_t)(c->tq_dev + tq_off[i]);
+    for (size_t k = 0; k < jobs.size(); ++k)
+        if (jobs[k].total_tiles) jobs[k].tq = (uint64_t)(uintptr_t)(c->tq_dev + tq_off[k]);
     /* stream-ordered after whatever still reads the previous table */
     { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return rcu; }
     /* 2b. tile queues: once per picture, from the descriptors (type bytes, vectors, basis words) that are now all in HBM */
@@ -1217,7 +1215,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
             HIPCHK(hipMalloc((void **)&d, n * 8));
             HIPCHK(hipMemsetAsync(d, 0, n * 8, c->stream));
             hvq_set_stamps(d);
-            HIPCHK(hvq_launch_recon(c->jobs_dev, c->tiles_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, c->stream));
+            HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, c->stream));
             hvq_set_stamps(nullptr);
             std::vector<unsigned long long> h(n);
             HIPCHK(hipStreamSynchronize(c->stream));
