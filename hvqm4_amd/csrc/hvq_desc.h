@@ -149,7 +149,8 @@ typedef struct HvqJob {
     uint32_t q_pairs_off;
     uint32_t q_caps;               /* list entries reserved per tile: items | pairs << 16 (literals: HVQ_TILE_BLOCKS) */
     uint64_t wave_base;            /* blob section: pool offset of every run of 64 blocks (read by hvq_tileq_kernel only) */
-    uint32_t pad2[4];
+    uint32_t q_recs_off;           /* byte offset from `tq` of the picture's block records */
+    uint32_t pad2[3];
 } HvqJob;
 #define HVQ_JOB_KIND_SHIFT  16
 #define HVQ_JOB_UNK_SHIFT   20
@@ -168,6 +169,12 @@ _Static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
  * part of the parse stage) instead of by every reconstruction launch: the reconstruction kernel no longer classifies,
  * ballots, scans or builds lists, and its AOT phase does not wait for its per-block phase.
  *   HvqTileQ   per tile: counts
+ *   records    8 bytes per block, HVQ_TILE_BLOCKS per tile: what the owning lane does with the block, with its operands
+ *              resolved -- the reconstruction kernel reads neither the map nor the vectors:
+ *              w1 = DC value | HVQ_BR_* action << 8 | half-sample flags (hx << 10, hy << 11)
+ *              w0 = motion compensated (also the MC part of an MC-residual block): ring offset of the top-left source
+ *                   sample (h4m:1327-1355, clamped into the slot); weighted DC: the four neighbour values the predictor
+ *                   sees, top | bottom << 8 | left << 16 | right << 24 (h4m:1437-1454, 1811-1814)
  *   literals   u32 per literal block: owner (lane of the tile) | pool offset << 8
  *   items      16 bytes per queued block (intra AOT first, then MC residual): owner | map entry << 8, pool offset of the
  *              payload, the two scalars of an MC-residual block (h4m:1405-1406)
@@ -184,6 +191,10 @@ typedef struct HvqTileQ {
 #define HVQ_TQ_INTRA   (1u << 26)  /* the tile has intra AOT items: the nest is staged */
 #define HVQ_TQ_SERIAL  (1u << 27)  /* more pairs than the picture's list reserves: no pair list, items loop over their bases */
 #define HVQ_PAIR_CAP_MAX 2048u     /* pairs per tile a list may reserve */
+#define HVQ_BR_LIST    0u          /* literal or AOT block: the lists do it */
+#define HVQ_BR_FLAT    1u          /* flat DC (h4m:281-286) */
+#define HVQ_BR_WDC     2u          /* weighted DC (h4m:299-383) */
+#define HVQ_BR_MC      3u          /* motion compensated */
 #define HVQ_PQ_NEG     (1u << 18)
 #define HVQ_PQ_X2      (1u << 19)
 #define HVQ_PQ_Y2      (1u << 20)

@@ -400,11 +400,50 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
     i32 bx, by;
     block_coords(valid ? b : 0u, hb, 1.0f / (float)hb, bx, by);
     const GLB uint8_t *map = (const GLB uint8_t *)J->plane[p].map;
-    const u32 e16 = *(const GLB uint16_t *)(map + 2 * ((by + 1) * (hb + 2) + bx + 1));
+    const i32 mstride = hb + 2;
+    const GLB uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
+    const u32 e16 = *(const GLB uint16_t *)ent;
+    const u32 nt = *(const GLB uint16_t *)(ent - 2 * mstride), nbt = *(const GLB uint16_t *)(ent + 2 * mstride);
+    const u32 nlf = *(const GLB uint16_t *)(ent - 2), nr = *(const GLB uint16_t *)(ent + 2);
+    u32 mvw = 0;
+    if (is_pb) mvw = ((const GLB u32 *)J->mv)[(by >> (1 - hs)) * (i32)J->mcb_w + (bx >> (1 - ws))];
     const u32 T = e16 >> 8;
     const u32 tc = valid ? g_type_class[(is_pb ? 512 : p == 0 ? 0 : 256) + T] : 0u;
     const u32 npay = HVQ_TC_NPAY(tc), cls = HVQ_TC_CLS(tc), nb = HVQ_TC_NB(tc);
     const bool lit = tc & HVQ_TC_LIT;
+    GLB uint8_t *q = (GLB uint8_t *)J->tq;
+    {   /* the block's record: what its owning lane does, operands resolved */
+        const i32 V = e16 & 0xFF;
+        u32 w0 = 0, w1 = (u32)V;
+        if (tc & HVQ_TC_MC) {
+            /* plain MC and the MC part of MC-residual blocks (h4m:1327-1355): half-sample rule per version (h4m:1337-1343) */
+            const bool is15 = flags & HVQ_F_IS15;
+            const i32 pw = (i32)(pw_sub & 0xFFFFu);
+            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+            const u32 roff = (((T >> 5) & 3u) == 1u) ? J->ref0_off : J->ref1_off;
+            const i32 pdx = rx >> ws, pdy = ry >> hs;
+            const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
+            i32 a = (i32)J->plane[p].plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+            /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
+            a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
+            w0 = roff + (u32)a;
+            w1 |= (HVQ_BR_MC << 8) | ((u32)hx << 10) | ((u32)hy << 11);
+        } else if (tc & HVQ_TC_WDC) {
+            /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
+             * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
+            const u32 Tt = (nt & 0x7700u) ? (u32)V : (nt & 0xFF);
+            const u32 Bb = (nbt & 0x7700u) ? (u32)V : (nbt & 0xFF);
+            const u32 Rr = (nr & 0x7700u) ? (u32)V : (nr & 0xFF);
+            const bool lexp = is_pb ? !(nlf & 0x7700u) : ((nlf >> 8) == 0 || (nlf >> 8) == 8);
+            const u32 Ll = lexp ? (nlf & 0xFF) : (u32)V;
+            w0 = Tt | (Bb << 8) | (Ll << 16) | (Rr << 24);
+            w1 |= HVQ_BR_WDC << 8;
+        } else if (valid && cls == 0 && !lit) {
+            w1 |= HVQ_BR_FLAT << 8;
+        }
+        const u32x2 br = { w0, w1 };
+        ((GLB u32x2 *)(q + J->q_recs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = br;
+    }
     const GLB u32 *__restrict__ pool = (const GLB u32 *)J->pool;
     const u32 off = ((const GLB u32 *)J->wave_base)[tile * HVQ_NW + (u32)wave] + wave_incl_scan(npay) - npay;
     /* queue order: intra AOT items first, then MC-residual items, each in block order; pairs follow their items */
@@ -423,7 +462,6 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
     const u32 nI = tot[0], nitems = tot[0] + tot[1], npairs = tot[2] + tot[3], nlit = tot[4];
     const u32 cap_items = J->q_caps & 0xFFFFu, cap_pairs = J->q_caps >> 16;
     const bool serial = npairs > cap_pairs;
-    GLB uint8_t *q = (GLB uint8_t *)J->tq;
     if (tid == 0) {
         GLB HvqTileQ *t = (GLB HvqTileQ *)q + tile;
         t->w0 = (serial ? 0u : npairs) | (nitems << 16) | (nI ? HVQ_TQ_INTRA : 0u) | (serial ? HVQ_TQ_SERIAL : 0u);
@@ -446,7 +484,6 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
             i32 origin = 0;
             u32 ref_off = 0;
             if (cls == 2) {
-                const u32 mvw = ((const GLB u32 *)J->mv)[(by >> (1 - hs)) * (i32)J->mcb_w + (bx >> (1 - ws))];
                 const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
                 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;   /* h4m:1865-1868 */
                 ref_off = ((T >> 5) & 3u) == 1u ? J->ref0_off : J->ref1_off;
@@ -589,12 +626,12 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
     u32 cw[20];
 #pragma unroll
     for (int i = 0; i < 20; ++i) cw[i] = CW[i];
-    u32 q_pairs_off = CW[44], q_caps = CW[45];
+    u32 q_pairs_off = CW[44], q_caps = CW[45], q_recs_off = CW[48];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { HVQ_PIN(w0[i]); HVQ_PIN(w1[i]); HVQ_PIN(w2[i]); }
 #pragma unroll
     for (int i = 0; i < 20; ++i) HVQ_PIN(cw[i]);
-    HVQ_PIN(q_pairs_off); HVQ_PIN(q_caps);
+    HVQ_PIN(q_pairs_off); HVQ_PIN(q_caps); HVQ_PIN(q_recs_off);
     const u32 total_tiles = cw[17];
     /* words of HvqPlaneRec: 0,1 map; 2,3 dst; 4 plane_off; 5 tile_first; 6 hbvb; 7 pw_sub.
      * Workgroup wg of the picture -> plane and the TPW consecutive tiles of that plane it owns (the last group may be short) */
@@ -640,22 +677,13 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
     const i32 mcb_w = (i32)cw[15];
     const u32 q_lits_off = cw[18], q_items_off = cw[19];
     const u32 cap_items = q_caps & 0xFFFFu, cap_pairs = q_caps >> 16;
-    /* ---- the block's own requests go out first: they need the job record only ---- */
-    bool valid[TPW];
-    i32 bx[TPW], by[TPW];
-    u32 e16[TPW], nt[TPW], nbt[TPW], nlf[TPW], nr[TPW], mvw[TPW];
+    /* ---- the blocks' records go out first: they need the job record only ---- */
+    const GLB u32x2 *__restrict__ qrecs = (const GLB u32x2 *)(qb + q_recs_off);
+    u32x2 brec[TPW];
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
-        const u32 b = b0 + (u32)(h * HVQ_TILE_BLOCKS + tid);
-        valid[h] = b < nblocks;
-        block_coords(valid[h] ? b : 0u, hb, rhb, bx[h], by[h]);
-        const GLB uint8_t *ent = map + 2 * ((by[h] + 1) * mstride + bx[h] + 1);
-        /* left neighbour, own entry and right neighbour are six consecutive bytes of the map: one load */
-        const uint64_t m8 = *(const GLB u64u *)(ent - 2);
-        nlf[h] = (u32)m8 & 0xFFFFu; e16[h] = ((u32)m8 >> 16); nr[h] = (u32)(m8 >> 32) & 0xFFFFu;
-        nt[h] = *(const GLB uint16_t *)(ent - 2 * mstride); nbt[h] = *(const GLB uint16_t *)(ent + 2 * mstride);
-        mvw[h] = 0;
-        if (is_pb) mvw[h] = mvs[(by[h] >> (1 - hs)) * mcb_w + (bx[h] >> (1 - ws))];
+        brec[h] = (u32x2)(0u);
+        if (h < ntl) brec[h] = qrecs[(size_t)(tile0 + (u32)h) * HVQ_TILE_BLOCKS + (u32)tid];
     }
     /* ---- the tiles' queue records.  Scalar loads: they are addressed through the kernel argument (the batch's queue buffer,
      * which holds the job's `tq`), because only a load the compiler can prove read-only becomes s_load -- through an address
@@ -712,31 +740,16 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
     STAMP(3, 0);
 
     /* ---- second round trip: motion-compensation rows (lane = block) and window rows (lane = pair) ---- */
-    const u32 kmask = (is_pb || p != 0) ? 0xFu : 0xFFu;                  /* I-picture luma: the kind is the whole byte (h4m:1093) */
     McRows rows[TPW];
-    int hxy[TPW];
-    bool act_mc[TPW];
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
-        const u32 T = e16[h] >> 8;
-        /* motion compensated: inter macroblock, anything but a literal block (h4m:1862-1910, 1327-1355) */
-        act_mc[h] = valid[h] && is_pb && (T & 0x60u) && (T & 0x1Fu) != 6u;
-        hxy[h] = 0;
-        if (act_mc[h]) {
+        if (((brec[h].y >> 8) & 3u) == HVQ_BR_MC) {
             /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
-            const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFF), ry = (i32)(int16_t)(mvw[h] >> 16);
-            const u32 roff = (((T >> 5) & 3u) == 1u) ? ref0_off : ref1_off;
-            const i32 pdx = rx >> ws, pdy = ry >> hs;
-            const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);   /* h4m:1337-1343 */
-            i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by[h] & (1 - hs)) * 4 * pw + (bx[h] & (1 - ws)) * 4;
-            /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
-            a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
-            const u32 vo = roff + (u32)a;
+            const u32 vo = brec[h].x;
 #pragma unroll
             for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(y * pw)));
             rows[h].q[4] = 0;
-            if (hy) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(4 * pw)));
-            hxy[h] = hx | (hy << 1);
+            if (brec[h].y & 0x800u) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(4 * pw)));   /* 5th row only for vertical half samples */
         }
     }
     /* one tile per workgroup: registers allow the first round's window rows to be in flight beside the rows above */
@@ -747,23 +760,16 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
     /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
-        const u32 T = e16[h] >> 8, k = T & kmask;
-        const i32 V = e16[h] & 0xFF;
-        const bool intra = !(is_pb && (T & 0x60u));
+        const u32 act = (brec[h].y >> 8) & 3u;
+        const i32 V = brec[h].y & 0xFF;
         Blk o;
-        if (act_mc[h]) {
-            o = mc_filter(rows[h], hxy[h] & 1, hxy[h] >> 1);
-        } else if (valid[h] && intra && k == 0u) {
-            /* weighted DC (h4m:299-383): neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442,
-             * 1811-1814).  I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
-            i32 Tt = (nt[h] & 0x7700u) ? V : (i32)(nt[h] & 0xFF);
-            i32 Bb = (nbt[h] & 0x7700u) ? V : (i32)(nbt[h] & 0xFF);
-            i32 Rr = (nr[h] & 0x7700u) ? V : (i32)(nr[h] & 0xFF);
-            bool lexp = is_pb ? !(nlf[h] & 0x7700u) : ((nlf[h] >> 8) == 0 || (nlf[h] >> 8) == 8);
-            i32 Ll = lexp ? (i32)(nlf[h] & 0xFF) : V;
-            o = weight_block(V, Tt, Bb, Ll, Rr);
-        } else if (valid[h] && intra && k == 8u) {
-            const u32 v = (u32)V * 0x01010101u;                               /* flat DC (h4m:281-286) */
+        if (act == HVQ_BR_MC) {
+            o = mc_filter(rows[h], (brec[h].y >> 10) & 1, (brec[h].y >> 11) & 1);
+        } else if (act == HVQ_BR_WDC) {
+            const u32 nb4 = brec[h].x;                                        /* neighbour values as the predictor sees them */
+            o = weight_block(V, (i32)(nb4 & 0xFF), (i32)((nb4 >> 8) & 0xFF), (i32)((nb4 >> 16) & 0xFF), (i32)(nb4 >> 24));
+        } else if (act == HVQ_BR_FLAT) {
+            const u32 v = (u32)V * 0x01010101u;
             o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
         } else continue;                                                       /* literal or AOT: the lists do it */
 #pragma unroll
@@ -813,7 +819,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
             if (qf & HVQ_TQ_SERIAL) {
                 /* a tile whose pair list exceeds what the picture reserves (pathological streams): the item walks its bases */
                 const bool ser = (second ? np[TPW - 1] : np[0]) == 0u;          /* a serial tile has no pair list */
-                const u32 kind = (q16 >> 8) & kmask;
+                const u32 kind = (q16 >> 8) & ((is_pb || p != 0) ? 0xFu : 0xFFu);   /* I-picture luma: the kind is the whole byte (h4m:1093) */
                 const u32 n = item_mc ? (kind & 0xFu) - 1u : kind;
                 if (ser) {
                     const GLB u32 *bases = pool + rec.y + (item_mc ? 2u : 0u);

@@ -1084,10 +1084,11 @@ static int flush_end(HvqContext *c)
             const uint32_t cap_items = std::min(256u, (uint32_t)p.max_items), cap_pairs = std::min(HVQ_PAIR_CAP_MAX, p.max_pairs);
             tq_bytes = align_up(tq_bytes, 256);
             tq_off[k] = tq_bytes;
-            const size_t lits = align_up((size_t)nt * sizeof(HvqTileQ), 16), items = lits + (size_t)nt * HVQ_TILE_BLOCKS * 4,
+            const size_t recs = align_up((size_t)nt * sizeof(HvqTileQ), 16), lits = recs + (size_t)nt * HVQ_TILE_BLOCKS * 8,
+                         items = lits + (size_t)nt * HVQ_TILE_BLOCKS * 4,
                          pairs = items + (size_t)nt * cap_items * 16, end = pairs + (size_t)nt * cap_pairs * 8;
             if (end >= ((size_t)1 << 32)) return fail(HVQ_E_OVERFLOW, "stream %d picture %d: tile queues exceed 4 GiB", p.stream, p.ordinal);
-            j.q_lits_off = (uint32_t)lits; j.q_items_off = (uint32_t)items; j.q_pairs_off = (uint32_t)pairs;
+            j.q_recs_off = (uint32_t)recs; j.q_lits_off = (uint32_t)lits; j.q_items_off = (uint32_t)items; j.q_pairs_off = (uint32_t)pairs;
             j.q_caps = cap_items | (cap_pairs << 16);
             tq_bytes += end;
             max_tiles = std::max(max_tiles, nt);
