@@ -340,6 +340,9 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 }
 
 #define HVQ_NW (HVQ_WG / 64)
+#ifndef HVQ_ABL
+#define HVQ_ABL 0
+#endif
 
 /* Diagnostic build only (-DHVQ_STAMPS, tools/variant.sh): s_memtime stamps of wave phases into a buffer of their own
  * (64 x u64 per workgroup: [wave][16]); the shipped kernel executes no stamp.  VM = also wait for the wave's
@@ -672,6 +675,9 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
     const GLB uint8_t *__restrict__ qb = (const GLB uint8_t *)HVQ_W64(8);
     const GLB u32 *__restrict__ nestp = (const GLB u32 *)HVQ_W64(10);
     GLB uint8_t *plane = (GLB uint8_t *)dst_a;
+    /* timing experiment 16: every row of the tile is stored into one 64 KB window (the stores are issued and acknowledged,
+     * HBM sees almost none of them) */
+    if (HVQ_ABL == 16) plane = (GLB uint8_t *)(HVQ_W64(0) + (uint64_t)((wg & 15u) * 4096u));
     const i32 slot = (i32)cw[12];
     const i32 lw = (i32)cw[14];
     const i32 mcb_w = (i32)cw[15];
@@ -745,7 +751,18 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
     for (int h = 0; h < TPW; ++h) {
         if (((brec[h].y >> 8) & 3u) == HVQ_BR_MC) {
             /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
-            const u32 vo = brec[h].x;
+            u32 vo = brec[h].x;
+            /* timing experiments only (tools/variant.sh <name> -DHVQ_ABL=n; wrong pictures):
+             *   11 chroma lane pairs read the same address (what a U/V-interleaved reference copy would buy)
+             *   12 every quad reads ONE address (a quarter of the lines, same instructions)   13 no row loads at all
+             *   14 rows read from the workgroup's own output position (sequential, L2-friendly) instead of the vector's target */
+            if (HVQ_ABL == 11 && p != 0) vo = (u32)__builtin_amdgcn_mov_dpp((int)vo, 0xA0 /* quad_perm [0,0,2,2] */, 0xF, 0xF, true);
+            if (HVQ_ABL == 12) vo = (u32)__builtin_amdgcn_mov_dpp((int)vo, 0x00 /* quad_perm [0,0,0,0] */, 0xF, 0xF, true);
+            if (HVQ_ABL == 13) {
+#pragma unroll
+                for (int y = 0; y < 5; ++y) rows[h].q[y] = (uint64_t)vo * 0x0101010101ull + (uint64_t)y;
+                continue;
+            }
 #pragma unroll
             for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(y * pw)));
             rows[h].q[4] = 0;
@@ -863,6 +880,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
     STAMP(10, 0);
 
     /* ---- phase C: tiles -> HBM ---- */
+    if (HVQ_ABL == 15 && s_out[0][0][tid] != 0x12345678u) return;             /* timing experiment: no stores */
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
@@ -877,7 +895,8 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
                 const u32x4 v = *(const u32x4 *)&s_out[h][rr][4 * g];
                 /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors
                  * in L2 (+1 % on MC-dominated streams, neutral on the dense one; profiles/r01j_ab_nontemporal.txt) */
-                if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
+                if (HVQ_ABL == 16) *(GLB u32x4 *)(plane + (size_t)(tid * 16)) = v;
+                else if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
                 else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
             }
         } else if (b0 + (u32)(h * HVQ_TILE_BLOCKS + tid) < nblocks) {
