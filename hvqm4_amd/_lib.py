@@ -95,6 +95,11 @@ SYMBOLS = {
     "hvq_stream_pic_bytes": (C.c_uint32, [C.c_void_p, C.c_int]),
     "hvq_read_picture_rgb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "hvq_rgb_bench": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "hvq_convert_yuv420_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "hvq_read_pictures": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "hvq_pinned_alloc": (C.c_void_p, [C.c_size_t]),
+    "hvq_pinned_free": (None, [C.c_void_p]),
+    "hvq_picture_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "hvq_get_stats": (C.c_int, [C.c_void_p, C.POINTER(HvqStats)]),
     "hvq_last_error_string": (C.c_char_p, []),
     "hvq_h4m_header": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(HvqH4mInfo)]),

@@ -78,6 +78,42 @@ class Context:
         check(lib().hvq_read_picture_rgb(self._h, sid, ordinal, out.ctypes.data, out.nbytes))
         return out.reshape(height, width, 3)
 
+    def convert_yuv420_rgb(self, yuv: np.ndarray, width: int, height: int) -> np.ndarray:
+        """the reference player's dumpRGB (h4m:897-926) on a host picture (Y|U|V 4:2:0) -> RGB24 (h, w, 3)"""
+        yuv = np.ascontiguousarray(yuv, dtype=np.uint8)
+        assert yuv.size == width * height * 3 // 2
+        out = np.empty(width * height * 3, dtype=np.uint8)
+        check(lib().hvq_convert_yuv420_rgb(self._h, yuv.ctypes.data, width, height, out.ctypes.data))
+        return out.reshape(height, width, 3)
+
+    def read_pictures(self, sids, ordinals, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """bulk readback (hvq_read_pictures): one synchronisation for all of them -> uint8[n, pic_bytes] (all streams of one size)"""
+        n = len(sids)
+        nb = self.pic_bytes(sids[0]) if n else 0
+        if out is None:
+            out = np.empty((n, nb), dtype=np.uint8)
+        a_s = (C.c_int * n)(*sids)
+        a_o = (C.c_int * n)(*ordinals)
+        a_d = (C.c_void_p * n)(*[out.ctypes.data + i * out.strides[0] for i in range(n)])
+        check(lib().hvq_read_pictures(self._h, n, a_s, a_o, a_d))
+        return out
+
+    def pinned_array(self, shape) -> np.ndarray:
+        """uint8 array in pinned host memory (hvq_pinned_alloc); freed with the context"""
+        nbytes = int(np.prod(shape))
+        p = lib().hvq_pinned_alloc(nbytes)
+        if not p:
+            raise MemoryError("hvq_pinned_alloc failed")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        buf = (C.c_uint8 * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
+
+    def picture_device_ptr(self, sid: int, ordinal: int) -> int:
+        ptr = C.c_void_p()
+        check(lib().hvq_picture_device_ptr(self._h, sid, ordinal, C.byref(ptr)))
+        return int(ptr.value or 0)
+
     def rgb_bench(self, reps: int):
         """-> (gpu_ms, bytes_per_rep, pictures): batched display epilogue over the newest picture of every stream"""
         ms, by, n = C.c_float(0), C.c_uint64(0), C.c_uint32(0)
@@ -91,6 +127,9 @@ class Context:
 
     def close(self):
         if self._h:
+            for p in getattr(self, "_pinned", []):
+                lib().hvq_pinned_free(p)
+            self._pinned = []
             lib().hvq_context_destroy(self._h)
             self._h = C.c_void_p()
 

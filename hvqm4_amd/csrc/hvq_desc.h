@@ -50,11 +50,15 @@
 #define HVQ_F_IS15        0x0001u   /* HVQM4 1.5 stream: per-plane half-sample rule (h4m:1337-1343) */
 #define HVQ_F_LANDSCAPE   0x0002u   /* width >= height (h4m:965-975) */
 #define HVQ_F_HAS_NEST    0x0004u   /* blob carries a nest: some block needs intra AOT */
-#define HVQ_F_SELF_REF    0x0008u   /* P picture with a future-referencing macroblock: the reference
-                                       reads the picture being written (h4m:2060); not reproducible
-                                       data-parallel -- flagged, decoded against `ref1` as given */
+#define HVQ_F_SELF_REF    0x0008u   /* P picture with a future-referencing (type 2) macroblock: the reference
+                                       reads the picture being written (h4m:2060).  Its other macroblocks are
+                                       reconstructed data-parallel into a side buffer, then hvq_selfref_kernel walks the
+                                       macroblocks in raster order like the reference does */
 #define HVQ_F_BIG_AOT     0x0010u   /* some block has more than 15 bases (I-luma type byte > 15) */
 #define HVQ_F_CLAMPED     0x0020u   /* malformed input: a value was clamped to keep the device in bounds */
+#define HVQ_F_CAPPED      0x0040u   /* an overflow-symbol loop (h4m:654-677: the reference sums for as long as the stream says) ended
+                                       on this back end's cap instead of on the stream: the value differs from the reference's --
+                                       the picture is refused, never decoded differently */
 
 typedef struct HvqPicHeader {
     uint32_t magic;
@@ -150,7 +154,8 @@ typedef struct HvqJob {
     uint32_t q_caps;               /* list entries reserved per tile: items | pairs << 16 (literals: HVQ_TILE_BLOCKS) */
     uint64_t wave_base;            /* blob section: pool offset of every run of 64 blocks (read by hvq_tileq_kernel only) */
     uint32_t q_recs_off;           /* byte offset from `tq` of the picture's block records */
-    uint32_t pad2[3];
+    uint32_t q_offs_off;           /* HVQ_F_SELF_REF pictures: byte offset from `tq` of the blocks' pool offsets (u32 per block), else 0 */
+    uint32_t pad2[2];
 } HvqJob;
 #define HVQ_JOB_KIND_SHIFT  16
 #define HVQ_JOB_UNK_SHIFT   20

@@ -63,7 +63,7 @@
  * signed-overflow value (DC delta, MC-residual scalar) is a handful of symbols in any real stream; a run count is at
  * most the number of macroblocks, 255 per symbol.  The caps are the same in hvq_parse.c, so malformed streams still
  * give identical blobs, and they bound a picture's decode time whatever the stream contains. */
-#define GP_SOVF_CAP 256
+#define GP_SOVF_CAP 4096
 #define GP_UOVF_CAP(nmb) ((int)((nmb) / 255u) + 16)
 #define GP_ALIGN16(x) (((x) + 15u) & ~15u)
 
@@ -289,20 +289,23 @@ GP_FN int32_t gsym(const GCode *c, GBits *b)                                   /
     return gc_leaf(c, id);
 }
 
-GP_FN int32_t gsym_sovf(const GCode *c, GBits *b, int32_t lo, int32_t hi)      /* h4m:654-664 */
+/* `*fl` gets HVQ_F_CAPPED when the loop ends on its cap, not on the stream (same rule as hvq_parse.c) */
+GP_FN int32_t gsym_sovf(const GCode *c, GBits *b, int32_t lo, int32_t hi, uint32_t *fl)      /* h4m:654-664 */
 {
     uint32_t total = 0;
     int32_t v;
     int guard = 0;
     do { v = gsym(c, b); total += (uint32_t)v; } while ((v <= lo || v >= hi) && ++guard < GP_SOVF_CAP);
+    if (v <= lo || v >= hi) *fl |= HVQ_F_CAPPED;
     return (int32_t)total;
 }
 
-GP_FN int32_t gsym_uovf(const GCode *c, GBits *b, int cap)                      /* h4m:667-677 */
+GP_FN int32_t gsym_uovf(const GCode *c, GBits *b, int cap, uint32_t *fl)        /* h4m:667-677 */
 {
     int32_t total = 0, v;
     int guard = 0;
     do { v = gsym(c, b); total += v; } while (v >= 0xFF && ++guard < cap);
+    if (v >= 0xFF) *fl |= HVQ_F_CAPPED;
     return total;
 }
 
@@ -385,6 +388,10 @@ typedef struct {
 #define GP_PART2 512
 #define GP_MISC 992
 #define GP_EP(plane, which, tid) (1024 + ((plane) * 2 + (which)) * 512 + (tid))
+/* part[GP_MISC + 16 + k]: HVQ_F_CAPPED of the chains that decode overflow symbols, one word each (no two waves share one):
+ * k = 0-2 I-picture DC planes, 3-5 P/B intra DC planes, 6-8 MC-residual scalars, 9 type runs, 10 proc runs */
+#define GP_CAPW(k) (GP_MISC + 16 + (k))
+#define GP_NCAPW 11
 
 GP_FN uint32_t gp_be32(const GPic *g, uint64_t off)
 {
@@ -476,6 +483,7 @@ GP_FN void gp_setup(GPic *g, const HvqParseJob *job)
     g->retry = 0; g->ncoded = 0; g->ntype0 = 0; g->ntrun = 0; g->nprun = 0; g->pend = 0; g->spins = 0;
     g->flags = 0; g->status = 0; g->max_items = 0; g->max_pairs = 0; g->pool_dwords = 0; g->total = 0;
     if (g->cap < g->fixed_bytes || g->len < 8 + 0x44 + 4) g->status |= GP_ST_BADARG;
+    for (int k = 0; k < GP_NCAPW; ++k) GP_ST(g->part[GP_CAPW(k)], 0u);
 }
 
 /* sections (h4m:1061-1071, 1979-1993, 2030-2044): byte offset of the payload of section i, *live as in hvq_parse.c */
@@ -635,7 +643,7 @@ GP_FN void gp_idc(GPic *g, const GCode *codes, int i, uint8_t *rowbuf)
     const GCode *c_dc = &codes[GC_DC], *c_run = &codes[GC_RUN];
     const int32_t lo = g->dc_lo, hi = g->dc_hi;
     for (int bx = 0; bx <= q->hb; ++bx) rowbuf[bx] = 0x7F;
-    uint32_t run = 0;
+    uint32_t run = 0, fl = 0;
     for (int by = 0; by < q->vb; ++by) {
         GP_G uint8_t *row = gp_map_ent(g, i, by, 0);
         uint8_t pred = by ? rowbuf[0] : 0x7F;
@@ -643,7 +651,7 @@ GP_FN void gp_idc(GPic *g, const GCode *codes, int i, uint8_t *rowbuf)
             uint32_t delta = 0;
             if (run) --run;
             else {
-                delta = (uint32_t)gsym_sovf(c_dc, &dc, lo, hi);
+                delta = (uint32_t)gsym_sovf(c_dc, &dc, lo, hi, &fl);
                 if (delta == 0) run = (uint32_t)gsym(c_run, &rle);
             }
             const uint8_t v = (uint8_t)(pred + delta);                  /* uint8 wrap: h4m:1145-1149 */
@@ -652,6 +660,7 @@ GP_FN void gp_idc(GPic *g, const GCode *codes, int i, uint8_t *rowbuf)
             rowbuf[bx] = v;
         }
     }
+    GP_ST(g->part[GP_CAPW(i)], fl);
 }
 
 /* parallel: nest from the luma DC values (h4m:1166-1239), nibble-packed as hvq_parse.c pack_nest */
@@ -928,16 +937,18 @@ GP_FN void gp_predi_params(GPic *g, const GCode *codes, int i)
     GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
     const uint32_t n = g->nchain[i];
     GList ents;
+    uint32_t fl = 0;
     gl_init(&ents, g->clist + g->pl[i].blk_first, n, i == 0 ? 16u : 17u);   /* Y on one wave, U and V on another */
     for (uint32_t e = 0; e < n; ++e) {
         const uint32_t ent = gl_next(&ents);
         if ((ent >> 30) != GP_MODE_PREDI) continue;
         GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
-        const int32_t s1 = gsym_sovf(c_dc, &dc, lo, hi);
-        const int32_t s2 = gsym_sovf(c_dc, &dc, lo, hi);
+        const int32_t s1 = gsym_sovf(c_dc, &dc, lo, hi, &fl);
+        const int32_t s2 = gsym_sovf(c_dc, &dc, lo, hi, &fl);
         GP_ST(dst[0], (uint32_t)(s1 >> sh_dc) << sh_unk);
         GP_ST(dst[1], (uint32_t)(s2 >> sh_dc));
     }
+    GP_ST(g->part[GP_CAPW(6 + i)], fl);
 }
 
 GP_FN uint32_t gp_be16(const GPic *g, uint64_t off)
@@ -999,8 +1010,8 @@ GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
     GBits b = g->mtype;
     const GCode *c = &codes[GC_MCB];
     const int cap = GP_UOVF_CAP((uint32_t)g->mw * (uint32_t)g->mh);
-    uint32_t value = 0, count = 0;
-    if (b.live) { value = gb_take(&b, 2); count = (uint32_t)gsym_uovf(c, &b, cap); }
+    uint32_t value = 0, count = 0, fl = 0;
+    if (b.live) { value = gb_take(&b, 2); count = (uint32_t)gsym_uovf(c, &b, cap, &fl); }
     const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
     uint32_t m = 0, nr = 0;
     while (m < n) {
@@ -1009,7 +1020,7 @@ GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
             const uint32_t v = value & 3u;
             /* step table { {1,2,0,2}, {2,0,1,0} } of hvq_parse.c pb_pass1 */
             value = bit ? (v == 0 ? 2u : (v == 2 ? 1u : 0u)) : (v == 0 ? 1u : (v == 2 ? 0u : 2u));
-            count = (uint32_t)gsym_uovf(c, &b, cap);
+            count = (uint32_t)gsym_uovf(c, &b, cap, &fl);
             if (count == 0) count = n;            /* the reference's counter wraps below zero: the run never ends */
         }
         const uint32_t len = count < n - m ? count : n - m;
@@ -1017,6 +1028,7 @@ GP_FN void gp_mbtypes(GPic *g, const GCode *codes)
         m += len; count -= len;
     }
     g->ntrun = nr;
+    GP_ST(g->part[GP_CAPW(9)], fl);
 }
 
 /* chain, concurrent with gp_mbtypes: proc value of the n-th INTER macroblock from the mproc runs (h4m:1649-1668).
@@ -1029,15 +1041,18 @@ GP_FN void gp_mbprocs(GPic *g, const GCode *codes)
     GBits b = g->mproc;
     const GCode *c = &codes[GC_MCB];
     const int cap = GP_UOVF_CAP((uint32_t)g->mw * (uint32_t)g->mh);
-    uint32_t value = 0, count = 0;
-    if (b.live) { value = gb_take(&b, 1); count = (uint32_t)gsym_uovf(c, &b, cap); }
+    /* this chain decodes past what the picture uses (above): a run length that ended on the cap only counts when the run is
+     * used, so the word holds 1 + the first entry of the first such run and gp_result compares it with the inter macroblocks */
+    uint32_t value = 0, count = 0, fl = 0, capped_at = 0;
+    if (b.live) { value = gb_take(&b, 1); count = (uint32_t)gsym_uovf(c, &b, cap, &fl); if (fl) capped_at = 1u; }
     const uint32_t n = (uint32_t)g->mw * (uint32_t)g->mh;
     uint32_t m = 0, nr = 0;
     while (m < n) {
         if (count == 0) {
             if (b.idx > b.nd + 2u) break;
             value ^= 1u;
-            count = (uint32_t)gsym_uovf(c, &b, cap);
+            count = (uint32_t)gsym_uovf(c, &b, cap, &fl);
+            if (fl && !capped_at) capped_at = m + 1u;
             if (count == 0) count = n;
         }
         const uint32_t len = count < n - m ? count : n - m;
@@ -1045,6 +1060,7 @@ GP_FN void gp_mbprocs(GPic *g, const GCode *codes)
         m += len; count -= len;
     }
     g->nprun = nr; g->pend = m;
+    GP_ST(g->part[GP_CAPW(10)], capped_at);
 }
 
 /* parallel, after the two chains: the runs spread over mbtype[] and procseq[] */
@@ -1197,7 +1213,7 @@ GP_FN void gp_pbdc(GPic *g, const GCode *codes, int i)
     const int32_t lo = g->dc_lo, hi = g->dc_hi;
     GP_G uint8_t *dv = (GP_G uint8_t *)g->pinfo + g->pl[i].blk_first;
     const uint32_t n = g->ntype0;
-    uint32_t pbdc = 0x7F, prev = ~0u, at = 0;
+    uint32_t pbdc = 0x7F, prev = ~0u, at = 0, fl = 0;
     GList t0;
     gl_init(&t0, g->t0, n, i == 0 ? 14u : 15u);
     for (uint32_t r = 0; r < n; ++r) {
@@ -1205,11 +1221,12 @@ GP_FN void gp_pbdc(GPic *g, const GCode *codes, int i)
         if (m != prev + 1u) pbdc = 0x7F;                                /* a non-intra macroblock in between resets */
         prev = m;
         for (int j = 0; j < nblk; ++j) {
-            pbdc += (uint32_t)gsym_sovf(c_dc, &dc, lo, hi);
+            pbdc += (uint32_t)gsym_sovf(c_dc, &dc, lo, hi, &fl);
             GP_ST(dv[at], (uint8_t)pbdc); ++at;
         }
     }
     g->dc[i] = dc;
+    GP_ST(g->part[GP_CAPW(3 + i)], fl);
 }
 
 /* parallel, after the DC chains */
@@ -1287,7 +1304,13 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
 GP_FN void gp_result(const GPic *g, GP_G HvqParseResult *out, uint32_t extra_flags)
 {
     out->status = g->status;
-    out->flags = g->flags | extra_flags | (g->is15 ? HVQ_F_IS15 : 0u) | (g->landscape ? HVQ_F_LANDSCAPE : 0u);
+    uint32_t capped = 0;
+    for (int k = 0; k < GP_NCAPW - 1; ++k) capped |= g->part[GP_CAPW(k)];
+    {   /* proc runs: entries [0, inter macroblocks) are the ones the picture uses */
+        const uint32_t at = g->part[GP_CAPW(10)], inter = (uint32_t)g->mw * (uint32_t)g->mh - g->ntype0;
+        if (g->is_pb && at && at - 1u < inter) capped |= HVQ_F_CAPPED;
+    }
+    out->flags = g->flags | extra_flags | capped | (g->is15 ? HVQ_F_IS15 : 0u) | (g->landscape ? HVQ_F_LANDSCAPE : 0u);
     out->max_items = g->max_items; out->max_pairs = g->max_pairs;
     out->pool_dwords = g->pool_dwords; out->total_bytes = g->total;
     out->pad[0] = out->pad[1] = 0;

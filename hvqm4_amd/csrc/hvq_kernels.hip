@@ -471,6 +471,7 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
         t->w1 = nlit;
     }
     if (lit) ((GLB u32 *)(q + J->q_lits_off))[(size_t)tile * HVQ_TILE_BLOCKS + mine[4] + lanes_below(ml)] = (u32)tid | (off << 8);
+    if (J->q_offs_off) ((GLB u32 *)(q + J->q_offs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = off;     /* for hvq_selfref_kernel */
     if (cls) {
         const u32 it = cls == 1 ? mine[0] + lanes_below(m1) : nI + mine[1] + lanes_below(m2);
         u32 p0 = 0, p1 = 0;
@@ -521,6 +522,161 @@ extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_jo
         const uint32_t n = njobs - at < 32768u ? njobs - at : 32768u;
         hipLaunchKernelGGL(hvq_tileq_kernel, dim3(max_tiles, n), dim3(HVQ_WG), 0, stream, jobs_dev, first_job + at);
     }
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------------------
+ * P pictures with future-referencing (type 2) macroblocks.  HVQM4DecodePpic passes the picture being written as `future`
+ * (h4m:2058-2061), so such a macroblock reads `present` in whatever state the raster-order walk of BpicPlaneDec
+ * (h4m:1919-1967) has left it: new samples where an earlier macroblock has been, the buffer's previous content elsewhere --
+ * its own destination included (the copy loops of _MotionComp_* read and write sample by sample, h4m:1242-1279).
+ * Encoders do not emit this; it is reproduced for parity, not for speed: every other macroblock has been reconstructed into
+ * `side` by the data-parallel kernel, `dst` holds the previous content, and ONE workgroup walks the macroblocks in the
+ * reference's order -- all threads move finished macroblocks from `side`, thread 0 restates the reference's scalar code for
+ * the type-2 ones, reading `dst` through L2 (agent-scope accesses) in exactly the reference's order.
+ */
+struct SrGeo {
+    GLB uint8_t *pic;                  /* the picture being written (`present`) */
+    i32 lim;                           /* last readable byte offset */
+};
+__device__ __forceinline__ u32 sr_ld(const SrGeo &g, i32 o)
+{
+    o = clampi(o, 0, g.lim);
+    return __hip_atomic_load(g.pic + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sr_st(const SrGeo &g, i32 o, u32 v)
+{
+    o = clampi(o, 0, g.lim);
+    __hip_atomic_store(g.pic + o, (uint8_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* _MotionComp (h4m:1242-1294): sample (i, j) of the half-sample filtered source at `so`, read NOW */
+__device__ __forceinline__ u32 sr_mc_sample(const SrGeo &g, i32 so, i32 stride, int hx, int hy, int i, int j)
+{
+    const i32 a = so + i * stride + j;
+    if (!hx && !hy) return sr_ld(g, a);
+    if (hx && !hy) return (sr_ld(g, a) + sr_ld(g, a + 1) + 1u) / 2u;
+    if (!hx) return (sr_ld(g, a) + sr_ld(g, a + stride) + 1u) / 2u;
+    return (sr_ld(g, a) + sr_ld(g, a + 1) + sr_ld(g, a + stride) + sr_ld(g, a + stride + 1) + 2u) >> 2;
+}
+
+__global__ __launch_bounds__(HVQ_WG)
+void hvq_selfref_kernel(const HvqJob *__restrict__ J, const uint8_t *__restrict__ side, uint8_t *pic)
+{
+    const int tid = threadIdx.x;
+    const u32 flags = J->flags;
+    const bool is15 = flags & HVQ_F_IS15, landscape = flags & HVQ_F_LANDSCAPE;
+    const i32 unk = (i32)((flags >> HVQ_JOB_UNK_SHIFT) & 31u);
+    const i32 lw = (i32)J->width, mcb_w = (i32)J->mcb_w;
+    const i32 nmb = mcb_w * (i32)((J->plane[0].hbvb >> 16) / 2u);
+    const GLB u32 *__restrict__ pool = (const GLB u32 *)J->pool;
+    const GLB u32 *__restrict__ mvs = (const GLB u32 *)J->mv;
+    const GLB u32 *__restrict__ offs = (const GLB u32 *)((const GLB uint8_t *)J->tq + J->q_offs_off);
+    SrGeo g;
+    g.pic = (GLB uint8_t *)pic;
+    g.lim = (i32)J->slot_bytes - 1;
+    struct { const GLB uint8_t *map; i32 hb, pw, ws, hs, poff; u32 tile_first; } P[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        P[k].map = (const GLB uint8_t *)J->plane[k].map;
+        P[k].hb = (i32)(J->plane[k].hbvb & 0xFFFFu);
+        P[k].pw = (i32)(J->plane[k].pw_sub & 0xFFFFu);
+        P[k].ws = (i32)((J->plane[k].pw_sub >> 16) & 0xFFu); P[k].hs = (i32)(J->plane[k].pw_sub >> 24);
+        P[k].poff = (i32)J->plane[k].plane_off;
+        P[k].tile_first = J->plane[k].tile_first;
+    }
+    bool moved = false;
+    for (i32 m = 0; m < nmb; ++m) {
+        const i32 my = m / mcb_w, mx = m - my * mcb_w;
+        const u32 T = (u32)__builtin_amdgcn_readfirstlane((int)P[0].map[2 * ((2 * my + 1) * (P[0].hb + 2) + 2 * mx + 1) + 1]);
+        if (((T >> 5) & 3u) != 2u) {
+            /* finished by the data-parallel pass: its samples move from the side buffer into the picture */
+            int k = -1, r = 0, col = 0;
+            const int cw = 8 >> P[1].ws, ch = 8 >> P[1].hs, cn = cw * ch;
+            if (tid < 64) { k = 0; r = tid >> 3; col = tid & 7; }
+            else if (tid - 64 < cn) { k = 1; r = (tid - 64) / cw; col = (tid - 64) - r * cw; }
+            else if (tid - 64 - cn < cn) { k = 2; r = (tid - 64 - cn) / cw; col = (tid - 64 - cn) - r * cw; }
+            if (k >= 0) {
+                const i32 o = P[k].poff + (my * (8 >> P[k].hs) + r) * P[k].pw + mx * (8 >> P[k].ws) + col;
+                pic[o] = side[o];
+            }
+            moved = true;
+            continue;
+        }
+        if (moved) { __syncthreads(); moved = false; }            /* what was moved is in L2 before thread 0 reads the picture */
+        if (tid == 0) {
+            const u32 mvw = mvs[m];
+            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);      /* absolute half-sample target (h4m:1954-1955) */
+            const bool proc = T & 0x10u;
+            const i32 origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;   /* h4m:1865-1868 */
+            for (int k = 0; k < 3; ++k) {
+                const i32 pw = P[k].pw, ws = P[k].ws, hs = P[k].hs;
+                const i32 pdx = rx >> ws, pdy = ry >> hs;
+                const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);       /* h4m:1337-1343, 1889-1896 */
+                const int bxp = 2 >> ws, byp = 2 >> hs, nblk = bxp * byp;
+                for (int j = 0; j < nblk; ++j) {                                                   /* TL, BL, BR, TR (h4m:447-455) */
+                    const int dx = nblk == 1 ? 0 : (j >> 1), dy = nblk == 1 ? 0 : ((j == 1 || j == 2) ? 1 : 0);
+                    const i32 bx = mx * bxp + dx, by = my * byp + dy;
+                    const i32 dsto = P[k].poff + by * 4 * pw + bx * 4;
+                    const i32 srco = P[k].poff + (pdy >> 1) * pw + (pdx >> 1) + dy * 4 * pw + dx * 4;
+                    const u32 kind = (u32)P[k].map[2 * ((by + 1) * (P[k].hb + 2) + bx + 1) + 1] & 0xFu;
+                    const u32 b = (u32)(by * P[k].hb + bx);
+                    const u32 off = offs[(size_t)(P[k].tile_first + b / HVQ_TILE_BLOCKS) * HVQ_TILE_BLOCKS + b % HVQ_TILE_BLOCKS];
+                    if (!proc && kind == 6u) {                                                     /* OrgBlock, h4m:543-549 */
+                        for (int i = 0; i < 4; ++i) {
+                            const u32 w4 = pool[off + (u32)i];
+                            for (int x = 0; x < 4; ++x) sr_st(g, dsto + i * pw + x, (w4 >> (8 * x)) & 0xFFu);
+                        }
+                    } else if (proc || kind == 0u) {
+                        /* _MotionComp straight into the picture: sample by sample, each read sees what has been written so far */
+                        for (int i = 0; i < 4; ++i)
+                            for (int x = 0; x < 4; ++x) sr_st(g, dsto + i * pw + x, sr_mc_sample(g, srco, pw, hx, hy, i, x));
+                    } else {
+                        /* PrediAotBlock (h4m:1379-1420): the AOT sum over the window first, then the MC block into a temporary,
+                         * only then the destination */
+                        u32 acc[16];
+                        for (int i = 0; i < 16; ++i) acc[i] = 0;
+                        const u32 nb = kind - 1u;
+                        for (u32 q = 0; q < nb; ++q) {
+                            const u32 d = pool[off + 2u + q];
+                            const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
+                            const u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
+                            i32 o, ys, xs;
+                            if (landscape) { o = lw * os + ol; xs = 1 << sl; ys = lw << ss; }
+                            else           { o = lw * ol + os; xs = 1 << ss; ys = lw << sl; }
+                            u32 e[16], lo = 255, hi = 0;
+                            for (int i = 0; i < 4; ++i)
+                                for (int x = 0; x < 4; ++x) {
+                                    const u32 v = (sr_ld(g, origin + o + i * ys + x * xs) >> 4) & 15u;
+                                    e[4 * i + x] = v; lo = min(lo, v); hi = max(hi, v);
+                                }
+                            const u32 gn = basis_gain(d, lo, hi);
+                            for (int i = 0; i < 16; ++i) acc[i] += gn * e[i];
+                        }
+                        u32 total = 0;
+                        for (int i = 0; i < 16; ++i) total += acc[i];
+                        const u32 mean_aot = (u32)((i32)total >> 4);
+                        u32 md[16], sum = 8, lo = 255, hi = 0;
+                        for (int i = 0; i < 4; ++i)
+                            for (int x = 0; x < 4; ++x) { const u32 v = sr_mc_sample(g, srco, pw, hx, hy, i, x); md[4 * i + x] = v; sum += v; lo = min(lo, v); hi = max(hi, v); }
+                        const i32 mean = (i32)(sum >> 4);
+                        const u32 addend = pool[off] - mean_aot;
+                        const u32 factor = pool[off + 1u] * udiv_small(0x1000u, hi - lo);            /* mcdivTable[max - min] */
+                        for (int i = 0; i < 16; ++i) {
+                            const u32 t = (u32)((i32)md[i] - mean) * factor;
+                            const i32 v = sar(acc[i] + addend + t, unk) + (i32)md[i];
+                            sr_st(g, dsto + (i >> 2) * pw + (i & 3), (u32)clampi(v, 0, 255));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *side, uint8_t *dst, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hvq_selfref_kernel, dim3(1), dim3(HVQ_WG), 0, stream, job_dev, side, dst);
     return hipGetLastError();
 }
 
@@ -956,9 +1112,13 @@ extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_bu
  * into FMAs), clamp, truncate.  Pure streaming kernel: 1.5 B/px read, 3 B/px written; one lane = 4 samples
  * of a row = one dword of Y in, three dwords of RGB out (a wave stores 768 contiguous bytes).
  */
-__device__ __forceinline__ u32 rgb_clamp(float f)
+/* clamp to [0, 255] and truncate (h4m:897-900), packed into byte `sel` of `acc`: v_floor_f32 + v_cvt_pk_u8_f32.  The pack
+ * instruction saturates at both ends but rounds to nearest, the floor in front makes it exact (tools/ubench/cvt_probe.hip on
+ * gfx950; the same arithmetic is proved equal to the reference's dumpRGB over all 2^24 (Y, U, V) triples in tests/test_rgb_exhaustive.py).
+ * Replaces two compares, two selects, a convert, a shift and an or per sample (857 -> 434 VALU per lane of 32 samples). */
+__device__ __forceinline__ u32 rgb_put(float f, u32 sel, u32 acc)
 {
-    return f < 0.f ? 0u : f > 255.f ? 255u : (u32)f;          /* h4m:897-900 */
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(f), sel, acc);
 }
 
 struct HvqRgbJob { const uint8_t *yuv; uint8_t *rgb; int w, h; };
@@ -972,13 +1132,13 @@ __device__ __forceinline__ void rgb4(u32 y4, u32 u2, u32 v2, u32 out[3])
         const float Y = (float)((y4 >> (8 * k)) & 0xFFu);
         const float U = __fsub_rn((float)((u2 >> (8 * (k >> 1))) & 0xFFu), 128.f);
         const float V = __fsub_rn((float)((v2 >> (8 * (k >> 1))) & 0xFFu), 128.f);
-        const u32 px[3] = { rgb_clamp(__fadd_rn(Y, __fmul_rn(1.402f, V))),
-                            rgb_clamp(__fsub_rn(__fsub_rn(Y, __fmul_rn(0.34414f, U)), __fmul_rn(0.71414f, V))),
-                            rgb_clamp(__fadd_rn(Y, __fmul_rn(1.772f, U))) };
+        const float px[3] = { __fadd_rn(Y, __fmul_rn(1.402f, V)),
+                              __fsub_rn(__fsub_rn(Y, __fmul_rn(0.34414f, U)), __fmul_rn(0.71414f, V)),
+                              __fadd_rn(Y, __fmul_rn(1.772f, U)) };
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int byte = 3 * k + c;
-            out[byte >> 2] |= px[c] << (8 * (byte & 3));
+            out[byte >> 2] = rgb_put(px[c], (u32)(byte & 3), out[byte >> 2]);
         }
     }
 }

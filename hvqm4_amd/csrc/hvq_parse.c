@@ -19,7 +19,7 @@
 
 #define LUT_BITS 10
 /* caps of the overflow-symbol loops, identical in hvq_gparse_core.h (see there) */
-#define SOVF_CAP 256
+#define SOVF_CAP 4096
 #define UOVF_CAP(nmb) ((int)((nmb) / 255u) + 16)
 
 /* ------------------------------------------------------------------ bit reader */
@@ -129,20 +129,23 @@ static inline int32_t sym(const Code *c, BitRd *b)                            /*
     return c->leaf[id];
 }
 
-static int32_t sym_sovf(const Code *c, BitRd *b, int32_t lo, int32_t hi)       /* h4m:654-664 */
+/* `*flags` gets HVQ_F_CAPPED when the loop ends on its cap, not on the stream: the reference would have gone on summing */
+static int32_t sym_sovf(const Code *c, BitRd *b, int32_t lo, int32_t hi, uint32_t *flags)       /* h4m:654-664 */
 {
     uint32_t total = 0;
     int32_t v;
     int guard = 0;
     do { v = sym(c, b); total += (uint32_t)v; } while ((v <= lo || v >= hi) && ++guard < SOVF_CAP);
+    if (v <= lo || v >= hi) *flags |= HVQ_F_CAPPED;
     return (int32_t)total;
 }
 
-static int32_t sym_uovf(const Code *c, BitRd *b, int cap)                      /* h4m:667-677 */
+static int32_t sym_uovf(const Code *c, BitRd *b, int cap, uint32_t *flags)     /* h4m:667-677 */
 {
     int32_t total = 0, v;
     int guard = 0;
     do { v = sym(c, b); total += v; } while (v >= 0xFF && ++guard < cap);
+    if (v >= 0xFF) *flags |= HVQ_F_CAPPED;
     return total;
 }
 
@@ -457,7 +460,7 @@ static void ipic_dc(HvqParser *p, uint8_t *blob)                                
                 uint32_t delta = 0;
                 if (run) --run;
                 else {
-                    delta = (uint32_t)sym_sovf(&p->c_dc, &p->dc[i], p->dc_lo, p->dc_hi);
+                    delta = (uint32_t)sym_sovf(&p->c_dc, &p->dc[i], p->dc_lo, p->dc_hi, &p->flags);
                     if (delta == 0) run = (uint32_t)sym(&p->c_run, &p->rle[i]);
                 }
                 uint8_t v = (uint8_t)(pred + delta);               /* uint8 wrap: h4m:1145-1149 */
@@ -583,8 +586,8 @@ static void pb_pass1(HvqParser *p, uint8_t *blob, int is_P)                     
     static const uint32_t step[2][4] = { { 1, 2, 0, 2 }, { 2, 0, 1, 0 } };
     const int cap = UOVF_CAP((uint32_t)(p->w / 8) * (uint32_t)(p->h / 8));
     RunLen type = { 0, 0 }, proc = { 0, 0 };
-    if (p->mproc.live) { proc.value = br_take(&p->mproc, 1); proc.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mproc, cap); }
-    if (p->mtype.live) { type.value = br_take(&p->mtype, 2); type.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mtype, cap); }
+    if (p->mproc.live) { proc.value = br_take(&p->mproc, 1); proc.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mproc, cap, &p->flags); }
+    if (p->mtype.live) { type.value = br_take(&p->mtype, 2); type.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mtype, cap, &p->flags); }
     uint32_t rl[2] = { 0, 0 };
     uint32_t pbdc[3] = { 0x7F, 0x7F, 0x7F };
     int mw = p->w / 8, mh = p->h / 8;
@@ -592,7 +595,7 @@ static void pb_pass1(HvqParser *p, uint8_t *blob, int is_P)                     
         for (int mx = 0; mx < mw; ++mx) {
             if (type.count == 0) {
                 type.value = step[br_take(&p->mtype, 1)][type.value & 3];
-                type.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mtype, cap);
+                type.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mtype, cap, &p->flags);
             }
             --type.count;
             if (type.value == 0) {
@@ -600,7 +603,7 @@ static void pb_pass1(HvqParser *p, uint8_t *blob, int is_P)                     
                     const PPlane *q = &p->pl[i];
                     uint8_t *e = map_ent(p, blob, i, my * q->by_per, mx * q->bx_per);
                     for (int j = 0; j < q->nblk; ++j) {
-                        pbdc[i] += (uint32_t)sym_sovf(&p->c_dc, &p->dc[i], p->dc_lo, p->dc_hi);
+                        pbdc[i] += (uint32_t)sym_sovf(&p->c_dc, &p->dc[i], p->dc_lo, p->dc_hi, &p->flags);
                         e[2 * q->moff[j]] = (uint8_t)pbdc[i];
                     }
                 }
@@ -608,7 +611,7 @@ static void pb_pass1(HvqParser *p, uint8_t *blob, int is_P)                     
             } else {
                 if (is_P && type.value >= 2) p->flags |= HVQ_F_SELF_REF;
                 pbdc[0] = pbdc[1] = pbdc[2] = 0x7F;
-                if (proc.count == 0) { proc.value ^= 1; proc.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mproc, cap); }
+                if (proc.count == 0) { proc.value ^= 1; proc.count = (uint32_t)sym_uovf(&p->c_mcb, &p->mproc, cap, &p->flags); }
                 --proc.count;
                 pb_kinds(p, blob, mx, my, proc.value, type.value, rl);
             }
@@ -710,8 +713,8 @@ static int parse_pbpic(HvqParser *p, int is_P, const uint8_t *pic, uint8_t *blob
                     uint32_t *dst = pool + p->blk_off[i][b];
                     if (k == 6) { fx_literal(p, i, dst); continue; }
                     emit_bases(p, i, k - 1, dst + 2);
-                    int32_t s1 = sym_sovf(&p->c_dc, &p->dc[i], p->dc_lo, p->dc_hi);    /* h4m:1405-1406 */
-                    int32_t s2 = sym_sovf(&p->c_dc, &p->dc[i], p->dc_lo, p->dc_hi);
+                    int32_t s1 = sym_sovf(&p->c_dc, &p->dc[i], p->dc_lo, p->dc_hi, &p->flags);    /* h4m:1405-1406 */
+                    int32_t s2 = sym_sovf(&p->c_dc, &p->dc[i], p->dc_lo, p->dc_hi, &p->flags);
                     dst[0] = (uint32_t)(s1 >> sh_dc) << sh_unk;
                     dst[1] = (uint32_t)(s2 >> sh_dc);
                 }

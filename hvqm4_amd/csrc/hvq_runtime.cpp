@@ -45,6 +45,7 @@ extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
                                        uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream);
 extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, hipStream_t stream);
+extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *side, uint8_t *dst, hipStream_t stream);
 extern "C" hipError_t hvq_upload_tables(void);
 
 #ifdef HVQ_STAMPS
@@ -88,14 +89,12 @@ static uint32_t picture_workgroups(const uint32_t tile_first[4])
 }
 
 /* Pictures this back end refuses instead of decoding them differently from the reference:
- *   HVQ_F_SELF_REF  a P picture with a future-referencing macroblock: the reference aliases `future` to the picture being
- *                   written (h4m:2058-2061, read at h4m:1941-1949), so such a macroblock reads samples in raster-order-
- *                   dependent states -- not reproducible by a data-parallel reconstruction;
+ *   HVQ_F_CAPPED    an overflow-symbol run ended on the parsers' cap: the reference would have gone on summing (h4m:654-677);
  *   HVQ_F_CLAMPED   a nest origin or vector target outside what the reference's arithmetic keeps in bounds was clamped
  *                   (malformed input); HVQM4_AMD_ALLOW_CLAMPED=1 decodes such pictures with the clamped values. */
 static const char *unsupported_reason(uint32_t flags)
 {
-    if (flags & HVQ_F_SELF_REF) return "P picture with a future-referencing macroblock (the reference reads the picture being written, h4m:2058-2061)";
+    if (flags & HVQ_F_CAPPED) return "an overflow-symbol run is longer than this back end follows (the reference sums for as long as the stream says, h4m:654-677)";
     if (flags & HVQ_F_CLAMPED) {
         const char *e = getenv("HVQM4_AMD_ALLOW_CLAMPED");
         if (!(e && atoi(e) > 0)) return "malformed picture: a nest origin or vector target had to be clamped (HVQM4_AMD_ALLOW_CLAMPED=1 decodes it anyway)";
@@ -131,6 +130,10 @@ struct Stream {
     uint8_t *nest_keep_ptr(int which) const { return nest_keep + (size_t)which * GP_ALIGN16(HVQ_NESTP_BYTES); }
     int nest_src = -1;                       /* pending index of the last I picture queued in this batch, -1: nest_keep */
     bool need_I = false;                     /* a picture of this stream was rejected: P/B pictures are refused until the next I picture */
+    /* the reference player's three buffers (h4m:2087-2093, 2131-2137), as ordinals of the pictures they hold (-1: never written):
+     * a P picture with future-referencing macroblocks reads what `present` held before (h4m:2058-2061) */
+    int rp_past = -1, rp_future = -1, rp_present = -1;
+    const void *sdk_present = nullptr;       /* SDK path: the caller's `present` buffer of the picture being submitted */
     uint8_t *slot_ptr(int s) const { return dev + (size_t)(s < 0 ? (int)slots.size() : s) * slot_bytes; }
 };
 
@@ -149,6 +152,9 @@ struct Pending {
     uint32_t flags = 0, unk_shift = 0, pool_dwords = 0;
     int status = 0;                    /* device parse status bits (GP_ST_*) */
     bool dropped = false;              /* rejected at flush time (or follows a rejected picture of its stream): not reconstructed */
+    int old_slot = -1;                 /* P pictures: slot that holds what the reference's `present` buffer held before this picture
+                                          (-1: never written -> the zero slot; -2: that picture's slot has been reused since) */
+    const void *host_old = nullptr;    /* SDK path: the caller's `present` buffer itself */
 };
 
 struct Launch {
@@ -159,6 +165,18 @@ struct Launch {
     uint32_t max_wg[2], wgs[2];        /* the same for one / two tiles per workgroup (chosen at flush_end, when the queues are known) */
     uint32_t tpw;
     uint32_t items_cap;                /* LDS sizing of the launch: max over its pictures */
+};
+
+/* a P picture with future-referencing macroblocks, behind the launch of its level: previous content into the destination slot
+ * (unless it is there already), then the raster-order walk (hvq_selfref_kernel) from the side buffer */
+struct SelfRef {
+    int level, queue;
+    uint32_t job;                      /* launch slot */
+    const uint8_t *old_dev;            /* device source of the previous content, nullptr: in place already */
+    const void *old_host;              /* SDK path: host source */
+    uint8_t *dst;
+    size_t side_off;                   /* side buffer inside selfref_dev */
+    uint32_t pic_bytes;
 };
 
 struct HvqContext {
@@ -177,7 +195,8 @@ struct HvqContext {
     size_t arena_cap_alt = 0;
     int arena_id = 0;                  /* which of the two the current one is */
     bool arena_waited = false;         /* copy_stream already waits for the last batch that used the current arena */
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, read_stream = nullptr;
+    hipEvent_t ev_read = nullptr;
     hipEvent_t ev_copy = nullptr, ev_parse = nullptr, ev_arena_free[2] = { nullptr, nullptr };
     std::vector<Pending> pending;
     /* batch in flight */
@@ -203,6 +222,9 @@ struct HvqContext {
     size_t jobs_cap = 0;
     uint8_t *tq_dev = nullptr;         /* tile queues of the resident batch (hvq_tileq_kernel), read by every (re)play */
     size_t tq_cap = 0;
+    uint8_t *selfref_dev = nullptr;    /* side buffers of the batch's self-referencing P pictures */
+    size_t selfref_cap = 0;
+    std::vector<SelfRef> selfrefs;
     std::vector<Launch> launches;
     std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
     HvqStats stats{};
@@ -301,6 +323,8 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->read_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_parse, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_arena_free[0], hipEventDisableTiming));
@@ -341,8 +365,11 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->ev_parse) (void)hipEventDestroy(c->ev_parse);
     for (auto e : c->ev_arena_free) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->read_stream) { (void)hipStreamSynchronize(c->read_stream); (void)hipStreamDestroy(c->read_stream); }
+    if (c->ev_read) (void)hipEventDestroy(c->ev_read);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tq_dev) (void)hipFree(c->tq_dev);
+    if (c->selfref_dev) (void)hipFree(c->selfref_dev);
     if (c->rgb_dev) (void)hipFree(c->rgb_dev);
     if (c->rgb_jobs_dev) (void)hipFree(c->rgb_jobs_dev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -413,7 +440,13 @@ static int enqueue_common(HvqContext *c, int sid, int frame_type, Pending q)
 {
     Stream &s = c->streams[(size_t)sid];
     q.stream = sid; q.ordinal = s.npics;
-    if (frame_type != HVQ_FRAME_B) std::swap(s.anchor_old, s.anchor_new);   /* past <-> future */
+    if (frame_type != HVQ_FRAME_B) { std::swap(s.anchor_old, s.anchor_new); std::swap(s.rp_past, s.rp_future); }   /* past <-> future */
+    /* where what the reference's `present` buffer holds right now lives here (looked up before the ring hands out a slot) */
+    const int old_ord = s.rp_present;
+    q.old_slot = old_ord < 0 ? -1 : (s.pic_slot[(size_t)old_ord] >= 0 ? s.pic_slot[(size_t)old_ord] : -2);
+    q.host_old = s.sdk_present;
+    s.rp_present = q.ordinal;
+    if (frame_type != HVQ_FRAME_B) std::swap(s.rp_present, s.rp_future);
     q.dst = alloc_slot(s);
     if (frame_type == HVQ_FRAME_I) { q.ref0 = -1; q.ref1 = -1; }
     else if (frame_type == HVQ_FRAME_P) { q.ref0 = s.anchor_old; q.ref1 = q.dst; }  /* future aliases present, h4m:2060 */
@@ -422,6 +455,12 @@ static int enqueue_common(HvqContext *c, int sid, int frame_type, Pending q)
     auto dep_w = [&](int slot) { if (slot >= 0 && slot != q.dst) lvl = std::max(lvl, s.slots[slot].w_level + 1); };
     dep_w(q.ref0); dep_w(q.ref1);
     lvl = std::max(lvl, std::max(s.slots[q.dst].w_level, s.slots[q.dst].r_level) + 1);
+    if (frame_type == HVQ_FRAME_P && q.old_slot >= 0 && q.old_slot != q.dst) {
+        /* should the picture turn out to reference itself (known after its parse), that slot is read behind this level's launch:
+         * complete by then, and not handed to a later picture before */
+        lvl = std::max(lvl, s.slots[(size_t)q.old_slot].w_level);
+        s.slots[(size_t)q.old_slot].r_level = std::max(s.slots[(size_t)q.old_slot].r_level, lvl);
+    }
     q.level = lvl;
     if (q.ref0 >= 0) s.slots[q.ref0].r_level = std::max(s.slots[q.ref0].r_level, lvl);
     if (q.ref1 >= 0 && q.ref1 != q.dst) s.slots[q.ref1].r_level = std::max(s.slots[q.ref1].r_level, lvl);
@@ -883,9 +922,16 @@ static int run_launches(HvqContext *c)
         HIPCHK(hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
-    for (auto &L : c->launches)
-        HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap,
-                                L.queue ? c->stream2 : c->stream));
+    for (auto &L : c->launches) {
+        hipStream_t st = L.queue ? c->stream2 : c->stream;
+        HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, st));
+        for (const SelfRef &sr : c->selfrefs) {
+            if (sr.level != L.level || sr.queue != L.queue) continue;
+            if (sr.old_host) HIPCHK(hipMemcpyAsync(sr.dst, sr.old_host, sr.pic_bytes, hipMemcpyHostToDevice, st));
+            else if (sr.old_dev) HIPCHK(hipMemcpyAsync(sr.dst, sr.old_dev, sr.pic_bytes, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hvq_launch_selfref(c->jobs_dev + sr.job, c->selfref_dev + sr.side_off, sr.dst, st));
+        }
+    }
     if (two) {
         HIPCHK(hipEventRecord(c->ev_join, c->stream2));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -1011,6 +1057,14 @@ static int flush_end(HvqContext *c)
                 if (p.status) { code = (p.status & GP_ST_OVERFLOW) ? HVQ_E_OVERFLOW : HVQ_E_ARG; why = "the GPU parser rejected the bitstream"; }
                 else if ((why = unsupported_reason(p.flags)) != nullptr) code = HVQ_E_UNSUPPORTED;
             }
+            if (!broken[(size_t)p.stream] && !code && p.kind == HVQ_PIC_P && p.old_slot == -2 && !p.host_old) {
+                const uint32_t fl = p.dev ? p.flags : ((const HvqPicHeader *)(c->fl_host + p.blob_off))->flags;
+                if (fl & HVQ_F_SELF_REF) {
+                    code = HVQ_E_UNSUPPORTED;
+                    why = "P picture with future-referencing macroblocks (h4m:2058-2061) whose `present` buffer content -- the picture "
+                          "the reference player's third buffer holds at this point -- is no longer resident: open the stream with more slots";
+                }
+            }
             if (code) {
                 broken[(size_t)p.stream] = 1;
                 if (!first_rc) first_rc = fail(code, "stream %d picture %d: %s (status %d); dropped with the later pictures of this stream, "
@@ -1043,8 +1097,9 @@ static int flush_end(HvqContext *c)
     jobs.assign(slots.size(), HvqJob{});
     std::vector<size_t> tq_off(slots.size(), 0);
     std::vector<uint32_t> slot_of(c->fl_pending.size(), 0);
-    size_t tq_bytes = 0;
+    size_t tq_bytes = 0, side_bytes = 0;
     uint32_t max_tiles = 0;
+    c->selfrefs.clear();
     HvqStats st{};
     for (size_t k = 0; k < slots.size(); ++k) {
         HvqJob &j = jobs[k];
@@ -1084,9 +1139,25 @@ static int flush_end(HvqContext *c)
             const uint32_t cap_items = std::min(256u, (uint32_t)p.max_items), cap_pairs = std::min(HVQ_PAIR_CAP_MAX, p.max_pairs);
             tq_bytes = align_up(tq_bytes, 256);
             tq_off[k] = tq_bytes;
+            const bool selfref = p.kind == HVQ_PIC_P && (hd->flags & HVQ_F_SELF_REF);
             const size_t recs = align_up((size_t)nt * sizeof(HvqTileQ), 16), lits = recs + (size_t)nt * HVQ_TILE_BLOCKS * 8,
                          items = lits + (size_t)nt * HVQ_TILE_BLOCKS * 4,
-                         pairs = items + (size_t)nt * cap_items * 16, end = pairs + (size_t)nt * cap_pairs * 8;
+                         pairs = items + (size_t)nt * cap_items * 16, offs = pairs + (size_t)nt * cap_pairs * 8,
+                         end = offs + (selfref ? (size_t)nt * HVQ_TILE_BLOCKS * 4 : 0);
+            if (selfref) {
+                /* the data-parallel pass writes a side buffer; the walk behind this level's launch merges it into the slot */
+                j.q_offs_off = (uint32_t)offs;
+                SelfRef sr{};
+                sr.level = p.level; sr.queue = c->fl_nq == 2 ? (p.stream & 1) : 0; sr.job = (uint32_t)k;
+                sr.old_host = p.host_old;
+                sr.old_dev = (p.host_old || p.old_slot == p.dst) ? nullptr : s.slot_ptr(p.old_slot);     /* -1: the zero slot */
+                sr.dst = s.slot_ptr(p.dst);
+                side_bytes = align_up(side_bytes, 256);
+                sr.side_off = side_bytes;
+                sr.pic_bytes = s.pic_bytes;
+                side_bytes += s.slot_bytes;
+                c->selfrefs.push_back(sr);
+            }
             if (end >= ((size_t)1 << 32)) return fail(HVQ_E_OVERFLOW, "stream %d picture %d: tile queues exceed 4 GiB", p.stream, p.ordinal);
             j.q_recs_off = (uint32_t)recs; j.q_lits_off = (uint32_t)lits; j.q_items_off = (uint32_t)items; j.q_pairs_off = (uint32_t)pairs;
             j.q_caps = cap_items | (cap_pairs << 16);
@@ -1121,11 +1192,13 @@ static int flush_end(HvqContext *c)
             mi = std::max(mi, p.max_items); mp = std::max(mp, p.max_pairs);
             payload += jobs[slot_of[i]].pool_dwords; ntl += p.ntiles;
         }
-        /* Two tiles per workgroup (pooled queue, twice the loads in flight per wave) while the pooled accumulators still leave
-         * 8 workgroups per CU; AOT-dense launches keep one tile per workgroup (profiles/r02o_ab_two_tiles.txt). */
+        /* Two tiles per workgroup: twice the loads in flight per wave for the same chain of round trips -- what a latency-bound
+         * kernel is short of (profiles/r03_ablation.txt).  Since the tile queues left the kernel's LDS (11.6 KB per tile) the pooled
+         * accumulators of two tiles cost the AOT-dense stream no occupancy either (dense +3.7 %, flat +5 %); one tile only when the
+         * two tiles' items would need more than 192 accumulator rows (LDS: fewer than 7 workgroups per CU). */
         static const int force_tpw = getenv("HVQM4_AMD_TILES_PER_WG") ? atoi(getenv("HVQM4_AMD_TILES_PER_WG")) : 0;
-        /* the AOT density of the launch decides: payload dwords per tile (dense synthetic stream ~220, realistic ~35, flat ~1) */
-        L.tpw = force_tpw ? (force_tpw >= 2 ? 2u : 1u) : (payload < 128u * std::max<uint64_t>(ntl, 1) ? 2u : 1u);
+        (void)payload; (void)ntl;
+        L.tpw = force_tpw ? (force_tpw >= 2 ? 2u : 1u) : (2u * mi <= 192u ? 2u : 1u);
         L.items_cap = std::min(256u * L.tpw, std::max(32u, L.tpw * mi));
         (void)mp;
         L.max_tiles = L.max_wg[L.tpw - 1]; L.workgroups = L.wgs[L.tpw - 1];
@@ -1149,6 +1222,16 @@ static int flush_end(HvqContext *c)
     }
     for (size_t k = 0; k < jobs.size(); ++k)
         if (jobs[k].total_tiles) jobs[k].tq = (uint64_t)(uintptr_t)(c->tq_dev + tq_off[k]);
+    if (side_bytes > c->selfref_cap) {
+        if (c->selfref_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->selfref_dev)); c->selfref_dev = nullptr; c->selfref_cap = 0; }
+        HIPCHK(hipMalloc((void **)&c->selfref_dev, side_bytes));
+        c->selfref_cap = side_bytes;
+    }
+    for (const SelfRef &sr : c->selfrefs)
+        for (int k = 0; k < 3; ++k) {
+            HvqPlaneRec &r = jobs[sr.job].plane[k];
+            r.dst = (uint64_t)(uintptr_t)(c->selfref_dev + sr.side_off) + r.plane_off;
+        }
     /* stream-ordered after whatever still reads the previous table */
     { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return rcu; }
     /* 2b. tile queues: once per picture, from the descriptors (type bytes, vectors, basis words) that are now all in HBM */
@@ -1194,6 +1277,8 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
     if (!c || reps < 0) return fail(HVQ_E_ARG, "bad arguments");
     { int rc = flush_end(c); if (rc) return rc; }
     if (c->launches.empty()) return fail(HVQ_E_STATE, "nothing flushed yet");
+    if (!c->selfrefs.empty())
+        return fail(HVQ_E_STATE, "the resident batch holds self-referencing P pictures: their previous buffer content is gone after the first pass");
     if (!c->pending.empty()) return fail(HVQ_E_STATE, "pictures queued since the last flush");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
@@ -1308,6 +1393,85 @@ HVQ_EXPORT int hvq_read_picture_rgb(HvqContext *c, int sid, int ordinal, void *d
     HIPCHK(hipMemcpyAsync(dst, c->rgb_dev, need, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return HVQ_OK;
+}
+
+/* the reference player's dumpRGB (h4m:897-926) on a host picture: Y|U|V 4:2:0 in, RGB24 out */
+HVQ_EXPORT int hvq_convert_yuv420_rgb(HvqContext *c, const void *yuv, int width, int height, void *rgb)
+{
+    if (!c || !yuv || !rgb || width <= 0 || height <= 0 || (width & 3) || (height & 1) || width > 16384 || height > 16384)
+        return fail(HVQ_E_ARG, "bad arguments (width a multiple of 4, height even)");
+    HIPCHK(hipSetDevice(c->device));
+    { int rc = flush_end(c); if (rc) return rc; }
+    const size_t nyuv = (size_t)width * height * 3 / 2, nrgb = (size_t)width * height * 3;
+    uint8_t *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, nyuv));
+    hipError_t e = hipMemcpyAsync(d, yuv, nyuv, hipMemcpyHostToDevice, c->stream);
+    int rc = HVQ_OK;
+    if (e != hipSuccess) rc = fail(HVQ_E_HIP, "upload: %s", hipGetErrorString(e));
+    RgbJob job{ d, nullptr, width, height };
+    if (!rc) rc = rgb_run(c, &job, 1, 1, nullptr);
+    if (!rc) {
+        e = hipMemcpyAsync(rgb, c->rgb_dev, nrgb, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(HVQ_E_HIP, "download: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    return rc;
+}
+
+/* ---- getting pictures out at the rate they are made (the per-picture hvq_read_picture synchronises every time) ---- */
+HVQ_EXPORT void *hvq_pinned_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(HVQ_E_HIP, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+
+HVQ_EXPORT void hvq_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+
+/* resident picture -> its slot, after ending the batch in flight; nullptr + error when it is queued, unknown or gone */
+static const uint8_t *resident_picture(HvqContext *c, int sid, int ordinal, int *rc)
+{
+    *rc = HVQ_OK;
+    if (sid < 0 || sid >= (int)c->streams.size() || !c->streams[(size_t)sid].open) { *rc = fail(HVQ_E_ARG, "bad stream %d", sid); return nullptr; }
+    Stream &s = c->streams[(size_t)sid];
+    if (ordinal < 0 || ordinal >= s.npics) { *rc = fail(HVQ_E_ARG, "stream %d: bad picture ordinal %d", sid, ordinal); return nullptr; }
+    for (auto &p : c->pending)
+        if (p.stream == sid && p.ordinal == ordinal) { *rc = fail(HVQ_E_STATE, "stream %d picture %d is queued but not flushed", sid, ordinal); return nullptr; }
+    const int slot = s.pic_slot[(size_t)ordinal];
+    if (slot < 0) { *rc = fail(HVQ_E_STATE, "stream %d picture %d is no longer resident (slot reused, or the picture was dropped)", sid, ordinal); return nullptr; }
+    return s.slot_ptr(slot);
+}
+
+HVQ_EXPORT int hvq_read_pictures(HvqContext *c, int n, const int *streams, const int *ordinals, void *const *dst)
+{
+    if (!c || n < 0 || (n && (!streams || !ordinals || !dst))) return fail(HVQ_E_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    { int rc = flush_end(c); if (rc) return rc; }
+    /* all copies are queued on the read stream behind what the compute stream has been given so far; ONE wait at the end */
+    HIPCHK(hipEventRecord(c->ev_read, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->read_stream, c->ev_read, 0));
+    for (int i = 0; i < n; ++i) {
+        int rc = HVQ_OK;
+        const uint8_t *src = resident_picture(c, streams[i], ordinals[i], &rc);
+        if (!src || !dst[i]) { (void)hipStreamSynchronize(c->read_stream); return src ? fail(HVQ_E_ARG, "null destination %d", i) : rc; }
+        HIPCHK(hipMemcpyAsync(dst[i], src, c->streams[(size_t)streams[i]].pic_bytes, hipMemcpyDeviceToHost, c->read_stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->read_stream));
+    return HVQ_OK;
+}
+
+/* device address of a resident picture (Y|U|V, hvq_stream_pic_bytes) for consumers on the GPU; valid until the stream's ring
+ * hands the slot to a later picture (nslots pictures later at the earliest).  Work queued by the caller must be ordered after
+ * hvq_sync(), or after the event the caller records behind it. */
+HVQ_EXPORT int hvq_picture_device_ptr(HvqContext *c, int sid, int ordinal, const void **ptr)
+{
+    if (!c || !ptr) return fail(HVQ_E_ARG, "bad arguments");
+    { int rc = flush_end(c); if (rc) return rc; }
+    int rc = HVQ_OK;
+    *ptr = resident_picture(c, sid, ordinal, &rc);
+    return rc;
 }
 
 HVQ_EXPORT int hvq_rgb_bench(HvqContext *c, int reps, float *gpu_ms, uint64_t *bytes_per_rep, uint32_t *pictures)
@@ -1462,7 +1626,9 @@ void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, con
     for (int i = 0; i < 3; ++i) if (i != used[0] && i != used[1] && (dst < 0 || b->host[i] == present)) dst = i;
     s.ring = dst;                                        /* alloc_slot takes the first slot from here that is no anchor */
     b->valid[dst] = false;
+    s.sdk_present = ftype == HVQ_FRAME_P ? present : nullptr;   /* a self-referencing P picture reads the caller's buffer (h4m:2058-2061) */
     int ord = hvq_stream_submit(c, b->stream, ftype, frame, len);
+    c->streams[(size_t)b->stream].sdk_present = nullptr;
     if (ord < 0) { sdk_fail(ord); return; }
     int rc = hvq_flush(c);
     if (rc) { sdk_fail(rc); return; }

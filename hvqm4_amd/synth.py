@@ -76,6 +76,9 @@ class SynthConfig:
     literal_weight: float = 1.0
     usec_per_frame: int = 33366
     sampling: str = "420"             # "420" (h_samp = v_samp = 2) | "444" (1, 1: four chroma blocks per macroblock)
+    long_escape: int = 0              # I pictures: one luma DC delta written as this many overflow symbols (h4m:654-664 sums
+                                      # for as long as the stream says) -- legal by format, far beyond what an encoder emits
+    long_escape_pb: int = 0           # P/B pictures: the first intra DC delta written as this many overflow symbols
 
 
 class _Ops:
@@ -388,6 +391,8 @@ class _Gen:
                     t = self._delta()
                     if t == 0:
                         t = 1
+                    if self.cfg.long_escape and p == 0 and i == n // 2:
+                        t = 127 * (self.cfg.long_escape - 1) + 5          # long_escape symbols: 127, 127, ..., 5
                     for lf in _sovf_leaves(t):
                         pic.ops[DC0 + p].leaf(lf)
                     i += 1
@@ -550,6 +555,9 @@ class _Gen:
                 for p, cnt in ((0, 4), (1, nc), (2, nc)):
                     for _ in range(cnt):
                         d = self._delta() if rng.random() > self.p_dc_zero else 0
+                        if self.cfg.long_escape_pb and not getattr(pic, "_long_done", False):
+                            d = 127 * (self.cfg.long_escape_pb - 1) + 5
+                            pic._long_done = True
                         for lf in _sovf_leaves(d):
                             pic.ops[DC0 + p].leaf(lf)
             elif procs[m] == 1:

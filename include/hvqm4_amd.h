@@ -104,9 +104,21 @@ int  hvq_replay(HvqContext *ctx, int reps, float *gpu_ms);
 int  hvq_read_picture(HvqContext *ctx, int stream, int ordinal, void *dst, size_t cap);
 uint32_t hvq_stream_pic_bytes(HvqContext *ctx, int stream);
 
+/* Bulk readback for the throughput path: `n` resident pictures to host memory, all copies queued on a stream of their own behind
+ * the reconstruction, ONE synchronisation.  dst[i] receives hvq_stream_pic_bytes() bytes; pinned destinations
+ * (hvq_pinned_alloc) make the copies asynchronous DMA. */
+int  hvq_read_pictures(HvqContext *ctx, int n, const int *streams, const int *ordinals, void *const *dst);
+void *hvq_pinned_alloc(size_t bytes);
+void hvq_pinned_free(void *p);
+/* Device address of a resident picture for consumers on the GPU (valid until the stream's ring reuses the slot, `nslots`
+ * pictures later at the earliest); order the consumer after hvq_sync(). */
+int  hvq_picture_device_ptr(HvqContext *ctx, int stream, int ordinal, const void **ptr);
+
 /* Display epilogue of the reference player (dumpRGB, h4m:897-926) on the GPU: converts a resident 4:2:0
  * picture to interleaved RGB24 (w*h*3 bytes, float math identical to the reference) and copies it to host. */
 int  hvq_read_picture_rgb(HvqContext *ctx, int stream, int ordinal, void *dst, size_t cap);
+/* The same conversion for a picture in host memory (Y|U|V 4:2:0, width a multiple of 4, height even): upload, convert, download. */
+int  hvq_convert_yuv420_rgb(HvqContext *ctx, const void *yuv, int width, int height, void *rgb);
 /* Measurement helper: converts the newest resident picture of every open 4:2:0 stream in ONE launch, `reps`
  * times, timed with HIP events on the launch stream.  bytes_per_rep = 1.5 B/px read + 3 B/px written. */
 int  hvq_rgb_bench(HvqContext *ctx, int reps, float *gpu_ms, uint64_t *bytes_per_rep, uint32_t *pictures);

@@ -11,6 +11,7 @@
  * h4m:679-817, 1358-1420, motion compensation h4m:1242-1294, 1327-1355.
  */
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "hvq_desc.h"
@@ -99,6 +100,20 @@ API int hvqd_recon(const uint8_t *blob, uint8_t *dst, const uint8_t *ref0, const
     const int16_t *mvs = h->mv_off ? (const int16_t *)(blob + h->mv_off) : NULL;
     int is_pb = h->pic_kind != HVQ_PIC_I, is15 = (h->flags & HVQ_F_IS15) != 0;
     int lw = h->width;
+    /* A P picture with future-referencing (type 2) macroblocks (HVQ_F_SELF_REF): `ref1` is the picture being written
+     * (h4m:2058-2061).  Specification of what the back end does: every other macroblock is reconstructed as usual, but into a
+     * side buffer; then the macroblocks are walked in raster order like BpicPlaneDec (h4m:1919-1967) -- finished ones move from
+     * the side buffer into `dst` (which holds the buffer's previous content), type-2 ones are computed from `dst` as it is at
+     * that moment, block by block (TL, BL, BR, TR, then U, then V), sample by sample where the reference copies in place. */
+    const int selfref = h->pic_kind == HVQ_PIC_P && (h->flags & HVQ_F_SELF_REF);
+    uint8_t *const real_dst = dst;
+    uint8_t *side = NULL;
+    uint32_t *boff[3] = { NULL, NULL, NULL };
+    if (selfref) {
+        side = calloc(1, slot_bytes);
+        for (int p = 0; p < 3; ++p) boff[p] = malloc(sizeof(uint32_t) * ((size_t)h->hb[p] * h->vb[p] + 1));
+        dst = side;
+    }
     for (int p = 0; p < 3; ++p) {
         int hb = h->hb[p], vb = h->vb[p], stride = hb + 2;
         int ws = p ? h->wshift : 0, hs = p ? h->hshift : 0;
@@ -114,9 +129,11 @@ API int hvqd_recon(const uint8_t *blob, uint8_t *dst, const uint8_t *ref0, const
             int I_luma = !is_pb && p == 0;
             uint32_t n = hvq_payload_dwords(T, is_pb, I_luma);
             const uint32_t *pay = pool + off;
+            if (selfref) boff[p][b] = off;
             off += n;
             uint8_t out[16];
             int inter = is_pb && (T & 0x60);
+            if (selfref && ((T >> 5) & 3) == 2) continue;       /* done by the raster-order walk below */
             uint32_t kind = I_luma ? T : (T & 0xF);
             if (!inter) {
                 if (kind == 0) {
@@ -168,6 +185,71 @@ API int hvqd_recon(const uint8_t *blob, uint8_t *dst, const uint8_t *ref0, const
             }
             for (int y = 0; y < 4; ++y) memcpy(plane + (size_t)(by * 4 + y) * pw + bx * 4, out + 4 * y, 4);
         }
+    }
+    if (selfref) {
+        uint8_t *pic = real_dst;
+        const int mw = (int)h->mcb_w, mh = (int)h->mcb_h;
+        for (int my = 0; my < mh; ++my)
+            for (int mx = 0; mx < mw; ++mx) {
+                const uint32_t T = (blob + h->map_off[0])[2 * ((2 * my + 1) * (h->hb[0] + 2) + 2 * mx + 1) + 1];
+                if (((T >> 5) & 3) != 2) {
+                    for (int p = 0; p < 3; ++p) {
+                        const int ws = p ? h->wshift : 0, hs = p ? h->hshift : 0, pw = h->width >> ws, bw = 8 >> ws, bh = 8 >> hs;
+                        for (int r = 0; r < bh; ++r) {
+                            const size_t o = h->plane_off[p] + (size_t)(my * bh + r) * pw + (size_t)mx * bw;
+                            memcpy(pic + o, side + o, (size_t)bw);
+                        }
+                    }
+                    continue;
+                }
+                const int32_t rx = mvs[2 * (my * mw + mx)], ry = mvs[2 * (my * mw + mx) + 1];
+                const int proc = (T >> 4) & 1;
+                const int64_t origin = (h->flags & HVQ_F_LANDSCAPE) ? (int64_t)(rx / 2) + (int64_t)(ry / 2 - 16) * lw - 32
+                                                                    : (int64_t)(rx / 2) + (int64_t)(ry / 2 - 32) * lw - 16;
+                for (int p = 0; p < 3; ++p) {
+                    const int ws = p ? h->wshift : 0, hs = p ? h->hshift : 0, pw = h->width >> ws;
+                    const int bxp = 2 >> ws, byp = 2 >> hs, nblk = bxp * byp, hb = h->hb[p];
+                    const int32_t pdx = rx >> ws, pdy = ry >> hs;
+                    const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
+                    for (int j = 0; j < nblk; ++j) {
+                        const int dx = nblk == 1 ? 0 : (j >> 1), dy = nblk == 1 ? 0 : ((j == 1 || j == 2) ? 1 : 0);
+                        const int bx = mx * bxp + dx, by = my * byp + dy;
+                        uint8_t *d = pic + h->plane_off[p] + (size_t)by * 4 * pw + (size_t)bx * 4;
+                        const int64_t a = (int64_t)h->plane_off[p] + (int64_t)(pdy >> 1) * pw + (pdx >> 1) + (int64_t)dy * 4 * pw + dx * 4;
+                        const uint32_t kind = (blob + h->map_off[p])[2 * ((by + 1) * (hb + 2) + bx + 1) + 1] & 0xF;
+                        const uint32_t *pay = pool + boff[p][by * hb + bx];
+                        if (!proc && kind == 6) {
+                            for (int y = 0; y < 4; ++y) memcpy(d + (size_t)y * pw, (const uint8_t *)pay + 4 * y, 4);
+                        } else if (proc || kind == 0) {
+                            /* _MotionComp in place: every sample is read when it is needed (h4m:1242-1279) */
+                            for (int y = 0; y < 4; ++y)
+                                for (int x = 0; x < 4; ++x) {
+                                    const int64_t sa = a + (int64_t)y * pw + x;
+                                    const int p00 = ref_px(pic, sa, slot_bytes), p01 = ref_px(pic, sa + 1, slot_bytes);
+                                    const int p10 = ref_px(pic, sa + pw, slot_bytes), p11 = ref_px(pic, sa + pw + 1, slot_bytes);
+                                    d[(size_t)y * pw + x] = (uint8_t)(!hx && !hy ? p00 : hx && !hy ? (p00 + p01 + 1) / 2
+                                                                      : !hx ? (p00 + p10 + 1) / 2 : (p00 + p01 + p10 + p11 + 2) >> 2);
+                                }
+                        } else {
+                            uint32_t acc[16];
+                            const uint32_t mean_aot = (uint32_t)aot(&c, pay + 2, kind - 1, pic, origin, lw, 1, acc);
+                            uint8_t m[16];
+                            mc16(&c, pic, a, pw, hx, hy, m);
+                            int32_t sum = 8, lo = 255, hi = 0;
+                            for (int i = 0; i < 16; ++i) { sum += m[i]; if (m[i] < lo) lo = m[i]; if (m[i] > hi) hi = m[i]; }
+                            const int32_t mean = sum / 16, range = hi - lo;
+                            const uint32_t addend = pay[0] - mean_aot;
+                            const uint32_t factor = pay[1] * (uint32_t)(range ? 0x1000 / range : 0);
+                            for (int i = 0; i < 16; ++i) {
+                                const uint32_t r = acc[i] + addend + (uint32_t)((int32_t)m[i] - mean) * factor;
+                                d[(size_t)(i >> 2) * pw + (i & 3)] = clamp255(((int32_t)r >> h->unk_shift) + m[i]);
+                            }
+                        }
+                    }
+                }
+            }
+        free(side);
+        for (int p = 0; p < 3; ++p) free(boff[p]);
     }
     return 0;
 }

@@ -26,6 +26,15 @@ SMALL = [
     ("yuv444_296x160", SynthConfig(width=296, height=160, gop="IPB", seed=20, sampling="444", weird_kinds=True)),
     # fills the last cells of tests/test_fixture_coverage.py: inter kind 8 in a chroma plane, past (P) and future (B)
     ("weird160x128", SynthConfig(width=160, height=128, gop="IPPBBPBB", seed=34, weird_kinds=True)),
+    # one DC delta of 300 overflow symbols (the reference sums for as long as the stream says, h4m:654-664): decoded like the
+    # reference; beyond the parsers' cap (4096 symbols) a picture is refused, never decoded differently (tests/test_gpu_reject.py)
+    ("longescape64x48", SynthConfig(width=64, height=48, gop="IPB", seed=35, long_escape=300)),
+    # P pictures with future-referencing (type 2) macroblocks: the reference passes the picture being written as `future`
+    # (h4m:2058-2061), so they read it in raster-order-dependent states and, where nothing has been written yet, what the player's
+    # third buffer held before: nothing (first P), the last B picture (P after B), the picture of three anchors ago (P after P)
+    ("pselfref64x48_15", SynthConfig(width=64, height=48, gop="IPBBPBPP", seed=36, p_future_refs=True)),
+    ("pselfref64x48_13", SynthConfig(width=64, height=48, gop="IPPPBP", seed=37, p_future_refs=True, version="1.3")),
+    ("pselfref444_48x64", SynthConfig(width=48, height=64, gop="IPBPP", seed=38, p_future_refs=True, sampling="444")),
 ]
 
 MEDIUM = [
@@ -37,6 +46,7 @@ MEDIUM = [
     # map flat (h4m:1169), so it reads border values and the next row's first entries -- deterministic, reproduced exactly
     ("nest_border1_320x240", SynthConfig(width=320, height=240, gop="IPB", seed=24, nest_overhang=1)),
     ("nest_border2_296x160", SynthConfig(width=296, height=160, gop="IPB", seed=25, nest_overhang=2)),
+    ("pselfref320x240", SynthConfig(width=320, height=240, gop="IPBBPBBP", seed=39, p_future_refs=True)),
 ]
 
 # config C4 -- the per-GPU share at 8 GPUs: clips 0, 8, ..., 56 of the 64 (4 x 320x240 + 4 x 640x480, HVQM4 1.3

@@ -1,9 +1,10 @@
 """GPU: pictures this back end refuses and what a refusal leaves behind.
 
-* A P picture with a future-referencing (type 2) macroblock: the reference aliases `future` to the picture being
-  written (h4m:2058-2061, read at h4m:1941-1949), a raster-order dependency a data-parallel reconstruction cannot
-  reproduce.  Every entry point reports HVQ_E_UNSUPPORTED instead of decoding something else, `present` stays
-  untouched, the stream resumes at its next I picture.
+* A picture with an overflow-symbol run beyond the parsers' cap (4096 symbols; the reference sums for as long as the stream
+  says, h4m:654-677): HVQ_F_CAPPED -- the value would differ from the reference's.  Every entry point reports
+  HVQ_E_UNSUPPORTED instead of decoding something else, `present` stays untouched, the stream resumes at its next I picture.
+  (A 300-symbol run decodes exactly: tests/clips.py longescape64x48.  P pictures with future-referencing macroblocks,
+  refused in round 2, are decoded like the reference now: tests/clips.py pselfref*.)
 * One bad picture must not poison the batch: the other streams of the same flush decode bit-exactly."""
 import numpy as np
 import pytest
@@ -14,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _self_ref_clip(seed=5, w=64, h=48, gop="IPBBPB"):
+    """a clip whose SECOND picture (the first P) carries an overflow-symbol run of 5000 symbols: over the cap"""
     from hvqm4_amd.synth import SynthConfig, make_clip
-    return make_clip(SynthConfig(width=w, height=h, gop=gop, seed=seed, p_future_refs=True))
+    return make_clip(SynthConfig(width=w, height=h, gop=gop, seed=seed, long_escape_pb=5000))
 
 
 def _pics(cl):
@@ -23,7 +25,7 @@ def _pics(cl):
     return [(ft, bytes(p)) for ft, _d, p in video_pictures(cl.data)]
 
 
-def test_host_parsed_self_referencing_P_picture_is_refused_and_the_stream_resumes_at_an_I_picture(gpu_ctx):
+def test_host_parsed_capped_picture_is_refused_and_the_stream_resumes_at_an_I_picture(gpu_ctx):
     from hvqm4_amd._lib import HVQ_E_STATE, HVQ_E_UNSUPPORTED, HvqError
     from oracle import bridge
     bad = _self_ref_clip()
@@ -33,8 +35,8 @@ def test_host_parsed_self_referencing_P_picture_is_refused_and_the_stream_resume
     sg = gpu_ctx.open_stream(good.width, good.height, 2, 2, True, len(gp) + 3)
     gpu_ctx.submit(sb, *bp[0])                                   # the I picture is fine
     with pytest.raises(HvqError) as e:
-        gpu_ctx.submit(sb, *bp[1])                               # P with type-2 macroblocks
-    assert e.value.code == HVQ_E_UNSUPPORTED and "future-referencing" in str(e.value)
+        gpu_ctx.submit(sb, *bp[1])                               # P with an overflow run over the cap
+    assert e.value.code == HVQ_E_UNSUPPORTED and "overflow-symbol" in str(e.value)
     with pytest.raises(HvqError) as e:
         gpu_ctx.submit(sb, *bp[2])                               # the B picture would reference the refused P
     assert e.value.code == HVQ_E_STATE
@@ -60,7 +62,7 @@ def test_host_parsed_self_referencing_P_picture_is_refused_and_the_stream_resume
     gpu_ctx.close_stream(sb); gpu_ctx.close_stream(sg)
 
 
-@pytest.mark.parametrize("what", ["self_ref", "bad_tree"])
+@pytest.mark.parametrize("what", ["capped", "bad_tree"])
 def test_one_refused_picture_does_not_poison_the_other_streams_of_a_gpu_parsed_batch(gpu_ctx, what):
     import struct
     from hvqm4_amd._lib import HVQ_E_STATE, HVQ_E_UNSUPPORTED, HvqError
@@ -85,7 +87,7 @@ def test_one_refused_picture_does_not_poison_the_other_streams_of_a_gpu_parsed_b
     gpu_ctx.submit_many_device(sids, fts, data)
     with pytest.raises(HvqError) as e:
         gpu_ctx.flush()
-    if what == "self_ref":
+    if what == "capped":
         assert e.value.code == HVQ_E_UNSUPPORTED
     assert f"stream {sb} picture 1" in str(e.value)
     gpu_ctx.sync()

@@ -54,7 +54,8 @@ def test_parse_plus_descriptor_spec_matches_oracle(case):
     want = bridge.oracle_decode(clip.data, clip.n_pictures)
     got, flags = decode_via_descriptors(clip)
     assert np.array_equal(got, want)
-    assert not flags & 0x28, "legal streams must not be flagged SELF_REF / CLAMPED"
+    assert not flags & 0x60, "legal streams must not be flagged CLAMPED / CAPPED"
+    assert bool(flags & 0x08) == case[0].startswith("pselfref"), "SELF_REF: exactly the P pictures with future-referencing macroblocks"
 
 
 def test_big_aot_flag_only_for_weird_streams():
