@@ -60,7 +60,7 @@ class HvqStats(C.Structure):
     _fields_ = [("pictures", C.c_uint64), ("luma_pixels", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("descriptor_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32),
                 ("parse_seconds", C.c_double), ("flags_or", C.c_uint32), ("gpu_parsed", C.c_uint32),
-                ("gpu_parse_ms", C.c_double), ("gpu_parse_retried", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("gpu_parse_ms", C.c_double), ("gpu_parse_retried", C.c_uint32), ("dropped", C.c_uint32)]
 
 
 # every symbol include/hvqm4.h and include/hvqm4_amd.h declare: (restype, argtypes)

@@ -1046,6 +1046,7 @@ static int flush_end(HvqContext *c)
      * reconstructed as if it had not been there.  The dropped pictures read as "not resident", the stream waits for its next
      * I picture, and the flush reports the first such error after everything else has been launched. */
     int first_rc = HVQ_OK;
+    uint32_t n_dropped = 0;
     {
         std::vector<char> broken(c->streams.size(), 0);
         for (size_t i = 0; i < c->fl_pending.size(); ++i) {
@@ -1053,11 +1054,11 @@ static int flush_end(HvqContext *c)
             Stream &s = c->streams[(size_t)p.stream];
             const char *why = nullptr;
             int code = HVQ_OK;
-            if (!broken[(size_t)p.stream] && p.dev) {
+            if ((!broken[(size_t)p.stream] || p.kind == HVQ_PIC_I) && !p.dropped && p.dev) {
                 if (p.status) { code = (p.status & GP_ST_OVERFLOW) ? HVQ_E_OVERFLOW : HVQ_E_ARG; why = "the GPU parser rejected the bitstream"; }
                 else if ((why = unsupported_reason(p.flags)) != nullptr) code = HVQ_E_UNSUPPORTED;
             }
-            if (!broken[(size_t)p.stream] && !code && p.kind == HVQ_PIC_P && p.old_slot == -2 && !p.host_old) {
+            if (!broken[(size_t)p.stream] && !p.dropped && !code && p.kind == HVQ_PIC_P && p.old_slot == -2 && !p.host_old) {
                 const uint32_t fl = p.dev ? p.flags : ((const HvqPicHeader *)(c->fl_host + p.blob_off))->flags;
                 if (fl & HVQ_F_SELF_REF) {
                     code = HVQ_E_UNSUPPORTED;
@@ -1070,8 +1071,12 @@ static int flush_end(HvqContext *c)
                 if (!first_rc) first_rc = fail(code, "stream %d picture %d: %s (status %d); dropped with the later pictures of this stream, "
                                                "the other streams of the batch were decoded", p.stream, p.ordinal, why, p.status);
             }
-            if (!broken[(size_t)p.stream]) continue;
+            if (p.kind == HVQ_PIC_I && !code) broken[(size_t)p.stream] = 0;     /* an I picture restarts its stream inside the batch */
+            /* dropped: follows a rejected picture of its stream in this batch, or was marked when the batch before this one was
+             * judged (streaming: it was queued already).  Either way it is not reconstructed and must not read as resident. */
+            if (!broken[(size_t)p.stream] && !p.dropped) continue;
             p.dropped = true;
+            ++n_dropped;
             if ((size_t)p.ordinal < s.pic_slot.size() && s.pic_slot[(size_t)p.ordinal] == p.dst) {
                 s.pic_slot[(size_t)p.ordinal] = -1;
                 if (s.slots[(size_t)p.dst].pic == p.ordinal) s.slots[(size_t)p.dst].pic = -1;
@@ -1080,10 +1085,15 @@ static int flush_end(HvqContext *c)
         for (size_t sid = 0; sid < broken.size(); ++sid)
             if (broken[sid]) {
                 Stream &s = c->streams[sid];
-                s.anchor_old = s.anchor_new = -1;
-                s.need_I = true;
-                for (auto &q : c->pending)                  /* already queued for the next batch: they follow the rejected picture */
-                    if (q.stream == (int)sid && q.kind != HVQ_PIC_I) q.dropped = true;
+                /* what is already queued for the next batch follows the rejected picture: P/B pictures up to the first queued
+                 * I picture are dropped; with an I picture queued the stream has restarted there and keeps its state */
+                bool restarted = false;
+                for (auto &q : c->pending) {
+                    if (q.stream != (int)sid) continue;
+                    if (q.kind == HVQ_PIC_I) { restarted = true; break; }
+                    q.dropped = true;
+                }
+                if (!restarted) { s.anchor_old = s.anchor_new = -1; s.need_I = true; }
             }
         /* nests of broken streams are not committed (their last I picture may be among the dropped) */
         std::vector<uint64_t> keep;
@@ -1209,6 +1219,7 @@ static int flush_end(HvqContext *c)
     st.parse_seconds = c->parse_seconds;
     st.gpu_parse_ms = st.gpu_parsed ? c->gpu_parse_ms : 0.0;
     st.gpu_parse_retried = st.gpu_parsed ? c->gpu_parse_retried : 0u;
+    st.dropped = n_dropped;
     if (jobs.size() > c->jobs_cap) {
         if (c->jobs_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->jobs_dev)); }
         c->jobs_cap = jobs.size() * 2;

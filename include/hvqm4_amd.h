@@ -54,7 +54,7 @@ typedef struct HvqStats {
     double   gpu_parse_ms;      /* device time of that parse launch (HIP events) */
     uint32_t gpu_parse_retried; /* of those, pictures the flat parse path handed to the chain decoder (unusual section layout,
                                    capacities, overflow groups at the caps) -- same result, slower */
-    uint32_t reserved0;
+    uint32_t dropped;           /* pictures of the batch that were not reconstructed: rejected, or behind a rejected picture of their stream */
 } HvqStats;
 
 int  hvq_context_create(int device, HvqContext **out);

@@ -158,3 +158,42 @@ def test_clamped_nest_origin_is_refused_unless_opted_in(gpu_ctx, monkeypatch):
     assert gpu_ctx.read_picture(sid, o).size == 320 * 240 * 3 // 2
     assert gpu_ctx.stats().flags_or & 0x20
     gpu_ctx.close_stream(sid)
+
+
+def test_rejection_while_the_next_batch_of_the_stream_is_already_queued(gpu_ctx):
+    """Streaming: batch N is judged in hvq_flush_end when batch N+1 is queued already.  The P/B pictures of the rejected stream
+    in N+1 follow the rejected picture: they are dropped -- and must read as NOT resident, not as whatever their slot held --
+    up to the stream's next I picture, which restarts it without any HVQ_E_STATE in between."""
+    from hvqm4_amd._lib import HVQ_E_STATE, HVQ_E_UNSUPPORTED, HvqError
+    from oracle import bridge
+    bad = _self_ref_clip(seed=21, gop="IPBB")                     # picture 1 (P) is over the cap
+    good = clips.get(clips.SMALL[3])                             # 64x48 1.5, IPBBPBB
+    bp, gp = _pics(bad), _pics(good)
+    sb = gpu_ctx.open_stream(bad.width, bad.height, 2, 2, True, 12)
+    so = gpu_ctx.open_stream(good.width, good.height, 2, 2, True, 12)
+    # batch N: the bad clip's I and P on sb, the good clip's first two pictures on so
+    gpu_ctx.submit_many_device([sb, so, sb, so], [bp[0][0], gp[0][0], bp[1][0], gp[1][0]], [bp[0][1], gp[0][1], bp[1][1], gp[1][1]])
+    gpu_ctx.flush_begin()
+    # batch N+1, queued before N is judged: two more B pictures of the bad clip, then a whole good clip on the same stream
+    o_b = gpu_ctx.submit_many_device([sb, sb], [bp[2][0], bp[3][0]], [bp[2][1], bp[3][1]])
+    o_g = gpu_ctx.submit_many_device([sb] * len(gp), [p[0] for p in gp], [p[1] for p in gp])
+    o_o = gpu_ctx.submit_many_device([so] * (len(gp) - 2), [p[0] for p in gp[2:]], [p[1] for p in gp[2:]])
+    with pytest.raises(HvqError) as e:
+        gpu_ctx.flush_end()
+    assert e.value.code == HVQ_E_UNSUPPORTED and f"stream {sb} picture 1" in str(e.value)
+    gpu_ctx.flush()                                              # batch N+1: no error of its own
+    assert gpu_ctx.stats().dropped == 2
+    for o in o_b:                                                # the B pictures behind the rejected P: not resident
+        with pytest.raises(HvqError) as e2:
+            gpu_ctx.read_picture(sb, o)
+        assert e2.value.code == HVQ_E_STATE
+    want = bridge.oracle_decode(good.data, good.n_pictures)
+    for k, o in enumerate(o_g):                                  # the stream restarted at the queued I picture
+        assert np.array_equal(gpu_ctx.read_picture(sb, o), want[k]), k
+    for k in range(2):
+        assert np.array_equal(gpu_ctx.read_picture(so, k), want[k])
+    for k, o in enumerate(o_o):
+        assert np.array_equal(gpu_ctx.read_picture(so, o), want[k + 2])
+    gpu_ctx.submit_many_device([sb], [gp[1][0]], [gp[1][1]])     # and takes P pictures again without an I picture first
+    gpu_ctx.flush()
+    gpu_ctx.close_stream(sb); gpu_ctx.close_stream(so)
