@@ -86,8 +86,6 @@ def launch_ranks(n: int, argv, child=None) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        if os.environ.get("HVQM4_BENCH_SHARE_GPU"):
-            env.setdefault("HVQM4_DIST_BACKEND", "gloo")     # RCCL refuses two ranks on one device
         procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=out0 if r == 0 else sys.stderr))
     rc = 0
     try:
@@ -161,6 +159,29 @@ def host_cores() -> int:
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
+def cpu_quota():
+    """CPU limit of this container's cgroup in cores (cgroup v2 cpu.max), None when unlimited or unknown"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:
+        return None
+
+
+def pin_rank(local_rank: int, local_world: int):
+    """One rank per GPU on a shared host (the scaling risk is host-side): every rank takes its own slice of the
+    cores the process may use -- its copy threads (which inherit the mask) then never compete with another rank's -- and
+    min(8, slice) copy threads.  Returns (copy threads, cores of the slice) for the result line."""
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    per = max(1, len(cores) // max(1, local_world))
+    mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+    if local_world > 1 and hasattr(os, "sched_setaffinity"):
+        os.sched_setaffinity(0, mine)
+    threads = int(os.environ.get("HVQM4_AMD_COPY_THREADS", "0")) or max(1, min(8, len(mine)))
+    os.environ["HVQM4_AMD_COPY_THREADS"] = str(threads)
+    return threads, mine
+
+
 # ---------------------------------------------------------------------------------------------- one rank
 def main():
     args = parse_args()
@@ -181,7 +202,8 @@ def main():
 
     mv_bits = tuple(int(x) for x in args.mv_bits.split(","))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    workers = args.gen_workers or max(1, host_cores() // max(1, local_world))
+    copy_threads, my_cores = pin_rank(local_rank % max(1, local_world), local_world)
+    workers = args.gen_workers or max(1, host_cores())          # after pin_rank: the cores of this rank's slice
 
     # ---- synthetic inputs (fixed seeds) ----
     t0 = time.time()
@@ -338,6 +360,56 @@ def main():
         px = int(st.luma_pixels)
         one = px / min(t_pass[1:]) / 1e6
         stream_v = px / t_pipe / 1e6
+        # the same streaming loop with EVERY picture brought back to (pinned) host memory: hvq_read_pictures of batch k runs
+        # beside the parse of batch k + 1 (one synchronisation per batch).  PCIe-bound; never `value`.
+        rb = None
+        try:
+            n_seq0 = len(pics[stream_clip[0]])
+            if all(len(pics[stream_clip[s]]) == n_seq0 for s in range(len(sids))) and len({clips[ci].picsize for ci in stream_clip}) == 1:
+                ctx3 = batch.Context(device)
+                sids3 = [ctx3.open_stream(clips[ci].width, clips[ci].height, 2, 2, clips[ci].version == "1.5", 2 * n_seq0 + 4)
+                         for ci in stream_clip]
+                a_sid3 = [sids3[s] for s in a_stream]
+                host = ctx3.pinned_array((len(a_sid3), ctx3.pic_bytes(sids3[0])))
+                k_of = []                                   # ordinal of entry i inside its stream's batch
+                seen = {}
+                for s in a_stream:
+                    k_of.append(seen.get(s, 0)); seen[s] = k_of[-1] + 1
+                nb3, nwarm3 = 6, 2
+                barrier(); ctx3.sync()
+                ctx3.submit_many_device(a_sid3, a_ft, a_raw)
+                ctx3.flush_begin()
+                t_done = []
+                for b in range(nb3 + nwarm3):
+                    last = b == nb3 + nwarm3 - 1
+                    if not last:
+                        ctx3.submit_many_device(a_sid3, a_ft, a_raw)
+                    ctx3.flush_end()
+                    if not last:
+                        ctx3.flush_begin()
+                    ctx3.read_pictures(a_sid3, [b * n_seq0 + k for k in k_of], out=host)
+                    t_done.append(time.perf_counter())
+                t_rb = (t_done[-1] - t_done[nwarm3 - 1]) / nb3
+                # what came back is the picture the resident-descriptor pass decoded
+                chk = 0
+                for i in range(0, len(a_sid3), max(1, len(a_sid3) // 16)):
+                    try:
+                        want = ctx.read_picture(sids[a_stream[i]], k_of[i])
+                    except HvqError as e:
+                        if e.code != HVQ_E_STATE:
+                            raise
+                        continue
+                    if not np.array_equal(host[i], want):
+                        raise SystemExit(f"PARITY FAILURE: bulk readback entry {i} differs")
+                    chk += 1
+                rb_v = px / t_rb / 1e6
+                rb = {"value": round(grp.sum(rb_v), 1), "unit": "Mpixels/s", "ms_per_batch": round(t_rb * 1e3, 2),
+                      "d2h_GBs": round(host.nbytes / t_rb / 1e9, 2), "pictures_checked": chk,
+                      "what": "streaming as above with every picture copied to pinned host memory (hvq_read_pictures of batch k beside "
+                              "the parse of batch k + 1); bounded by PCIe, 1.5 B per pixel"}
+                ctx3.close()
+        except MemoryError as e:
+            rb = {"error": str(e)}
         gpu_e2e = {"value": round(grp.sum(one), 1), "unit": "Mpixels/s",
                    "streaming_value": round(grp.sum(stream_v), 1),
                    "streaming_value_min_rank": round(-grp.max(-stream_v), 1),
@@ -347,8 +419,11 @@ def main():
                    "streaming_parse_kernel_ms": round(parse_ms_streaming, 3),
                    "parse_kernel_ms": round(min(parse_ms[1:]), 3), "pass_ms": [round(t * 1e3, 2) for t in t_pass],
                    "submit_flush_sync_ms": t_split,
-                   "host_copy_threads": int(os.environ.get("HVQM4_AMD_COPY_THREADS", "8" if (os.cpu_count() or 1) >= 16 else "4")),
+                   "host_copy_threads": copy_threads,
+                   "affinity": {"cores_of_rank0": len(my_cores), "first": my_cores[0], "last": my_cores[-1], "ranks_on_host": local_world,
+                                "pinned": local_world > 1},
                    "pictures_checked_against_host_parsed": ok,
+                   "streaming_with_readback": rb,
                    "what": "raw bitstreams in host memory -> H2D -> entropy parse kernel (one workgroup per picture) -> "
                            "reconstruction launches -> pictures in HBM; no host entropy parse; all ranks at once (sum over ranks, "
                            "per-rank min and max of the streaming rate; the per-rank detail fields are rank 0's).  value: one "
@@ -506,22 +581,27 @@ def cpu_baseline(budget_s: float, c3_clip, preset: str):
     c2 = make_clip(SynthConfig(width=320, height=240, version="1.5", gop="I", n_gops=16, seed=2, preset=preset))
     c3 = c3_clip or make_clip(SynthConfig(width=640, height=480, version="1.5", gop=GOP16, seed=1000, preset=preset))
     res = {"C1": one_core(c1), "C2": one_core(c2), "C3": one_core(c3)}
-    # all cores: C4 clips 0..15 (8 x 320x240 + 8 x 640x480, both versions), one GOP each, one process per clip
+    # all cores (SURVEY.md 8d ii): ALL 64 clips of C4 (32 x 320x240 + 32 x 640x480, both versions), one GOP each, one process
+    # per clip over min(nproc, 64) processes.  nproc = cores this process may run on; the container's CPU quota (cgroup cpu.max)
+    # is reported beside it -- the box gives a 1-GPU job a share of the host, so "all cores" is that share, not the host's 256.
     cores = host_cores()
-    cfgs = [c4_clip_config(i, preset, 1) for i in range(16)]
+    nproc = min(cores, 64)
+    cfgs = [c4_clip_config(i, preset, 1) for i in range(64)]
     sample = gen_clips(cfgs, cores)
-    t1, _ = timer(sample[-1].data, 1)
-    reps = max(1, int(2.0 * per / max(t1 * max(1.0, 16.0 / cores), 1e-6)))
+    t1, _ = timer(sample[-1].data, 1)                    # a 640x480 clip, the slow kind
+    waves = (64 + nproc - 1) // nproc
+    reps = max(1, int(2.0 * per / max(t1 * waves, 1e-6)))
     import multiprocessing as mp
     t0 = time.perf_counter()
-    with mp.get_context("spawn").Pool(min(cores, 16)) as pool:
+    with mp.get_context("spawn").Pool(nproc) as pool:
         t_start = time.perf_counter()
         r = pool.map(_time_clip_worker, [(c.data, reps) for c in sample], chunksize=1)
         t_all = time.perf_counter() - t_start
     px_all = sum(px for _t, px in r)
-    res["all_cores_C4"] = {"value": round(px_all / t_all / 1e6, 1), "unit": "Mpixels/s", "cores": min(cores, 16), "nproc": cores,
-                           "sample": f"C4 clips 0..15 (8 x 320x240 + 8 x 640x480, HVQM4 1.3/1.5 alternating, one 16-picture GOP each), "
-                                     f"{reps} passes per clip, one process per clip over {min(cores, 16)} processes "
+    res["all_cores_C4"] = {"value": round(px_all / t_all / 1e6, 1), "unit": "Mpixels/s", "cores": nproc, "nproc": cores,
+                           "processes": nproc, "cgroup_cpu_quota_cores": cpu_quota(), "host_logical_cpus": os.cpu_count(),
+                           "sample": f"all 64 C4 clips (32 x 320x240 + 32 x 640x480, HVQM4 1.3/1.5 alternating, one 16-picture GOP each), "
+                                     f"{reps} passes per clip, one process per clip over {nproc} processes "
                                      f"(wall time of the pool map {t_all:.1f} s, process start-up {t_start - t0:.1f} s excluded)"}
     info = {}
     try:

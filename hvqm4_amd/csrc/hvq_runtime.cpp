@@ -134,6 +134,7 @@ struct Stream {
      * a P picture with future-referencing macroblocks reads what `present` held before (h4m:2058-2061) */
     int rp_past = -1, rp_future = -1, rp_present = -1;
     const void *sdk_present = nullptr;       /* SDK path: the caller's `present` buffer of the picture being submitted */
+    int inflight_from = 0x7FFFFFFF;          /* ordinals >= this belong to the batch between hvq_flush_begin and hvq_flush_end */
     uint8_t *slot_ptr(int s) const { return dev + (size_t)(s < 0 ? (int)slots.size() : s) * slot_bytes; }
 };
 
@@ -1018,6 +1019,10 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
     /* the batch is in flight: levels restart from zero for whatever is queued next, which goes to the other arena */
     c->fl_pending.swap(c->pending);
     c->pending.clear();
+    for (auto &p : c->fl_pending) {
+        Stream &s = c->streams[(size_t)p.stream];
+        s.inflight_from = std::min(s.inflight_from, p.ordinal);
+    }
     for (auto &s : c->streams)
         for (auto &sl : s.slots) { sl.w_level = -1; sl.r_level = -1; }
     c->fl_host = c->host_arena; c->fl_dev = c->dev_arena; c->fl_arena_id = c->arena_id;
@@ -1254,6 +1259,8 @@ static int flush_end(HvqContext *c)
         HIPCHK(hvq_launch_nest_commit(c->np_dev, (uint32_t)(c->fl_nest_pairs.size() / 2), c->stream));
     }
     HIPCHK(hipEventRecord(c->ev_arena_free[c->fl_arena_id], c->stream));    /* this batch's arena may be refilled after this */
+    HIPCHK(hipEventRecord(c->ev_read, c->stream));                           /* every picture flushed so far is complete behind this */
+    for (auto &s : c->streams) s.inflight_from = 0x7FFFFFFF;
     c->stats = st;
     c->fl_pending.clear();
     c->fl_idx.clear();
@@ -1459,9 +1466,15 @@ HVQ_EXPORT int hvq_read_pictures(HvqContext *c, int n, const int *streams, const
 {
     if (!c || n < 0 || (n && (!streams || !ordinals || !dst))) return fail(HVQ_E_ARG, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
-    { int rc = flush_end(c); if (rc) return rc; }
-    /* all copies are queued on the read stream behind what the compute stream has been given so far; ONE wait at the end */
-    HIPCHK(hipEventRecord(c->ev_read, c->stream));
+    /* Pictures of batches that hvq_flush_end has launched are read WITHOUT ending the batch in flight: a streaming player calls
+     * flush_end(k), flush_begin(k + 1), read(k) -- the copies of batch k then run beside the parse of batch k + 1.  Only when a
+     * requested picture belongs to the batch in flight is that batch ended first. */
+    bool need_end = false;
+    for (int i = 0; i < n && !need_end; ++i)
+        if (streams[i] >= 0 && streams[i] < (int)c->streams.size() && ordinals[i] >= c->streams[(size_t)streams[i]].inflight_from) need_end = true;
+    if (need_end) { int rc = flush_end(c); if (rc) return rc; }
+    /* all copies are queued on the read stream behind the launches of the last ended batch (the event flush_end recorded); ONE
+     * wait at the end */
     HIPCHK(hipStreamWaitEvent(c->read_stream, c->ev_read, 0));
     for (int i = 0; i < n; ++i) {
         int rc = HVQ_OK;

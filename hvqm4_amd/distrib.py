@@ -1,7 +1,8 @@
 """One-process-per-GPU plumbing for the independent-clip sharding: clips are dealt
 round-robin to ranks, there is NO collective on the data path; torch.distributed is used only for the
-start/stop barrier and to reduce timings / counters / checksums at the end (backend "nccl" = RCCL on the
-GPU box, "gloo" in CPU tests)."""
+start/stop barrier and to reduce timings / counters / checksums at the end.  The backend is gloo (host
+TCP) by default: a barrier and three scalars per run need no RCCL, `north_star` asks for none, and eight
+ranks then cannot fail in a communicator they do not use (HVQM4_DIST_BACKEND=nccl selects RCCL)."""
 from __future__ import annotations
 
 import os
@@ -46,7 +47,7 @@ class Group:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            backend = backend or os.environ.get("HVQM4_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = backend or os.environ.get("HVQM4_DIST_BACKEND") or "gloo"
             # RCCL prints a version banner on stdout when the first communicator is created: keep stdout for the
             # one JSON result line (emit) and send everything else to stderr
             import sys

@@ -73,19 +73,30 @@ def test_c_player_decodes_the_golden_clips_like_the_reference(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("parser", ["gpu", "host"])
-def test_c_batch_example_streams_the_golden_clip(parser):
+@pytest.mark.parametrize("name", ["gop64x48_15", "twogops64x48", "pselfref64x48_15"])
+def test_c_batch_example_drains_every_picture_in_display_order(tmp_path, parser, name):
     """examples/h4m_batch.c: N streams of one clip through the batched C API (GPU or host entropy parse), streamed with
-    hvq_flush_begin / hvq_flush_end; every stream's last picture must be the oracle's"""
+    hvq_flush_begin / hvq_flush_end, every picture read back with hvq_read_pictures (bulk, pinned, beside the next batch's
+    parse) and written in DISPLAY order: all of them must be the oracle's pictures, reordered by the container's disp_id"""
+    from hvqm4_amd.container import display_order
     from oracle import bridge
     build()
     man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
-    ent = man["clips"]["gop64x48_15"]
+    ent = man["clips"][name]
     path = os.path.join(ROOT, "tests", "golden", ent["file"])
-    r = subprocess.run([BIN_BATCH, path, "5", parser], capture_output=True, text=True)
+    out = tmp_path / "all.yuv"
+    r = subprocess.run([BIN_BATCH, path, "5", parser, str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     data = open(path, "rb").read()
-    want = bridge.oracle_decode(data, len(ent["frame_types"]))
-    lines = r.stdout.strip().splitlines()
-    assert len(lines) == 5
-    for l in lines:
-        assert int(l.split()[-1], 16) == fnv1a(want[-1].tobytes())
+    npic = len(ent["frame_types"])
+    want = bridge.oracle_decode(data, npic)                               # decode order
+    order = list(display_order(data))                                       # decode ordinal of every display index (gop_start + disp_id)
+    assert sorted(order) == list(range(npic))
+    lines = [l.split() for l in r.stdout.strip().splitlines()]
+    assert len(lines) == npic
+    got = np.fromfile(out, dtype=np.uint8).reshape(npic, -1)
+    for k, l in enumerate(lines):
+        o = int(l[3])
+        assert int(l[1]) == k and order[k] == o
+        assert np.array_equal(got[k], want[o]), (k, o)
+        assert int(l[-1], 16) == fnv1a(want[o].tobytes())
