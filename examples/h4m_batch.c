@@ -89,24 +89,24 @@ int main(int argc, char **argv)
     uint8_t *all = hvq_pinned_alloc((size_t)nstreams * npic * info.pic_bytes);
     if (!all) { fprintf(stderr, "%s\n", hvq_last_error_string()); return 1; }
     const double t0 = now();
-    int prev_at = -1, prev_n = 0;
-    for (int at = 0; at <= npic; at += per) {
-        int m = 0;
-        if (at < npic) {
+    const int nbatch = (npic + per - 1) / per;
+    for (int b = 0; b <= nbatch; ++b) {                          /* round b: submit batch b, launch and read batch b - 1 */
+        const int at = b * per;
+        if (b < nbatch) {
+            int m = 0;
             for (int k = at; k < at + per && k < npic; ++k)          /* picture-major, like a player would submit them */
                 for (int s = 0; s < nstreams; ++s) { b_sid[m] = sid[s]; b_ft[m] = types[k]; b_pic[m] = pics[k]; b_len[m] = lens[k]; ++m; }
             if (gpu_parse) CHECK(hvq_submit_many_device(ctx, m, b_sid, b_ft, b_pic, b_len, NULL));
             else CHECK(hvq_submit_many(ctx, m, b_sid, b_ft, b_pic, b_len, 8, NULL));
         }
-        if (prev_at >= 0) CHECK(hvq_flush_end(ctx));               /* the batch submitted one round earlier: reconstruction launched */
-        if (at < npic) CHECK(hvq_flush_begin(ctx));
-        if (prev_at >= 0) {                                       /* ... and read, beside the parse of the batch just begun */
+        if (b > 0) CHECK(hvq_flush_end(ctx));                     /* batch b - 1: reconstruction launched */
+        if (b < nbatch) CHECK(hvq_flush_begin(ctx));              /* batch b: parse queued */
+        if (b > 0) {                                              /* ... and batch b - 1 read, beside that parse */
             int r = 0;
-            for (int k = prev_at; k < prev_at + prev_n; ++k)
-                for (int s = 0; s < nstreams; ++s) { r_sid[r] = sid[s]; r_ord[r] = k; r_dst[r] = all + ((size_t)s * npic + k) * info.pic_bytes; ++r; }
+            for (int s = 0; s < nstreams; ++s)                    /* stream-major: consecutive destinations, few large copies */
+                for (int k = at - per; k < at && k < npic; ++k) { r_sid[r] = sid[s]; r_ord[r] = k; r_dst[r] = all + ((size_t)s * npic + k) * info.pic_bytes; ++r; }
             CHECK(hvq_read_pictures(ctx, r, r_sid, r_ord, r_dst));
         }
-        prev_at = at; prev_n = at + per <= npic ? per : npic - at;
     }
     const double dt = now() - t0;
 

@@ -1143,9 +1143,12 @@ __device__ __forceinline__ void rgb4(u32 y4, u32 u2, u32 v2, u32 out[3])
     }
 }
 
-/* WIDE: one lane = 16 samples of TWO rows that share their chroma (two 16-byte Y loads, one 8-byte U and V load, six
- * 16-byte stores; the chroma products are computed once for the 2x2 samples they serve).  Needs width % 16 == 0 and an
- * even height (4:2:0 has both); otherwise 4 samples of one row per lane. */
+/* WIDE: one lane = 16 samples of TWO rows that share their chroma (two 16-byte Y loads, one 8-byte U and V load; the chroma
+ * products are computed once for the 2x2 samples they serve).  A lane's 48 output bytes per row are contiguous, but stored
+ * straight from the lane every store instruction would write 16 of every 48 bytes -- three partial passes over each line.
+ * So a wave turns its 3 KB of a row around in LDS: chunk c (16 bytes) of the wave's output belongs to lane c / 3, and store
+ * instruction j of lane l writes chunk l + 64 j -- every instruction a contiguous kilobyte (r03: 0.53 -> see DESIGN.md 8 f3).
+ * Needs width % 16 == 0 and an even height (4:2:0 has both); otherwise 4 samples of one row per lane. */
 template <bool WIDE>
 __global__ __launch_bounds__(256)
 void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
@@ -1156,19 +1159,39 @@ void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
     const int w = J.w, h = J.h;
     constexpr int S = WIDE ? 16 : 4;
     const int qw = w / S;                                    /* lanes per row */
+    const int total = qw * (WIDE ? h / 2 : h);
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= qw * (WIDE ? h / 2 : h)) return;
-    const int yr = idx / qw, xq = idx - yr * qw;
-    const int y = WIDE ? 2 * yr : yr;
-    const uint8_t *yp = yuv + (size_t)y * w + S * xq;
-    const uint8_t *up = yuv + (size_t)w * h + (size_t)(y >> 1) * (w >> 1) + (S / 2) * xq;
-    const uint8_t *vp = up + (size_t)(w >> 1) * (h >> 1);
-    u32 *dst = (u32 *)(rgb + ((size_t)y * w + S * xq) * 3);
     if (WIDE) {
+        __shared__ __attribute__((aligned(16))) u32 s_t[4][64 * 12];     /* per wave: 64 lanes x 48 bytes of one row */
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wave_idx0 = idx - lane;
+        if (wave_idx0 >= total) return;                      /* whole wave beyond the picture (uniform) */
+        const bool live = idx < total;
+        const int li = live ? idx : total - 1;
+        const int yr = li / qw, xq = li - yr * qw;
+        const int y = 2 * yr;
+        const uint8_t *yp = yuv + (size_t)y * w + S * xq;
+        const uint8_t *up = yuv + (size_t)w * h + (size_t)(y >> 1) * (w >> 1) + (S / 2) * xq;
+        const uint8_t *vp = up + (size_t)(w >> 1) * (h >> 1);
         const uint4 ya = *(const uint4 *)yp, yb = *(const uint4 *)(yp + w);
         const uint2 u8 = *(const uint2 *)up, v8 = *(const uint2 *)vp;
         const u32 us[4] = { u8.x & 0xFFFFu, u8.x >> 16, u8.y & 0xFFFFu, u8.y >> 16 };
         const u32 vs[4] = { v8.x & 0xFFFFu, v8.x >> 16, v8.y & 0xFFFFu, v8.y >> 16 };
+        /* where the three chunks this lane STORES live: chunk c = lane + 64 j belongs to lane c / 3 of the wave */
+        size_t chunk_off[3];
+        bool chunk_live[3];
+        const float rqw = 1.0f / (float)qw;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = lane + 64 * j, owner = (c * 21846) >> 16, part = c - 3 * owner;       /* c / 3 for c < 192 */
+            const int oi = wave_idx0 + owner;
+            int oyr = (int)((float)oi * rqw);                                                   /* estimate within +-1, fixed up */
+            int oxq = oi - oyr * qw;
+            if (oxq < 0) { oxq += qw; --oyr; } else if (oxq >= qw) { oxq -= qw; ++oyr; }
+            chunk_live[j] = oi < total;
+            chunk_off[j] = ((size_t)(2 * oyr) * w + (size_t)S * oxq) * 3 + 16 * (size_t)part;
+        }
+        typedef u32 u32x4t __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
             const uint4 y16 = row ? yb : ya;
@@ -1176,15 +1199,52 @@ void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
             u32 o[12];
 #pragma unroll
             for (int q = 0; q < 4; ++q) rgb4(ys[q], us[q], vs[q], o + 3 * q);     /* the chroma terms are common subexpressions of the two rows */
-            u32 *d = dst + row * (3 * w / 4);
+            u32x4t *mine = (u32x4t *)&s_t[wave][lane * 12];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) ((uint4 *)d)[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            for (int q = 0; q < 3; ++q) { const u32x4t v = { o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3] }; mine[q] = v; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32x4t v = *(const u32x4t *)&s_t[wave][(lane + 64 * j) * 4];
+                if (chunk_live[j]) *(u32x4t *)(rgb + chunk_off[j] + (size_t)row * 3 * w) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                 /* the second row overwrites the buffer */
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     } else {
+        if (idx >= total) return;
+        const int yr = idx / qw, xq = idx - yr * qw;
+        const uint8_t *yp = yuv + (size_t)yr * w + S * xq;
+        const uint8_t *up = yuv + (size_t)w * h + (size_t)(yr >> 1) * (w >> 1) + (S / 2) * xq;
+        const uint8_t *vp = up + (size_t)(w >> 1) * (h >> 1);
+        u32 *dst = (u32 *)(rgb + ((size_t)yr * w + S * xq) * 3);
         u32 o[3];
         rgb4(*(const u32 *)yp, *(const uint16_t *)up, *(const uint16_t *)vp, o);
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
     }
+}
+
+/* bulk readback (hvq_read_pictures): `n` resident pictures gathered into one contiguous staging buffer, so that the copy to the
+ * host is one large transfer instead of `n` small ones */
+__global__ __launch_bounds__(256)
+void hvq_gather_kernel(const uint64_t *__restrict__ src, uint8_t *__restrict__ dst, u32 pic_bytes)
+{
+    typedef u32 u32x4g __attribute__((ext_vector_type(4)));
+    const u32x4g *s = (const u32x4g *)(uintptr_t)src[blockIdx.y];
+    u32x4g *d = (u32x4g *)(dst + (size_t)blockIdx.y * pic_bytes);
+    const u32 n16 = pic_bytes / 16u;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) __builtin_nontemporal_store(s[i], d + i);
+}
+
+extern "C" hipError_t hvq_launch_gather(const uint64_t *src_dev, uint8_t *dst_dev, uint32_t n, uint32_t pic_bytes, hipStream_t stream)
+{
+    if (!n) return hipSuccess;
+    const uint32_t per = (pic_bytes / 16u + 255u) / 256u;
+    hipLaunchKernelGGL(hvq_gather_kernel, dim3(per < 16u ? (per ? per : 1u) : 16u, n), dim3(256), 0, stream, src_dev, dst_dev, pic_bytes);
+    return hipGetLastError();
 }
 
 /* jobs_dev: array of {yuv, rgb, w, h} in device memory; max_lanes = max over jobs of (w/4)*h; wide = every
