@@ -149,7 +149,9 @@ __device__ static void gf_decode_wave(GPic *g, const GCode *codes, int lane, uin
             __builtin_amdgcn_s_sleep(1);
             if (++guard > GF_SPIN_CAP) break;
         }
-        if (guard > GF_SPIN_CAP) { g->status |= GP_ST_BADARG; break; }
+        /* the staging wave did not deliver in time: a scheduling matter, not a malformed stream -- the chains kernel takes the
+         * picture (same blob), exactly as for anything else the flat path cannot serve */
+        if (guard > GF_SPIN_CAP) { g->retry = 1; break; }
         GF_T(t1);
         if (act) {
             const uint2 lo = gf_four(c, tab, bits, ring, l, &pos, &a, nbits, &guard);

@@ -853,9 +853,14 @@ static int device_parse_finish(HvqContext *c)
                 c->redo_cap = redo.size() * 2;
             }
             HIPCHK(hipMemcpyAsync(c->redo_dev, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipEventRecord(c->ev0, c->stream));
             HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, n_redo, c->fl_rowbuf, 0u, c->redo_dev, nullptr, c->stream));
+            HIPCHK(hipEventRecord(c->ev1, c->stream));
             HIPCHK(hipMemcpyAsync(c->pr_host, c->pr_dev, idx.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));       /* also keeps `redo` alive until its upload is done */
+            float ms2 = 0;
+            HIPCHK(hipEventElapsedTime(&ms2, c->ev0, c->ev1));
+            c->gpu_parse_ms += ms2;                        /* the parse time of the batch includes the second launch */
         }
     }
     const bool want_timing_print = c->timing_dev != nullptr;

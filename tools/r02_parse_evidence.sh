@@ -12,7 +12,7 @@ for preset in dense natural realistic; do
   done
 done
 HVQM4_AMD_PARSE_TIMING=1 timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-sdk --cpu-seconds 0 --streams 1 --distinct 1 --no-verify > $O/lone.json 2> $O/lone.err || exit 1
-timeout -k 5 120 tools/ubench/lut_chain > $O/lut_chain.txt 2>&1 || true
+hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/ubench/lut_chain.hip -o tools/ubench/lut_chain && timeout -k 5 120 tools/ubench/lut_chain > $O/lut_chain.txt 2>&1 || true
 python3 - <<PY > $O/summary.txt
 import json, re
 O="$O"

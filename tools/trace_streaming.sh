@@ -3,7 +3,11 @@
 set -e
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-trace}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-verify --no-sdk > $O/bench.json 2> $O/err.txt
+# clips are generated once, OUTSIDE the profiler: a profiled run must start no worker processes (the profiler's preload has
+# initialised the GPU in the parent; see tools/pmc_passes.sh)
+CACHE=/tmp/hvq_clip_cache
+python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-verify --no-gpu-parse --no-sdk --clip-cache $CACHE $BENCH_ARGS > /dev/null 2>&1 || true
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --gen-workers 1 --clip-cache $CACHE --no-verify --no-sdk > $O/bench.json 2> $O/err.txt
 python3 - <<PY
 import csv, glob
 O="$O"
