@@ -871,6 +871,16 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
     };
     u32x2 pr = { 0u, 0u };
     if ((u32)tid < npairs) pr = pair_at((u32)tid);
+    /* the first round's item records with the prologue's requests: their first touch is an HBM miss that would otherwise sit
+     * between the pair phase and the item phase (r03q: +2 %) */
+    typedef u32 u32x4i __attribute__((ext_vector_type(4)));
+    const GLB u32x4i *__restrict__ qitems = (const GLB u32x4i *)(qb + q_items_off);
+    auto item_at = [&](u32 it) -> u32x4i {
+        const bool second = TPW == 2 && it >= ni[0];
+        return qitems[(size_t)(tile0 + (second ? 1u : 0u)) * cap_items + (it - (second ? ni[0] : 0u))];
+    };
+    u32x4i rec = (u32x4i)(0u);
+    if ((u32)tid < nitems) rec = item_at((u32)tid);
     /* the literal list is held by the LAST lanes of the workgroup: the first waves already carry the pair and item lists */
     u32 lit = 0;
     const u32 li = (u32)(HVQ_WG - 1 - tid);
@@ -925,8 +935,8 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
             if (brec[h].y & 0x800u) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(4 * pw)));   /* 5th row only for vertical half samples */
         }
     }
-    /* one tile per workgroup: registers allow the first round's window rows to be in flight beside the rows above */
-    constexpr bool EARLY = TPW == 1;
+    /* the first round's window rows are in flight beside the rows above (r03q: +2 %; with the item records below +5 %) */
+    constexpr bool EARLY = true;
     uint64_t wq[4] = { 0, 0, 0, 0 };
     if (EARLY && (u32)tid < npairs && (pr.x & HVQ_PQ_MC)) window_load(ring, pr.y, (u32)lw << ((pr.x >> 20) & 1u), wq);
 
@@ -971,14 +981,6 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
         }
         STAMP(7, 1);
         /* ---- phase B2: one lane per item (two rounds when a pair of tiles queued more than 256) ---- */
-        typedef u32 u32x4i __attribute__((ext_vector_type(4)));
-        const GLB u32x4i *__restrict__ qitems = (const GLB u32x4i *)(qb + q_items_off);
-        auto item_at = [&](u32 it) -> u32x4i {
-            const bool second = TPW == 2 && it >= ni[0];
-            return qitems[(size_t)(tile0 + (second ? 1u : 0u)) * cap_items + (it - (second ? ni[0] : 0u))];
-        };
-        u32x4i rec = (u32x4i)(0u);
-        if ((u32)tid < nitems) rec = item_at((u32)tid);                        /* travels while the barrier is waited for */
         __syncthreads();                                                       /* barrier 2: accumulators complete */
         STAMP(8, 0);
         for (u32 it = (u32)tid; it < nitems; it += HVQ_WG) {

@@ -1164,7 +1164,8 @@ static int flush_end(HvqContext *c)
         if (p.dropped) continue;
         {   /* the picture's tile queues: per tile a record, a literal list, and item and pair lists sized for its fullest tile */
             const uint32_t nt = hd->tile_first[3];
-            const uint32_t cap_items = std::min(256u, (uint32_t)p.max_items), cap_pairs = std::min(HVQ_PAIR_CAP_MAX, p.max_pairs);
+            /* at least one entry each: the reconstruction kernel requests the first round of every list before it knows the counts */
+            const uint32_t cap_items = std::max(1u, std::min(256u, (uint32_t)p.max_items)), cap_pairs = std::max(1u, std::min(HVQ_PAIR_CAP_MAX, p.max_pairs));
             tq_bytes = align_up(tq_bytes, 256);
             tq_off[k] = tq_bytes;
             const bool selfref = p.kind == HVQ_PIC_P && (hd->flags & HVQ_F_SELF_REF);
