@@ -343,6 +343,9 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 #ifndef HVQ_ABL
 #define HVQ_ABL 0
 #endif
+#ifndef HVQ_BARRIER1_EARLY
+#define HVQ_BARRIER1_EARLY 1     /* 0: barrier 1 behind phase A instead of in front of the second round trip (r03s: dense -7 %, flat -5 %, natural +3 %) */
+#endif
 
 /* Diagnostic build only (-DHVQ_STAMPS, tools/variant.sh): s_memtime stamps of wave phases into a buffer of their own
  * (64 x u64 per workgroup: [wave][16]); the shipped kernel executes no stamp.  VM = also wait for the wave's
@@ -905,10 +908,9 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
         if (nest_second) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
     }
     STAMP(2, 1);
-    /* barrier 1 -- nest staged, accumulators zero -- sits HERE, where every wave has just waited for the same round trip and
-     * nothing has been computed yet: behind it the pair phase no longer depends on the block phase, so the window rows of the
-     * MC-residual pairs travel together with the motion-compensation rows */
+#if HVQ_BARRIER1_EARLY
     if (nitems) __syncthreads();
+#endif
     STAMP(3, 0);
 
     /* ---- second round trip: motion-compensation rows (lane = block) and window rows (lane = pair) ---- */
@@ -963,6 +965,11 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
         so[0] = litv.x; so[HVQ_WG] = litv.y; so[2 * HVQ_WG] = litv.z; so[3 * HVQ_WG] = litv.w;
     }
     STAMP(4, 1);
+#if !HVQ_BARRIER1_EARLY
+    /* barrier 1 -- nest staged, accumulators zero: both happened before the second round trip was even requested; the rows
+     * and the window rows were requested WITHOUT waiting for the other waves, only their use in the pair phase is behind it */
+    if (nitems) __syncthreads();
+#endif
 
     if (nitems) {
         /* ---- phase B1: one lane per (item, basis) pair ---- */
