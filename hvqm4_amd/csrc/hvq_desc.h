@@ -195,7 +195,7 @@ typedef struct HvqTileQ {
 } HvqTileQ;
 #define HVQ_TQ_INTRA   (1u << 26)  /* the tile has intra AOT items: the nest is staged */
 #define HVQ_TQ_SERIAL  (1u << 27)  /* more pairs than the picture's list reserves: no pair list, items loop over their bases */
-#define HVQ_PAIR_CAP_MAX 2048u     /* pairs per tile a list may reserve */
+#define HVQ_PAIR_CAP_MAX 1024u     /* pairs per tile a list may reserve (the queue build keeps two tiles' lists in LDS) */
 #define HVQ_BR_LIST    0u          /* literal or AOT block: the lists do it */
 #define HVQ_BR_FLAT    1u          /* flat DC (h4m:281-286) */
 #define HVQ_BR_WDC     2u          /* weighted DC (h4m:299-383) */

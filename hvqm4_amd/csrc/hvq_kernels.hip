@@ -1,30 +1,31 @@
 /*
  * hvq_kernels.hip -- HVQM4 picture reconstruction for CDNA4 / gfx950 (MI355X).
  *
- * One launch reconstructs a BATCH of pictures (one job per picture, any mix of streams,
- * sizes and picture kinds).  One 256-thread workgroup = one tile = 256 consecutive 4x4
- * blocks of one plane (raster order); a block is four packed dwords (4 samples per dword).  Because intra prediction reads neighbour DC values from the descriptor map, not
- * neighbour pixels, every block of a picture is independent:
- * no intra-picture wavefront dependency exists and the whole batch is data-parallel.
+ * One launch reconstructs a BATCH of pictures (one job per picture, any mix of streams, sizes and picture kinds).  One
+ * 256-thread workgroup = one or two tiles of 256 consecutive 4x4 blocks of one plane (raster order); a block is four packed
+ * dwords (4 samples per dword).  Because intra prediction reads neighbour DC values from the descriptor map, not neighbour
+ * pixels, every block of a picture is independent: no intra-picture wavefront dependency
+ * exists and the whole batch is data-parallel.
  *
- * Integer/byte work, no dense contraction: no MFMA.  What matters here (measurements in DESIGN.md section 5):
- *   - the tile is assembled in LDS and leaves as 16-byte row segments: every store instruction of a wave
- *     writes four complete 256-byte runs, every output line reaches HBM once and whole;
- *   - payload lookup: a block's payload length is a function of its type byte, so one 64-lane prefix scan
- *     (DPP) replaces per-block offsets (no offset traffic);
- *   - cheap block kinds are reconstructed by the lane that owns the block; AOT work is re-dealt so that one
- *     lane handles one (block, basis) pair -- the cumulative coefficient sum is resolved by the host, which
- *     makes bases independent -- and meets in LDS accumulators (ds_add);
- *   - the 70x38 intra nest is staged per workgroup in LDS, nibble-packed: one unaligned ds_read_b64 per
- *     basis row; MC-residual window rows are one unaligned 8-byte global load each;
- *   - sample arithmetic is SIMD-within-register: v_lerp_u8 for the 2-tap half-sample filters, 16-bit packed
- *     math for the weighted-DC predictor, v_sad_u8 for block sums, 24-bit multiplies for the AOT products;
- *     the reference's divTable / mcdivTable lookups are a v_rcp_f32 estimate with an exact integer fix-up;
- *   - reference pictures are addressed LINEARLY inside the Y|U|V buffer exactly like the reference's pointer
- *     arithmetic; every address is clamped to the picture slot so malformed vectors cannot
+ * Integer/byte work, no dense contraction: no MFMA.  Kernels (measurements in DESIGN.md section 5):
+ *   hvq_tileq_kernel   once per picture, part of the parse stage: classifies the blocks and leaves per tile a record per block
+ *                      (action + resolved operands), the literal list, the AOT items and the fully decoded (item, basis) pairs
+ *   hvq_recon_kernel   per dependency level: block records -> flat / weighted-DC / motion-compensated blocks by the owning lane,
+ *                      pairs -> nest or window gather, gain, 16 products -> LDS accumulators (ds_add), items -> samples;
+ *                      the tile is assembled in LDS and leaves as 16-byte row segments (every store instruction of a wave
+ *                      writes four complete 256-byte runs, every output line reaches HBM once and whole)
+ *   hvq_selfref_kernel P pictures with future-referencing macroblocks: the reference's raster-order walk
+ *   hvq_yuv420_rgb_kernel, hvq_gather_kernel   display epilogue, bulk readback
+ *   - sample arithmetic is SIMD-within-register: v_lerp_u8 for the 2-tap and 4-tap half-sample filters, 16-bit packed math for
+ *     the weighted-DC predictor, v_sad_u8 for block sums; the AOT products in the reference's own uint32 wrap arithmetic
+ *     (v_mul_lo_u32); the reference's divTable / mcdivTable lookups are a v_rcp_f32 estimate with an exact integer fix-up;
+ *   - reference pictures are addressed LINEARLY inside the Y|U|V buffer exactly like the reference's pointer arithmetic
+ *      as ring base + 32-bit offset; every address is clamped to the picture slot so malformed vectors cannot
  *     fault the GPU.
- * The limiter on vector-heavy streams is the number of distinct cache lines a CU's texture addresser can
- * process (~0.43 per clock, tools/ubench/gather_rate.hip), not HBM bandwidth and not the ALUs.
+ * What bounds the reconstruction (profiles/r03_ablation.txt): latency.  At the hardware's 8 waves per SIMD every unit is at most
+ * half busy; a wave's life is three dependent round trips (records, rows, stores).  Round 3 therefore cut instructions AND
+ * dependent hops: nothing is derived in the kernel that can be derived once per picture, and everything a round trip can
+ * carry is requested in the same round trip.
  *
  * Reference behaviour restated per device function (h4m: = h4m_audio_decode.c).
  */
@@ -384,136 +385,209 @@ typedef u32 u32x2 __attribute__((ext_vector_type(2)));
  * from the type bytes on every launch (class, payload offset by prefix scan, queue slot by ballot, pair slot by a second
  * scan, the basis word's decode, the window origin of an MC-residual block) is done here and left in three lists.
  */
+#define HVQ_TQ_TILES 2           /* tiles per workgroup of the queue build: the second tile's map and vector loads travel while the
+                                    first tile is worked on (the kernel is one chain of round trips per tile, like the reconstruction) */
+struct TqLoad {                  /* what a lane requests first for its block of one tile */
+    int p;
+    bool live, valid;
+    i32 bx, by, hb;
+    u32 e16, nt, nbt, nlf, nr, mvw, wbase, hbvb, pw_sub;
+};
+
 __global__ __launch_bounds__(HVQ_WG)
 void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
 {
-    __shared__ u32 s_cnt[HVQ_NW][5];
+    __shared__ u32 s_cnt[HVQ_TQ_TILES][HVQ_NW][5];
+    __shared__ u32 s_meta[HVQ_TQ_TILES][HVQ_TILE_BLOCKS][3];          /* per item: pool index of its first basis | MC flag, window origin, ring offset of its reference */
+    __shared__ u32 s_pref[HVQ_TQ_TILES][HVQ_PAIR_CAP_MAX];            /* per pair: item | basis number << 9 */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const HvqJob *__restrict__ J = jobs + first_job + blockIdx.y;
-    const u32 tile = blockIdx.x;
-    if (tile >= J->total_tiles) return;
-    const int p = (tile >= J->plane[1].tile_first) + (tile >= J->plane[2].tile_first);
+    const u32 total_tiles = J->total_tiles;
+    if (blockIdx.x * HVQ_TQ_TILES >= total_tiles) return;
     const u32 flags = J->flags;
     const bool is_pb = ((flags >> HVQ_JOB_KIND_SHIFT) & 3u) != HVQ_PIC_I;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
-    const u32 hbvb = J->plane[p].hbvb, pw_sub = J->plane[p].pw_sub;
-    const i32 hb = (i32)(hbvb & 0xFFFFu);
-    const u32 nblocks = (u32)hb * (hbvb >> 16);
-    const i32 ws = (i32)((pw_sub >> 16) & 0xFFu), hs = (i32)(pw_sub >> 24);
     const i32 lw = (i32)J->width, slot = (i32)J->slot_bytes;
-    const u32 b = (tile - J->plane[p].tile_first) * HVQ_TILE_BLOCKS + (u32)tid;
-    const bool valid = b < nblocks;
-    i32 bx, by;
-    block_coords(valid ? b : 0u, hb, 1.0f / (float)hb, bx, by);
-    const GLB uint8_t *map = (const GLB uint8_t *)J->plane[p].map;
-    const i32 mstride = hb + 2;
-    const GLB uint8_t *ent = map + 2 * ((by + 1) * mstride + bx + 1);
-    const u32 e16 = *(const GLB uint16_t *)ent;
-    const u32 nt = *(const GLB uint16_t *)(ent - 2 * mstride), nbt = *(const GLB uint16_t *)(ent + 2 * mstride);
-    const u32 nlf = *(const GLB uint16_t *)(ent - 2), nr = *(const GLB uint16_t *)(ent + 2);
-    u32 mvw = 0;
-    if (is_pb) mvw = ((const GLB u32 *)J->mv)[(by >> (1 - hs)) * (i32)J->mcb_w + (bx >> (1 - ws))];
-    const u32 T = e16 >> 8;
-    const u32 tc = valid ? g_type_class[(is_pb ? 512 : p == 0 ? 0 : 256) + T] : 0u;
-    const u32 npay = HVQ_TC_NPAY(tc), cls = HVQ_TC_CLS(tc), nb = HVQ_TC_NB(tc);
-    const bool lit = tc & HVQ_TC_LIT;
-    GLB uint8_t *q = (GLB uint8_t *)J->tq;
-    {   /* the block's record: what its owning lane does, operands resolved */
-        const i32 V = e16 & 0xFF;
-        u32 w0 = 0, w1 = (u32)V;
-        if (tc & HVQ_TC_MC) {
-            /* plain MC and the MC part of MC-residual blocks (h4m:1327-1355): half-sample rule per version (h4m:1337-1343) */
-            const bool is15 = flags & HVQ_F_IS15;
-            const i32 pw = (i32)(pw_sub & 0xFFFFu);
-            const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-            const u32 roff = (((T >> 5) & 3u) == 1u) ? J->ref0_off : J->ref1_off;
-            const i32 pdx = rx >> ws, pdy = ry >> hs;
-            const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
-            i32 a = (i32)J->plane[p].plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
-            /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
-            a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
-            w0 = roff + (u32)a;
-            w1 |= (HVQ_BR_MC << 8) | ((u32)hx << 10) | ((u32)hy << 11);
-        } else if (tc & HVQ_TC_WDC) {
-            /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
-             * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
-            const u32 Tt = (nt & 0x7700u) ? (u32)V : (nt & 0xFF);
-            const u32 Bb = (nbt & 0x7700u) ? (u32)V : (nbt & 0xFF);
-            const u32 Rr = (nr & 0x7700u) ? (u32)V : (nr & 0xFF);
-            const bool lexp = is_pb ? !(nlf & 0x7700u) : ((nlf >> 8) == 0 || (nlf >> 8) == 8);
-            const u32 Ll = lexp ? (nlf & 0xFF) : (u32)V;
-            w0 = Tt | (Bb << 8) | (Ll << 16) | (Rr << 24);
-            w1 |= HVQ_BR_WDC << 8;
-        } else if (valid && cls == 0 && !lit) {
-            w1 |= HVQ_BR_FLAT << 8;
-        }
-        const u32x2 br = { w0, w1 };
-        ((GLB u32x2 *)(q + J->q_recs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = br;
-    }
     const GLB u32 *__restrict__ pool = (const GLB u32 *)J->pool;
-    const u32 off = ((const GLB u32 *)J->wave_base)[tile * HVQ_NW + (u32)wave] + wave_incl_scan(npay) - npay;
-    /* queue order: intra AOT items first, then MC-residual items, each in block order; pairs follow their items */
-    const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), ml = __ballot(lit);
-    const u32 sc1 = wave_incl_scan(cls == 1 ? nb : 0u), sc2 = wave_incl_scan(cls == 2 ? nb : 0u);
-    if (lane == 63) {
-        s_cnt[wave][0] = (u32)__popcll(m1); s_cnt[wave][1] = (u32)__popcll(m2); s_cnt[wave][2] = sc1; s_cnt[wave][3] = sc2;
-        s_cnt[wave][4] = (u32)__popcll(ml);
+    GLB uint8_t *q = (GLB uint8_t *)J->tq;
+    const u32 cap_items = J->q_caps & 0xFFFFu, cap_pairs = J->q_caps >> 16;
+
+    TqLoad L[HVQ_TQ_TILES];
+#pragma unroll
+    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
+        const u32 tile = blockIdx.x * HVQ_TQ_TILES + (u32)h;
+        TqLoad &l = L[h];
+        l.live = tile < total_tiles;
+        const u32 t = l.live ? tile : total_tiles - 1u;
+        l.p = (t >= J->plane[1].tile_first) + (t >= J->plane[2].tile_first);
+        l.hbvb = J->plane[l.p].hbvb; l.pw_sub = J->plane[l.p].pw_sub;
+        l.hb = (i32)(l.hbvb & 0xFFFFu);
+        const u32 b = (t - J->plane[l.p].tile_first) * HVQ_TILE_BLOCKS + (u32)tid;
+        l.valid = l.live && b < (u32)l.hb * (l.hbvb >> 16);
+        block_coords(l.valid ? b : 0u, l.hb, 1.0f / (float)l.hb, l.bx, l.by);
+        const i32 ws = (i32)((l.pw_sub >> 16) & 0xFFu), hs = (i32)(l.pw_sub >> 24);
+        const i32 mstride = l.hb + 2;
+        const GLB uint8_t *ent = (const GLB uint8_t *)J->plane[l.p].map + 2 * ((l.by + 1) * mstride + l.bx + 1);
+        l.e16 = *(const GLB uint16_t *)ent;
+        l.nt = *(const GLB uint16_t *)(ent - 2 * mstride); l.nbt = *(const GLB uint16_t *)(ent + 2 * mstride);
+        l.nlf = *(const GLB uint16_t *)(ent - 2); l.nr = *(const GLB uint16_t *)(ent + 2);
+        l.mvw = 0;
+        if (is_pb) l.mvw = ((const GLB u32 *)J->mv)[(l.by >> (1 - hs)) * (i32)J->mcb_w + (l.bx >> (1 - ws))];
+        l.wbase = ((const GLB u32 *)J->wave_base)[t * HVQ_NW + (u32)wave];
+    }
+
+    /* ---- phase 1, both tiles: class, block record, scans, counts ---- */
+    u32 off[HVQ_TQ_TILES], cls[HVQ_TQ_TILES], nb[HVQ_TQ_TILES], sc1[HVQ_TQ_TILES], sc2[HVQ_TQ_TILES];
+    bool lit[HVQ_TQ_TILES];
+    unsigned long long m1[HVQ_TQ_TILES], m2[HVQ_TQ_TILES], ml[HVQ_TQ_TILES];
+#pragma unroll
+    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
+        const TqLoad &l = L[h];
+        const u32 tile = blockIdx.x * HVQ_TQ_TILES + (u32)h;
+        const int p = l.p;
+        const i32 bx = l.bx, by = l.by;
+        const i32 ws = (i32)((l.pw_sub >> 16) & 0xFFu), hs = (i32)(l.pw_sub >> 24);
+        const u32 e16 = l.e16, mvw = l.mvw, T = e16 >> 8;
+        const bool valid = l.valid;
+        /* the block's class, computed (a table in memory would be one more dependent access) */
+        const u32 tc = valid ? hvq_type_class(T, is_pb ? 2 : p == 0 ? 0 : 1) : 0u;
+        const u32 npay = HVQ_TC_NPAY(tc);
+        cls[h] = HVQ_TC_CLS(tc); nb[h] = HVQ_TC_NB(tc);
+        lit[h] = tc & HVQ_TC_LIT;
+        if (l.live) {   /* the block's record: what its owning lane does, operands resolved */
+            const i32 V = e16 & 0xFF;
+            u32 w0 = 0, w1 = (u32)V;
+            if (tc & HVQ_TC_MC) {
+                /* plain MC and the MC part of MC-residual blocks (h4m:1327-1355): half-sample rule per version (h4m:1337-1343) */
+                const bool is15 = flags & HVQ_F_IS15;
+                const i32 pw = (i32)(l.pw_sub & 0xFFFFu);
+                const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
+                const u32 roff = (((T >> 5) & 3u) == 1u) ? J->ref0_off : J->ref1_off;
+                const i32 pdx = rx >> ws, pdy = ry >> hs;
+                const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
+                i32 a = (i32)J->plane[p].plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+                /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
+                a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
+                w0 = roff + (u32)a;
+                w1 |= (HVQ_BR_MC << 8) | ((u32)hx << 10) | ((u32)hy << 11);
+            } else if (tc & HVQ_TC_WDC) {
+                /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
+                 * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
+                const u32 Tt = (l.nt & 0x7700u) ? (u32)V : (l.nt & 0xFF);
+                const u32 Bb = (l.nbt & 0x7700u) ? (u32)V : (l.nbt & 0xFF);
+                const u32 Rr = (l.nr & 0x7700u) ? (u32)V : (l.nr & 0xFF);
+                const bool lexp = is_pb ? !(l.nlf & 0x7700u) : ((l.nlf >> 8) == 0 || (l.nlf >> 8) == 8);
+                const u32 Ll = lexp ? (l.nlf & 0xFF) : (u32)V;
+                w0 = Tt | (Bb << 8) | (Ll << 16) | (Rr << 24);
+                w1 |= HVQ_BR_WDC << 8;
+            } else if (valid && cls[h] == 0 && !lit[h]) {
+                w1 |= HVQ_BR_FLAT << 8;
+            }
+            const u32x2 br = { w0, w1 };
+            ((GLB u32x2 *)(q + J->q_recs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = br;
+        }
+        off[h] = l.wbase + wave_incl_scan(npay) - npay;
+        /* queue order: intra AOT items first, then MC-residual items, each in block order; pairs follow their items */
+        m1[h] = __ballot(cls[h] == 1); m2[h] = __ballot(cls[h] == 2); ml[h] = __ballot(lit[h]);
+        sc1[h] = wave_incl_scan(cls[h] == 1 ? nb[h] : 0u); sc2[h] = wave_incl_scan(cls[h] == 2 ? nb[h] : 0u);
+        if (lane == 63) {
+            s_cnt[h][wave][0] = (u32)__popcll(m1[h]); s_cnt[h][wave][1] = (u32)__popcll(m2[h]); s_cnt[h][wave][2] = sc1[h]; s_cnt[h][wave][3] = sc2[h];
+            s_cnt[h][wave][4] = (u32)__popcll(ml[h]);
+        }
     }
     __syncthreads();
-    u32 tot[5] = { 0, 0, 0, 0, 0 }, mine[5] = { 0, 0, 0, 0, 0 };
+    /* ---- phase 2, both tiles: slots; literal list; what the pair lanes need, into LDS; the scalars of MC-residual items requested ---- */
+    u32 npairs[HVQ_TQ_TILES], it_of[HVQ_TQ_TILES], p0[HVQ_TQ_TILES], p1[HVQ_TQ_TILES];
+    bool serial[HVQ_TQ_TILES];
 #pragma unroll
-    for (int v = 0; v < HVQ_NW; ++v)
+    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
+        const TqLoad &l = L[h];
+        const u32 tile = blockIdx.x * HVQ_TQ_TILES + (u32)h;
+        u32 tot[5] = { 0, 0, 0, 0, 0 }, mine[5] = { 0, 0, 0, 0, 0 };
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { const u32 c = s_cnt[v][k]; tot[k] += c; if (v < wave) mine[k] += c; }
-    const u32 nI = tot[0], nitems = tot[0] + tot[1], npairs = tot[2] + tot[3], nlit = tot[4];
-    const u32 cap_items = J->q_caps & 0xFFFFu, cap_pairs = J->q_caps >> 16;
-    const bool serial = npairs > cap_pairs;
-    if (tid == 0) {
-        GLB HvqTileQ *t = (GLB HvqTileQ *)q + tile;
-        t->w0 = (serial ? 0u : npairs) | (nitems << 16) | (nI ? HVQ_TQ_INTRA : 0u) | (serial ? HVQ_TQ_SERIAL : 0u);
-        t->w1 = nlit;
-    }
-    if (lit) ((GLB u32 *)(q + J->q_lits_off))[(size_t)tile * HVQ_TILE_BLOCKS + mine[4] + lanes_below(ml)] = (u32)tid | (off << 8);
-    if (J->q_offs_off) ((GLB u32 *)(q + J->q_offs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = off;     /* for hvq_selfref_kernel */
-    if (cls) {
-        const u32 it = cls == 1 ? mine[0] + lanes_below(m1) : nI + mine[1] + lanes_below(m2);
-        u32 p0 = 0, p1 = 0;
-        if (cls == 2) { p0 = pool[off]; p1 = pool[off + 1]; }
-        if (it < cap_items) {                           /* always: the cap is the picture's largest tile queue */
-            typedef u32 u32x4q __attribute__((ext_vector_type(4)));
-            const u32x4q rec = { (u32)tid | (e16 << 8), off, p0, p1 };
-            ((GLB u32x4q *)(q + J->q_items_off))[(size_t)tile * cap_items + it] = rec;
+        for (int v = 0; v < HVQ_NW; ++v)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { const u32 c = s_cnt[h][v][k]; tot[k] += c; if (v < wave) mine[k] += c; }
+        const u32 nI = tot[0], nitems = tot[0] + tot[1], nlit = tot[4];
+        npairs[h] = tot[2] + tot[3];
+        serial[h] = npairs[h] > cap_pairs;
+        it_of[h] = 0; p0[h] = 0; p1[h] = 0;
+        if (!l.live) continue;                                       /* uniform */
+        if (tid == 0) {
+            GLB HvqTileQ *t = (GLB HvqTileQ *)q + tile;
+            t->w0 = (serial[h] ? 0u : npairs[h]) | (nitems << 16) | (nI ? HVQ_TQ_INTRA : 0u) | (serial[h] ? HVQ_TQ_SERIAL : 0u);
+            t->w1 = nlit;
         }
-        if (!serial && it < cap_items) {
-            const u32 pstart = cls == 1 ? mine[2] + sc1 - nb : tot[2] + mine[3] + sc2 - nb;
-            GLB u32x2 *dst = (GLB u32x2 *)(q + J->q_pairs_off) + (size_t)tile * cap_pairs + pstart;
-            const GLB u32 *bases = pool + off + (cls == 2 ? 2u : 0u);
-            i32 origin = 0;
-            u32 ref_off = 0;
-            if (cls == 2) {
-                const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-                origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;   /* h4m:1865-1868 */
-                ref_off = ((T >> 5) & 3u) == 1u ? J->ref0_off : J->ref1_off;
-            }
-            for (u32 k = 0; k < nb; ++k) {
-                const u32 d = bases[k];
-                const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;                       /* h4m:683-711 */
-                const u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
-                const u32 x2 = landscape ? sl : ss, y2 = landscape ? ss : sl;
-                u32 w0 = (d >> 14) | ((d & 0x2000u) ? HVQ_PQ_NEG : 0u) | (x2 ? HVQ_PQ_X2 : 0u) | (y2 ? HVQ_PQ_Y2 : 0u) | (it << HVQ_PQ_ITEM_SHIFT);
-                u32 w1;
-                if (cls == 1) {
-                    const i32 stride = landscape ? 70 : 38;
-                    w1 = (u32)(landscape ? stride * os + ol : stride * ol + os);
-                } else {
-                    const i32 o = landscape ? lw * os + ol : lw * ol + os;
-                    const i32 ys = lw << y2;
-                    w1 = ref_off + (u32)clampi(origin + o, 0, slot - 8 - 3 * ys);     /* one clamp: legal windows lie inside the slot */
-                    w0 |= HVQ_PQ_MC;
+        if (lit[h]) ((GLB u32 *)(q + J->q_lits_off))[(size_t)tile * HVQ_TILE_BLOCKS + mine[4] + lanes_below(ml[h])] = (u32)tid | (off[h] << 8);
+        if (J->q_offs_off) ((GLB u32 *)(q + J->q_offs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = off[h];     /* for hvq_selfref_kernel */
+        if (cls[h]) {
+            const u32 T = l.e16 >> 8;
+            const u32 it = cls[h] == 1 ? mine[0] + lanes_below(m1[h]) : nI + mine[1] + lanes_below(m2[h]);
+            it_of[h] = it;
+            if (cls[h] == 2) { p0[h] = pool[off[h]]; p1[h] = pool[off[h] + 1]; }        /* not used before phase 3: both tiles' travel together */
+            if (!serial[h] && it < cap_items) {
+                /* the pairs are written by one lane per PAIR (the basis dwords of a block are dependent loads when its owner walks
+                 * them one after the other): the owner leaves what a pair needs from its item, and the pair slots of its bases */
+                const u32 pstart = cls[h] == 1 ? mine[2] + sc1[h] - nb[h] : tot[2] + mine[3] + sc2[h] - nb[h];
+                i32 origin = 0;
+                u32 ref_off = 0;
+                if (cls[h] == 2) {
+                    const i32 rx = (i32)(int16_t)(l.mvw & 0xFFFF), ry = (i32)(int16_t)(l.mvw >> 16);
+                    origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;   /* h4m:1865-1868 */
+                    ref_off = ((T >> 5) & 3u) == 1u ? J->ref0_off : J->ref1_off;
                 }
-                const u32x2 pw01 = { w0, w1 };
-                dst[k] = pw01;
+                s_meta[h][it][0] = (off[h] + (cls[h] == 2 ? 2u : 0u)) | (cls[h] == 2 ? 0x80000000u : 0u);
+                s_meta[h][it][1] = (u32)origin;
+                s_meta[h][it][2] = ref_off;
+#pragma clang loop unroll(disable) vectorize(disable)
+                for (u32 k = 0; k < nb[h]; ++k) s_pref[h][pstart + k] = it | (k << 9);
             }
+        }
+    }
+    __syncthreads();
+    /* ---- phase 3, both tiles: one lane per pair (first round's basis dwords of both tiles requested together), item records ---- */
+    u32 d0[HVQ_TQ_TILES], pr0[HVQ_TQ_TILES];
+#pragma unroll
+    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
+        d0[h] = 0; pr0[h] = 0;
+        if (L[h].live && !serial[h] && (u32)tid < npairs[h]) {
+            pr0[h] = s_pref[h][tid];
+            d0[h] = pool[(s_meta[h][pr0[h] & 511u][0] & 0x7FFFFFFFu) + (pr0[h] >> 9)];
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
+        const TqLoad &l = L[h];
+        if (!l.live) continue;
+        const u32 tile = blockIdx.x * HVQ_TQ_TILES + (u32)h;
+        if (cls[h] && it_of[h] < cap_items) {                        /* always: the cap is the picture's largest tile queue */
+            typedef u32 u32x4q __attribute__((ext_vector_type(4)));
+            const u32x4q rec = { (u32)tid | (l.e16 << 8), off[h], p0[h], p1[h] };
+            ((GLB u32x4q *)(q + J->q_items_off))[(size_t)tile * cap_items + it_of[h]] = rec;
+        }
+        if (serial[h]) continue;
+        GLB u32x2 *dst = (GLB u32x2 *)(q + J->q_pairs_off) + (size_t)tile * cap_pairs;
+        for (u32 pi = (u32)tid; pi < npairs[h]; pi += HVQ_WG) {
+            const u32 pr = pi == (u32)tid ? pr0[h] : s_pref[h][pi], it = pr & 511u;
+            const u32 m0 = s_meta[h][it][0];
+            const bool mc = m0 & 0x80000000u;
+            const u32 d = pi == (u32)tid ? d0[h] : pool[(m0 & 0x7FFFFFFFu) + (pr >> 9)];
+            const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;                       /* h4m:683-711 */
+            const u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
+            const u32 x2 = landscape ? sl : ss, y2 = landscape ? ss : sl;
+            u32 w0 = (d >> 14) | ((d & 0x2000u) ? HVQ_PQ_NEG : 0u) | (x2 ? HVQ_PQ_X2 : 0u) | (y2 ? HVQ_PQ_Y2 : 0u) | (it << HVQ_PQ_ITEM_SHIFT);
+            u32 w1;
+            if (!mc) {
+                const i32 stride = landscape ? 70 : 38;
+                w1 = (u32)(landscape ? stride * os + ol : stride * ol + os);
+            } else {
+                const i32 o = landscape ? lw * os + ol : lw * ol + os;
+                const i32 ys = lw << y2;
+                w1 = s_meta[h][it][2] + (u32)clampi((i32)s_meta[h][it][1] + o, 0, slot - 8 - 3 * ys);     /* one clamp: legal windows lie inside the slot */
+                w0 |= HVQ_PQ_MC;
+            }
+            const u32x2 pw01 = { w0, w1 };
+            dst[pi] = pw01;
         }
     }
 }
@@ -523,7 +597,7 @@ extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_jo
     if (njobs == 0 || max_tiles == 0) return hipSuccess;
     for (uint32_t at = 0; at < njobs; at += 32768u) {
         const uint32_t n = njobs - at < 32768u ? njobs - at : 32768u;
-        hipLaunchKernelGGL(hvq_tileq_kernel, dim3(max_tiles, n), dim3(HVQ_WG), 0, stream, jobs_dev, first_job + at);
+        hipLaunchKernelGGL(hvq_tileq_kernel, dim3((max_tiles + HVQ_TQ_TILES - 1) / HVQ_TQ_TILES, n), dim3(HVQ_WG), 0, stream, jobs_dev, first_job + at);
     }
     return hipGetLastError();
 }

@@ -10,8 +10,12 @@
  * Ownership (h4m:2409-2419, 2340-2350): the caller allocates and frees everything -- a work
  * buffer of HVQM4BuffSize() bytes and the picture buffers of w*h*(hs*vs+2)/(hs*vs) bytes,
  * planes Y|U|V tightly packed.  `frame` points 4 bytes past the record start (after disp_id,
- * h4m:2100) and must be readable 8 bytes past its end (the reference needs 3, h4m:2080-2082).
- * All calls are synchronous: on return `present` holds the decoded picture.
+ * h4m:2100).  Nothing behind the picture's last section is read (the reference reads up to 3
+ * bytes past it, h4m:2080-2082): the length comes from the picture's own section table, and
+ * HVQM4SetMaxFrameSize bounds the walk over that table (tests/native/sdk_bounds_asan.c).
+ * All calls are synchronous: on return `present` holds the decoded picture.  HVQM4DecodePpic
+ * reads `present` like the reference does when the picture carries future-referencing
+ * macroblocks (h4m:2058-2061): the buffer's content at the call is part of the input then.
  *
  * The functions return void like the reference; failures (no GPU, HIP error, unsupported
  * geometry) are reported on stderr and through HVQM4GetLastError() -- `present` is then left
