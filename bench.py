@@ -468,6 +468,7 @@ def main():
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_over_algorithmic": traffic["over_algorithmic"] if traffic else None,
             "traffic_source": traffic["source"] if traffic else None,
+            "valu": pmc_valu(args),
             "kernel": "hvq_recon_kernel", "algorithmic_bytes_per_launch": int(st.algorithmic_bytes // launches),
             "avg_launch_us": round(avg_launch_s * 1e6, 2),
             "descriptor_bytes_per_launch": int(st.descriptor_bytes // launches),
@@ -552,6 +553,20 @@ def pmc_traffic(args):
     hbm = j.get("hbm_bytes_per_launch_calibrated", j.get("hbm_bytes_per_launch"))
     return {"hbm_bytes_per_launch": int(hbm), "over_algorithmic": j.get("over_algorithmic"),
             "source": "profiles/" + os.path.basename(files[-1]) + (" (calibrated)" if "hbm_bytes_per_launch_calibrated" in j else " (raw counters)")}
+
+
+def pmc_valu(args):
+    """vector-instruction bound of hvq_recon_kernel beside the HBM fraction (which stays the contract number): instructions per
+    wave and VALU busy fraction from the committed PMC passes of this default workload (tools/pmc_valu.py); None otherwise"""
+    if pmc_traffic(args) is None:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")))
+    if not files:
+        return None
+    j = json.load(open(files[-1]))
+    return {"insts_per_wave": j["insts_per_wave"], "busy_frac": j["busy_frac"], "note": j.get("note"),
+            "source": "profiles/" + os.path.basename(files[-1])}
 
 
 def _time_clip_worker(job):
