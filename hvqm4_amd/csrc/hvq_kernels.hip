@@ -1135,7 +1135,7 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
                 /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors
                  * in L2 (+1 % on MC-dominated streams, neutral on the dense one; profiles/r01j_ab_nontemporal.txt) */
                 if (HVQ_ABL == 16) *(GLB u32x4 *)(plane + (size_t)(tid * 16)) = v;
-                else if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
+                else if (HVQ_ABL == 17 ? true : HVQ_ABL == 18 ? false : pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));   /* 17 / 18: all / no stores non-temporal */
                 else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
             }
         } else if (b0 + (u32)(h * HVQ_TILE_BLOCKS + tid) < nblocks) {
