@@ -482,30 +482,6 @@ def main():
         "flags_or": int(st.flags_or),
     }
 
-    # the same resident-descriptor pass with the dependency levels of the even and of the odd streams on TWO HIP streams
-    # (HVQM4_AMD_QUEUES=2): while one chain drains a level the other keeps the CUs busy.  Reported beside the headline, never as
-    # `value` or `roofline`: overlapping launches make per-kernel durations incomparable with the elapsed time (DESIGN.md 5.0).
-    if rank == 0 and world == 1 and not args.no_sdk:
-        try:
-            os.environ["HVQM4_AMD_QUEUES"] = "2"
-            ctxq = batch.Context(device)
-            sidsq = [ctxq.open_stream(clips[ci].width, clips[ci].height, 2, 2, clips[ci].version == "1.5", args.nslots) for ci in stream_clip]
-            ctxq.submit_many([sidsq[s] for s in a_stream], a_ft, a_pic, threads)
-            ctxq.flush(); ctxq.sync()
-            ctxq.replay(args.warmup or 1)
-            msq = ctxq.replay(args.steps)
-            okq = all(np.array_equal(ctxq.read_picture(sidsq[s], len(pics[stream_clip[s]]) - 1), ctx.read_picture(sids[s], len(pics[stream_clip[s]]) - 1))
-                      for s in range(min(4, len(sids))))
-            ctxq.close()
-            out["two_queues"] = {"value": round(px_step * args.steps / (msq * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
-                                 "frac_of_roofline": round(st.algorithmic_bytes * args.steps / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "pictures_equal_single_queue": bool(okq),
-                                 "what": "HVQM4_AMD_QUEUES=2: levels of even / odd streams on two HIP streams, HIP-event time over the same steps"}
-        except Exception as e:
-            out["two_queues"] = {"error": str(e)}
-        finally:
-            os.environ.pop("HVQM4_AMD_QUEUES", None)
-
     # display epilogue: YUV420 -> RGB24 of the newest picture of every stream, one launch
     try:
         ctx.rgb_bench(2)
@@ -524,9 +500,34 @@ def main():
 
     if cpu_base is not None:
         out["cpu_baseline"] = cpu_base
+    last_single = [ctx.read_picture(sids[s], len(pics[stream_clip[s]]) - 1) for s in range(min(4, len(sids)))]
+    ctx.close()
+    # (after the main context is closed: HIP maps streams onto four hardware queues, and two streams that share one do not overlap)
+    # the same resident-descriptor pass with the dependency levels of the even and of the odd streams on TWO HIP streams
+    # (HVQM4_AMD_QUEUES=2): while one chain drains a level the other keeps the CUs busy.  Reported beside the headline, never as
+    # `value` or `roofline`: overlapping launches make per-kernel durations incomparable with the elapsed time (DESIGN.md 5.0).
+    if rank == 0 and world == 1 and not args.no_sdk:
+        try:
+            os.environ["HVQM4_AMD_QUEUES"] = "2"
+            ctxq = batch.Context(device)
+            sidsq = [ctxq.open_stream(clips[ci].width, clips[ci].height, 2, 2, clips[ci].version == "1.5", args.nslots) for ci in stream_clip]
+            ctxq.submit_many([sidsq[s] for s in a_stream], a_ft, a_pic, threads)
+            ctxq.flush(); ctxq.sync()
+            ctxq.replay(args.warmup or 1)
+            msq = ctxq.replay(args.steps)
+            okq = all(np.array_equal(ctxq.read_picture(sidsq[s], len(pics[stream_clip[s]]) - 1), last_single[s]) for s in range(len(last_single)))
+            ctxq.close()
+            out["two_queues"] = {"value": round(px_step * args.steps / (msq * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+                                 "frac_of_roofline": round(st.algorithmic_bytes * args.steps / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "pictures_equal_single_queue": bool(okq),
+                                 "what": "HVQM4_AMD_QUEUES=2: levels of even / odd streams on two HIP streams, HIP-event time over the same steps"}
+        except Exception as e:
+            out["two_queues"] = {"error": str(e)}
+        finally:
+            os.environ.pop("HVQM4_AMD_QUEUES", None)
+
     if rank == 0:
         grp.emit(json.dumps(out))
-    ctx.close()
     grp.close()
 
 

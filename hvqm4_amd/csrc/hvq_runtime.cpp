@@ -327,7 +327,6 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     struct Guard { HvqContext *c; ~Guard() { if (c) hvq_context_destroy(c); } } guard{ c };     /* a failing step below frees what exists */
     HIPCHK(hvq_upload_tables());
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->read_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));
@@ -933,6 +932,8 @@ static int run_launches(HvqContext *c)
     bool two = false;
     for (auto &L : c->launches) two |= L.queue == 1;
     if (two) {
+        /* created on demand: HIP maps a process's streams onto four hardware queues, a fifth stream would share one */
+        if (!c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
