@@ -1038,6 +1038,16 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
         u32 *so = &s_out[lit_second ? TPW - 1 : 0][0][lit & 0xFFu];
         so[0] = litv.x; so[HVQ_WG] = litv.y; so[2 * HVQ_WG] = litv.z; so[3 * HVQ_WG] = litv.w;
     }
+    if (TPW == 2 && nlits > (u32)HVQ_WG) {                                     /* two tiles with more literal blocks than lanes: a second round (rare) */
+        const u32 l2 = li + (u32)HVQ_WG;
+        if (l2 < nlits) {
+            const bool sec = l2 >= nl[0];
+            const u32 e = ((const GLB u32 *)(qb + q_lits_off))[(size_t)(tile0 + (sec ? 1u : 0u)) * HVQ_TILE_BLOCKS + (l2 - (sec ? nl[0] : 0u))];
+            const u32x4l v = *(const GLB u32x4l *)(pool + (e >> 8));
+            u32 *so = &s_out[sec ? TPW - 1 : 0][0][e & 0xFFu];
+            so[0] = v.x; so[HVQ_WG] = v.y; so[2 * HVQ_WG] = v.z; so[3 * HVQ_WG] = v.w;
+        }
+    }
     STAMP(4, 1);
 #if !HVQ_BARRIER1_EARLY
     /* barrier 1 -- nest staged, accumulators zero: both happened before the second round trip was even requested; the rows

@@ -79,6 +79,7 @@ class SynthConfig:
     long_escape: int = 0              # I pictures: one luma DC delta written as this many overflow symbols (h4m:654-664 sums
                                       # for as long as the stream says) -- legal by format, far beyond what an encoder emits
     long_escape_pb: int = 0           # P/B pictures: the first intra DC delta written as this many overflow symbols
+    p_zero: float = -1.0              # >= 0: probability of a zero-kind run start, overriding the preset's (small: nearly every block coded)
 
 
 class _Ops:
@@ -277,6 +278,8 @@ class _Gen:
             self.p_proc1 = 0.9
         else:
             raise ValueError(p)
+        if cfg.p_zero >= 0:
+            self.p_zero = cfg.p_zero
 
     # -- helpers ------------------------------------------------------------
     def _run(self, mean: float, lo: int = 0, hi: int = 255) -> int:

@@ -35,6 +35,8 @@ SMALL = [
     ("pselfref64x48_15", SynthConfig(width=64, height=48, gop="IPBBPBPP", seed=36, p_future_refs=True)),
     ("pselfref64x48_13", SynthConfig(width=64, height=48, gop="IPPPBP", seed=37, p_future_refs=True, version="1.3")),
     ("pselfref444_48x64", SynthConfig(width=48, height=64, gop="IPBPP", seed=38, p_future_refs=True, sampling="444")),
+    # nearly every coded block a literal (kind 6, h4m:543-549): more literal blocks in a pair of tiles than a workgroup has lanes
+    ("literals96x96", SynthConfig(width=96, height=96, gop="IPB", seed=40, literal_weight=400.0, p_zero=0.02)),
 ]
 
 MEDIUM = [
