@@ -811,6 +811,10 @@ __device__ __forceinline__ void gather_nest_q(i32 o, bool x2, i32 ys, const uint
 /* window gather of one decoded pair, MC residual (h4m:734-765): voff = ring offset of sample (0,0), ys = row stride */
 __device__ __forceinline__ void window_load(const GLB uint8_t *ring, u32 voff, u32 ys, uint64_t q[4])
 {
+    /* timing experiments (wrong pictures): 19 = two row loads instead of four; 20 = one; 21 = four, from a 64 KB window of the ring (cache hits) */
+    if (HVQ_ABL == 19) { q[0] = *(const GLB u64u *)(ring + (size_t)voff); q[1] = *(const GLB u64u *)(ring + (size_t)(u32)(voff + ys)); q[2] = q[0] ^ 1; q[3] = q[1] ^ 1; return; }
+    if (HVQ_ABL == 20) { q[0] = *(const GLB u64u *)(ring + (size_t)voff); q[1] = q[0] ^ 1; q[2] = q[0] ^ 2; q[3] = q[1] ^ 3; return; }
+    if (HVQ_ABL == 21) voff &= 0xFFFFu;
 #pragma unroll
     for (int y = 0; y < 4; ++y) q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(voff + (u32)y * ys));
 }
