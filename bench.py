@@ -502,6 +502,56 @@ def main():
         out["cpu_baseline"] = cpu_base
     last_single = [ctx.read_picture(sids[s], len(pics[stream_clip[s]]) - 1) for s in range(min(4, len(sids)))]
     ctx.close()
+    # the same 2048 pictures per step with the GOP phase of the streams STAGGERED (stream s is s mod 16 pictures into its GOP when
+    # the batch starts): every launch then holds I, P and B pictures in the stream's own proportion instead of one kind per
+    # dependency level.  An extra line; the headline stays lock-step (every stream at the same picture, as a batch of players is).
+    if rank == 0 and world == 1 and not args.no_sdk and args.workload == "c5" and all(len(p) == 16 for p in pics):
+        try:
+            from oracle import bridge as _bridge
+            ctxs = batch.Context(device)
+            sidss = [ctxs.open_stream(clips[ci].width, clips[ci].height, 2, 2, clips[ci].version == "1.5", args.nslots) for ci in stream_clip]
+            phase = [s % 16 for s in range(len(sidss))]
+            w_sid, w_ft, w_pic = [], [], []
+            for k in range(16):                                          # warm-up: every stream up to its phase
+                for s, sid in enumerate(sidss):
+                    if k < phase[s]:
+                        ft, _d, pic = pics[stream_clip[s]][k]
+                        w_sid.append(sid); w_ft.append(ft); w_pic.append(pic)
+            ctxs.submit_many(w_sid, w_ft, w_pic, threads); ctxs.flush(); ctxs.sync()
+            b_sid, b_ft, b_pic = [], [], []
+            for j in range(16):                                          # the batch: 16 pictures of every stream from its phase on (the GOP repeats)
+                for s, sid in enumerate(sidss):
+                    ft, _d, pic = pics[stream_clip[s]][(phase[s] + j) % 16]
+                    b_sid.append(sid); b_ft.append(ft); b_pic.append(pic)
+            ctxs.submit_many(b_sid, b_ft, b_pic, threads); ctxs.flush(); ctxs.sync()
+            sts = ctxs.stats()
+            chk = 0
+            for s in (1, 5, 11):                                         # first pass checked against the oracle (ordinal o = GOP position o mod 16)
+                if s >= len(sidss):
+                    continue
+                want = _bridge.oracle_decode(clips[stream_clip[s]].data, 16)
+                for o in range(phase[s] + 16):
+                    try:
+                        got = ctxs.read_picture(sidss[s], o)
+                    except HvqError as e:
+                        if e.code != HVQ_E_STATE:
+                            raise
+                        continue
+                    if not np.array_equal(got, want[o % 16]):
+                        raise SystemExit(f"PARITY FAILURE (staggered): stream {s} ordinal {o} differs from the oracle")
+                    chk += 1
+            # replays repeat the launches over whatever the slots hold by then (the references of the first pictures have been
+            # overwritten by the batch's last ones): the same descriptors, addresses and work -- timing only
+            ctxs.replay(args.warmup or 1)
+            mss = ctxs.replay(args.steps)
+            ctxs.close()
+            out["c5_staggered"] = {"value": round(int(sts.luma_pixels) * args.steps / (mss * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+                                   "frac_of_roofline": round(sts.algorithmic_bytes * args.steps / (mss * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "launches_per_step": int(sts.launches), "pictures_per_step": int(sts.pictures), "pictures_checked": chk,
+                                   "what": "stream s starts its batch s mod 16 pictures into its GOP: mixed picture kinds in every launch"}
+        except Exception as e:
+            out["c5_staggered"] = {"error": str(e)}
+
     # (after the main context is closed: HIP maps streams onto four hardware queues, and two streams that share one do not overlap)
     # the same resident-descriptor pass with the dependency levels of the even and of the odd streams on TWO HIP streams
     # (HVQM4_AMD_QUEUES=2): while one chain drains a level the other keeps the CUs busy.  Reported beside the headline, never as
