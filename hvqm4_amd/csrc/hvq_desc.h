@@ -181,8 +181,9 @@ _Static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
  *                   sample (h4m:1327-1355, clamped into the slot); weighted DC: the four neighbour values the predictor
  *                   sees, top | bottom << 8 | left << 16 | right << 24 (h4m:1437-1454, 1811-1814)
  *   literals   u32 per literal block: owner (lane of the tile) | pool offset << 8
- *   items      16 bytes per queued block (intra AOT first, then MC residual): owner | map entry << 8, pool offset of the
- *              payload, the two scalars of an MC-residual block (h4m:1405-1406)
+ *   items      8 bytes per queued block (intra AOT first, then MC residual): owner | map entry << 8 | HVQ_IQ_WIDE, and the two
+ *              scalars of an MC-residual block (h4m:1405-1406) as 16-bit values, the first before its shift by unk_shift;
+ *              HVQ_IQ_WIDE (scalars beyond 16 bits, and every item of a serial tile): the pool offset of the payload instead
  *   pairs      8 bytes per (item, basis), items in order, fully decoded (h4m:683-731 / 738-772):
  *              w0 = [17:0] coefficient sum + offset, [18] negate, [19] sample stride 2, [20] row stride 2, [21] MC residual,
  *                   [31:23] item of the tile
@@ -205,6 +206,7 @@ typedef struct HvqTileQ {
 #define HVQ_PQ_Y2      (1u << 20)
 #define HVQ_PQ_MC      (1u << 21)
 #define HVQ_PQ_ITEM_SHIFT 23
+#define HVQ_IQ_WIDE    (1u << 24)
 
 /* Block classification by map type byte, one dword per (context, type): context 0 = I-picture luma (kind = whole byte,
  * h4m:1093), 1 = I-picture chroma, 2 = P/B picture.  Filled by hvq_type_class() on the host, read by the kernel. */

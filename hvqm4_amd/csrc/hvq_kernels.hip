@@ -408,6 +408,7 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
     const bool is_pb = ((flags >> HVQ_JOB_KIND_SHIFT) & 3u) != HVQ_PIC_I;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const i32 lw = (i32)J->width, slot = (i32)J->slot_bytes;
+    const i32 unk = (i32)((flags >> HVQ_JOB_UNK_SHIFT) & 31u);
     const GLB u32 *__restrict__ pool = (const GLB u32 *)J->pool;
     GLB uint8_t *q = (GLB uint8_t *)J->tq;
     const u32 cap_items = J->q_caps & 0xFFFFu, cap_pairs = J->q_caps >> 16;
@@ -561,9 +562,14 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
         if (!l.live) continue;
         const u32 tile = blockIdx.x * HVQ_TQ_TILES + (u32)h;
         if (cls[h] && it_of[h] < cap_items) {                        /* always: the cap is the picture's largest tile queue */
-            typedef u32 u32x4q __attribute__((ext_vector_type(4)));
-            const u32x4q rec = { (u32)tid | (l.e16 << 8), off[h], p0[h], p1[h] };
-            ((GLB u32x4q *)(q + J->q_items_off))[(size_t)tile * cap_items + it_of[h]] = rec;
+            /* 8 bytes: owner | map entry, and the two scalars of an MC-residual block as 16-bit values (h4m:1405-1406: the first is
+             * (s >> dc_shift) << unk_shift, kept unshifted).  Scalars that do not fit, and every item of a serial tile (whose owner
+             * walks its bases), carry the payload offset instead: the reconstruction kernel then reads the pool itself. */
+            const i32 a = (i32)p0[h] >> unk, b = (i32)p1[h];
+            const bool fits = ((u32)a << unk) == p0[h] && a == (i32)(int16_t)a && b == (i32)(int16_t)b;
+            const bool wide = serial[h] || (cls[h] == 2 && !fits);
+            const u32x2 rec = { (u32)tid | (l.e16 << 8) | (wide ? HVQ_IQ_WIDE : 0u), wide ? off[h] : (((u32)a & 0xFFFFu) | ((u32)b << 16)) };
+            ((GLB u32x2 *)(q + J->q_items_off))[(size_t)tile * cap_items + it_of[h]] = rec;
         }
         if (serial[h]) continue;
         GLB u32x2 *dst = (GLB u32x2 *)(q + J->q_pairs_off) + (size_t)tile * cap_pairs;
@@ -954,13 +960,13 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
     if ((u32)tid < npairs) pr = pair_at((u32)tid);
     /* the first round's item records with the prologue's requests: their first touch is an HBM miss that would otherwise sit
      * between the pair phase and the item phase (r03q: +2 %) */
-    typedef u32 u32x4i __attribute__((ext_vector_type(4)));
+    typedef u32x2 u32x4i;                                                   /* 8-byte item records (hvq_desc.h) */
     const GLB u32x4i *__restrict__ qitems = (const GLB u32x4i *)(qb + q_items_off);
     auto item_at = [&](u32 it) -> u32x4i {
         const bool second = TPW == 2 && it >= ni[0];
         return qitems[(size_t)(tile0 + (second ? 1u : 0u)) * cap_items + (it - (second ? ni[0] : 0u))];
     };
-    u32x4i rec = (u32x4i)(0u);
+    u32x4i rec = { 0u, 0u };
     if ((u32)tid < nitems) rec = item_at((u32)tid);
     /* the literal list is held by the LAST lanes of the workgroup: the first waves already carry the pair and item lists */
     u32 lit = 0;
@@ -1120,7 +1126,9 @@ void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restric
                 Blk m;                                       /* the owner left the MC block in the tile */
 #pragma unroll
                 for (int y = 0; y < 4; ++y) m.r[y] = so[y * HVQ_WG];
-                o = predi_finish(r, m, rec.z, rec.w, unk);
+                u32 p0 = (u32)(i32)(int16_t)(rec.y & 0xFFFFu) << unk, p1 = (u32)(i32)(int16_t)(rec.y >> 16);
+                if (rec.x & HVQ_IQ_WIDE) { p0 = pool[rec.y]; p1 = pool[rec.y + 1]; }              /* rare: scalars beyond 16 bits, serial tiles */
+                o = predi_finish(r, m, p0, p1, unk);
             } else {
                 o = intra_finish(r, (i32)(q16 & 0xFF), unk);
             }

@@ -1166,13 +1166,16 @@ static int flush_end(HvqContext *c)
         {   /* the picture's tile queues: per tile a record, a literal list, and item and pair lists sized for its fullest tile */
             const uint32_t nt = hd->tile_first[3];
             /* at least one entry each: the reconstruction kernel requests the first round of every list before it knows the counts */
-            const uint32_t cap_items = std::max(1u, std::min(256u, (uint32_t)p.max_items)), cap_pairs = std::max(1u, std::min(HVQ_PAIR_CAP_MAX, p.max_pairs));
+            /* HVQM4_AMD_PAIR_CAP (tests): a smaller pair list, so that ordinary clips reach the tiles-with-too-many-pairs path
+             * (HVQ_TQ_SERIAL: no pair list, the items walk their bases) */
+            static const uint32_t pair_cap = getenv("HVQM4_AMD_PAIR_CAP") ? std::min(HVQ_PAIR_CAP_MAX, (uint32_t)std::max(1, atoi(getenv("HVQM4_AMD_PAIR_CAP")))) : HVQ_PAIR_CAP_MAX;
+            const uint32_t cap_items = std::max(1u, std::min(256u, (uint32_t)p.max_items)), cap_pairs = std::max(1u, std::min(pair_cap, p.max_pairs));
             tq_bytes = align_up(tq_bytes, 256);
             tq_off[k] = tq_bytes;
             const bool selfref = p.kind == HVQ_PIC_P && (hd->flags & HVQ_F_SELF_REF);
             const size_t recs = align_up((size_t)nt * sizeof(HvqTileQ), 16), lits = recs + (size_t)nt * HVQ_TILE_BLOCKS * 8,
                          items = lits + (size_t)nt * HVQ_TILE_BLOCKS * 4,
-                         pairs = items + (size_t)nt * cap_items * 16, offs = pairs + (size_t)nt * cap_pairs * 8,
+                         pairs = items + (size_t)nt * cap_items * 8, offs = pairs + (size_t)nt * cap_pairs * 8,
                          end = offs + (selfref ? (size_t)nt * HVQ_TILE_BLOCKS * 4 : 0);
             if (selfref) {
                 /* the data-parallel pass writes a side buffer; the walk behind this level's launch merges it into the slot */

@@ -79,6 +79,8 @@ class SynthConfig:
     long_escape: int = 0              # I pictures: one luma DC delta written as this many overflow symbols (h4m:654-664 sums
                                       # for as long as the stream says) -- legal by format, far beyond what an encoder emits
     long_escape_pb: int = 0           # P/B pictures: the first intra DC delta written as this many overflow symbols
+    predi_big: float = 0.0            # P/B pictures: probability that a scalar of an MC-residual block (h4m:1405-1406) lies beyond 16 bits
+    p_proc1: float = -1.0             # >= 0: probability of a run of plain-MC (proc = 1) macroblocks, overriding the preset's
     p_zero: float = -1.0              # >= 0: probability of a zero-kind run start, overriding the preset's (small: nearly every block coded)
 
 
@@ -280,6 +282,8 @@ class _Gen:
             raise ValueError(p)
         if cfg.p_zero >= 0:
             self.p_zero = cfg.p_zero
+        if cfg.p_proc1 >= 0:
+            self.p_proc1 = cfg.p_proc1
 
     # -- helpers ------------------------------------------------------------
     def _run(self, mean: float, lo: int = 0, hi: int = 255) -> int:
@@ -616,6 +620,8 @@ class _Gen:
                             tval = int(np.rint(rng.laplace(0, 10)))
                             if rng.random() < 0.02:
                                 tval = int(rng.integers(-300, 301))
+                            if self.cfg.predi_big and rng.random() < self.cfg.predi_big:
+                                tval = int(rng.integers(33000, 50000)) * (1 if rng.random() < 0.5 else -1)
                             for lf in _sovf_leaves(tval):
                                 pic.ops[DC0 + p].leaf(lf)
         return pic

@@ -36,6 +36,8 @@ SMALL = [
     ("pselfref64x48_13", SynthConfig(width=64, height=48, gop="IPPPBP", seed=37, p_future_refs=True, version="1.3")),
     ("pselfref444_48x64", SynthConfig(width=48, height=64, gop="IPBPP", seed=38, p_future_refs=True, sampling="444")),
     # nearly every coded block a literal (kind 6, h4m:543-549): more literal blocks in a pair of tiles than a workgroup has lanes
+    # MC-residual scalars beyond 16 bits (long overflow runs in the DC sections): the item records carry the payload offset instead
+    ("bigscalars64x64", SynthConfig(width=64, height=64, gop="IPB", seed=42, predi_big=0.03, dc_shifts=(0,))),
     ("literals96x96", SynthConfig(width=96, height=96, gop="IPB", seed=40, literal_weight=400.0, p_zero=0.02)),
 ]
 
@@ -48,6 +50,9 @@ MEDIUM = [
     # map flat (h4m:1169), so it reads border values and the next row's first entries -- deterministic, reproduced exactly
     ("nest_border1_320x240", SynthConfig(width=320, height=240, gop="IPB", seed=24, nest_overhang=1)),
     ("nest_border2_296x160", SynthConfig(width=296, height=160, gop="IPB", seed=25, nest_overhang=2)),
+    # up to 14 bases per MC-residual block, nearly every block coded: tiles with more (item, basis) pairs than a pair list holds
+    # (1024) -- their items walk their bases themselves (HVQ_TQ_SERIAL)
+    ("manybases320x240", SynthConfig(width=320, height=240, gop="IPB", seed=41, max_predi_bases=14, p_zero=0.02, p_proc1=0.0, literal_weight=0.1)),
     ("pselfref320x240", SynthConfig(width=320, height=240, gop="IPBBPBBP", seed=39, p_future_refs=True)),
 ]
 

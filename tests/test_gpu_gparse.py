@@ -31,6 +31,8 @@ def test_gpu_parsed_clip_matches_oracle(gpu_ctx, case):
     if not os.environ.get("HVQM4_AMD_PARSE_FLAT") == "0":
         if case[0].startswith("longescape"):      # an overflow run of 300 symbols goes to the chains by design: same pictures
             assert st.gpu_parse_retried == 1
+        elif case[0].startswith("bigscalars"):    # so do the runs of several hundred symbols behind its 16-bit-plus scalars (P and B picture)
+            assert 1 <= st.gpu_parse_retried <= 2
         else:
             assert st.gpu_parse_retried == 0, "the flat parse path handed a regular picture to the chains"
 

@@ -24,6 +24,20 @@ def test_parity_suites_with_forced_tiles_per_workgroup(tiles):
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("cap", ["24", "200"])
+def test_parity_suites_with_tiles_beyond_the_pair_list(cap):
+    """A tile with more (item, basis) pairs than the picture's pair list reserves (1024 at most) gets no pair list: its items walk
+    their bases themselves (HVQ_TQ_SERIAL) and carry the payload offset instead of the packed MC-residual scalars (HVQ_IQ_WIDE).
+    No encoder-like stream reaches 1024 pairs in 256 blocks; with the list capped at 24 nearly every tile of the parity clips
+    takes that path, at 200 the two kinds of tile meet inside one workgroup."""
+    env = dict(os.environ, HVQM4_AMD_PAIR_CAP=cap)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "tests/test_gpu_parity.py", "tests/test_gpu_gparse.py"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert " passed" in r.stdout
+
+
 def test_gpu_parse_suite_with_the_chains_only():
     """The device entropy parse has two ways to a blob: the flat path (all sections at once, scans) and round 1's chains,
     which the flat path also falls back to per picture.  The default run exercises the flat path; here the GPU-parse suite
