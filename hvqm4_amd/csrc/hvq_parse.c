@@ -184,7 +184,11 @@ static void build_type_info(void);
 HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int is15)
 {
     if (width < 8 || height < 8 || (width & 7) || (height & 7) || width > 8192 || height > 8192) return NULL;
-    if (!((h_samp == 2 && v_samp == 2) || (h_samp == 1 && v_samp == 1))) return NULL;
+    /* 4:2:0, 4:4:4, and 4:2:2 as h_samp 2 / v_samp 1 (two chroma blocks per macroblock, one above the other).  The fourth
+     * combination the reference's setHVQPlaneDesc accepts, h_samp 1 / v_samp 2, is not decodable by the reference itself: with
+     * two blocks per macroblock its tables (mcb_offset[1] = stride, pb_offset[1] = 4 rows down, h4m:863-870) address the block
+     * BELOW, i.e. the next macroblock row's, and never the one to the right. */
+    if (!((h_samp == 2 || h_samp == 1) && (v_samp == 2 || v_samp == 1)) || (h_samp == 1 && v_samp == 2)) return NULL;
     pthread_once(&g_type_info_once, build_type_info);
     HvqParser *p = calloc(1, sizeof *p);
     if (!p) return NULL;

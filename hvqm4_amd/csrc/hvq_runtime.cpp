@@ -395,7 +395,7 @@ HVQ_EXPORT int hvq_stream_open(HvqContext *c, int width, int height, int h_samp,
     if (nslots < 3) return fail(HVQ_E_ARG, "nslots must be >= 3 (past, present, future)");
     HIPCHK(hipSetDevice(c->device));
     HvqParser *p = hvq_parser_create(width, height, h_samp, v_samp, is15);
-    if (!p) return fail(HVQ_E_GEOMETRY, "unsupported geometry %dx%d sampling %dx%d (need multiples of 8, <= 8192, 4:2:0 or 4:4:4)",
+    if (!p) return fail(HVQ_E_GEOMETRY, "unsupported geometry %dx%d sampling %dx%d (need multiples of 8, <= 8192; samplings 2x2, 1x1 and 2x1 -- the reference's own tables cannot decode 1x2)",
                         width, height, h_samp, v_samp);
     Stream s;
     s.open = true; s.parser = p; s.w = width; s.h = height;

@@ -75,7 +75,8 @@ class SynthConfig:
     max_predi_bases: int = 6
     literal_weight: float = 1.0
     usec_per_frame: int = 33366
-    sampling: str = "420"             # "420" (h_samp = v_samp = 2) | "444" (1, 1: four chroma blocks per macroblock)
+    sampling: str = "420"             # "420" (h_samp = v_samp = 2) | "444" (1, 1: four chroma blocks per macroblock) |
+                                      # "422" (2, 1: two, one above the other)
     long_escape: int = 0              # I pictures: one luma DC delta written as this many overflow symbols (h4m:654-664 sums
                                       # for as long as the stream says) -- legal by format, far beyond what an encoder emits
     long_escape_pb: int = 0           # P/B pictures: the first intra DC delta written as this many overflow symbols
@@ -246,13 +247,12 @@ class _Gen:
         assert w % 8 == 0 and h % 8 == 0 and w >= 8 and h >= 8
         self.w, self.h = w, h
         self.hb, self.vb = w // 4, h // 4
-        self.s444 = cfg.sampling == "444"
-        self.cshift = 0 if self.s444 else 1                    # chroma plane shift
-        self.cblk = 4 if self.s444 else 1                      # chroma blocks per macroblock (h4m:852-854)
-        self.chb, self.cvb = (w // 4, h // 4) if self.s444 else (w // 8, h // 8)
+        self.cws, self.chs = {"420": (1, 1), "444": (0, 0), "422": (1, 0)}[cfg.sampling]   # chroma plane shifts (h4m:845-848)
+        self.cblk = (2 >> self.cws) * (2 >> self.chs)          # chroma blocks per macroblock (h4m:852-854)
+        self.chb, self.cvb = (w >> self.cws) // 4, (h >> self.chs) // 4
         self.landscape = w >= h
         self.nest_w, self.nest_h = (70, 38) if self.landscape else (38, 70)
-        self.picsize = w * h * 3 if self.s444 else w * h * 3 // 2
+        self.picsize = w * h + 2 * (w >> self.cws) * (h >> self.chs)
         self.is15 = cfg.version == "1.5"
         self.smooth_mv = cfg.preset == "natural"
         p = cfg.preset
@@ -416,11 +416,11 @@ class _Gen:
     def _mc_extent(self, rx: int, ry: int):
         """largest in-plane coordinates touched by the MC reads of one macroblock:
         (luma col, luma row, chroma col, chroma row); half-pel rule per version (h4m:1329-1343)"""
-        pdx, pdy = rx >> self.cshift, ry >> self.cshift
+        pdx, pdy = rx >> self.cws, ry >> self.chs
         hx, hy = (pdx & 1, pdy & 1) if self.is15 else (rx & 1, ry & 1)
-        cext = 7 if self.s444 else 3                           # chroma macroblock is 8x8 in 4:4:4
+        cex, cey = (8 >> self.cws) - 1, (8 >> self.chs) - 1    # a chroma macroblock is (8 >> shift) samples wide / high
         return ((rx >> 1) + 7 + (rx & 1), (ry >> 1) + 7 + (ry & 1),
-                (pdx >> 1) + cext + hx, (pdy >> 1) + cext + hy)
+                (pdx >> 1) + cex + hx, (pdy >> 1) + cey + hy)
 
     def _mv_legal(self, rx: int, ry: int, predi: bool) -> bool:
         """every MC read stays inside its own plane's storage (rows may run off the right
@@ -429,7 +429,7 @@ class _Gen:
         if rx < 0 or ry < 0:
             return False
         lc, lr, cc, cr = self._mc_extent(rx, ry)
-        cw, ch = w >> self.cshift, h >> self.cshift
+        cw, ch = w >> self.cws, h >> self.chs
         if lr * w + lc > w * h - 1 or cr * cw + cc > cw * ch - 1:
             return False
         if predi:
@@ -448,7 +448,7 @@ class _Gen:
         if rx < 0 or ry < 0:
             return False
         lc, lr, cc, cr = self._mc_extent(rx, ry)
-        return lc <= self.w - 1 and lr <= self.h - 1 and cc <= (self.w >> self.cshift) - 1 and cr <= (self.h >> self.cshift) - 1
+        return lc <= self.w - 1 and lr <= self.h - 1 and cc <= (self.w >> self.cws) - 1 and cr <= (self.h >> self.chs) - 1
 
     def gen_PB(self, kind: int) -> _Picture:
         rng = self.rng
@@ -660,11 +660,20 @@ class SynthClip:
     kinds: List[int]                       # frame type per picture, decode order
     cursors: List[List[int]]               # expected reader cursor per picture per stream
     pictures: List[bytes] = field(default_factory=list)   # picture data (after disp_id), decode order
-    samp: int = 2
+    samp: int = 2                          # h_samp (= v_samp for 4:2:0 and 4:4:4)
+    samp_v: int = 0                        # v_samp; 0: same as samp
+
+    @property
+    def samp_h(self) -> int:
+        return self.samp
+
+    def __post_init__(self):
+        if not self.samp_v:
+            self.samp_v = self.samp
 
     @property
     def picsize(self) -> int:
-        ss = self.samp * self.samp
+        ss = self.samp * self.samp_v
         return self.width * self.height * (ss + 2) // ss
 
     @property
@@ -703,7 +712,7 @@ def make_clip(cfg: SynthConfig) -> SynthClip:
     magic = (b"HVQM4 1.5" if cfg.version == "1.5" else b"HVQM4 1.3").ljust(16, b"\0")
     hdr = magic + struct.pack(">IIIIIIIII", 0x44, len(body), cfg.n_gops * cfg.repeat_gops, len(kinds), 0,
                               cfg.usec_per_frame, max_frame, 0, 0)
-    samp = 1 if cfg.sampling == "444" else 2
-    hdr += struct.pack(">HHBBBBBBBBI", cfg.width, cfg.height, samp, samp, 0, 0, 0, 0, 0, 0, 0)
+    samp, samp_v = {"420": (2, 2), "444": (1, 1), "422": (2, 1)}[cfg.sampling]
+    hdr += struct.pack(">HHBBBBBBBBI", cfg.width, cfg.height, samp, samp_v, 0, 0, 0, 0, 0, 0, 0)
     assert len(hdr) == 0x44, len(hdr)
-    return SynthClip(bytes(hdr + body), cfg.width, cfg.height, cfg.version, kinds, cursors, pictures, samp)
+    return SynthClip(bytes(hdr + body), cfg.width, cfg.height, cfg.version, kinds, cursors, pictures, samp, samp_v)

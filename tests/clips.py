@@ -24,6 +24,10 @@ SMALL = [
     ("yuv444_64x48", SynthConfig(width=64, height=48, gop="IPBBPBB", seed=18, sampling="444")),
     ("yuv444_13_portrait48x64", SynthConfig(width=48, height=64, gop="IPBB", seed=19, sampling="444", version="1.3", runoff_prob=0.3)),
     ("yuv444_296x160", SynthConfig(width=296, height=160, gop="IPB", seed=20, sampling="444", weird_kinds=True)),
+    # 4:2:2 as the reference spells it (h_samp 2, v_samp 1): two chroma blocks per macroblock, one above the other (h4m:852-870)
+    ("yuv422_64x48", SynthConfig(width=64, height=48, gop="IPBBPBB", seed=43, sampling="422")),
+    ("yuv422_13_portrait48x64", SynthConfig(width=48, height=64, gop="IPBB", seed=44, sampling="422", version="1.3", runoff_prob=0.3)),
+    ("yuv422_296x160", SynthConfig(width=296, height=160, gop="IPB", seed=45, sampling="422", weird_kinds=True)),
     # fills the last cells of tests/test_fixture_coverage.py: inter kind 8 in a chroma plane, past (P) and future (B)
     ("weird160x128", SynthConfig(width=160, height=128, gop="IPPBBPBB", seed=34, weird_kinds=True)),
     # one DC delta of 300 overflow symbols (the reference sums for as long as the stream says, h4m:654-664): decoded like the
@@ -35,6 +39,7 @@ SMALL = [
     ("pselfref64x48_15", SynthConfig(width=64, height=48, gop="IPBBPBPP", seed=36, p_future_refs=True)),
     ("pselfref64x48_13", SynthConfig(width=64, height=48, gop="IPPPBP", seed=37, p_future_refs=True, version="1.3")),
     ("pselfref444_48x64", SynthConfig(width=48, height=64, gop="IPBPP", seed=38, p_future_refs=True, sampling="444")),
+    ("pselfref422_64x48", SynthConfig(width=64, height=48, gop="IPBPP", seed=46, p_future_refs=True, sampling="422")),
     # nearly every coded block a literal (kind 6, h4m:543-549): more literal blocks in a pair of tiles than a workgroup has lanes
     # MC-residual scalars beyond 16 bits (long overflow runs in the DC sections): the item records carry the payload offset instead
     ("bigscalars64x64", SynthConfig(width=64, height=64, gop="IPB", seed=42, predi_big=0.03, dc_shifts=(0,))),

@@ -33,7 +33,7 @@ def histogram(clip) -> Counter:
     from hvqm4_amd._lib import lib
     l = lib()
     is15 = clip.version == "1.5"
-    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp, clip.samp, 1 if is15 else 0)
+    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp_h, clip.samp_v, 1 if is15 else 0)
     bound = l.hvq_parser_blob_bound(prs)
     blob = np.zeros(bound, dtype=np.uint8)
     h = Counter()

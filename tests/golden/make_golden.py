@@ -35,7 +35,7 @@ def main():
             "clip_sha256": hashlib.sha256(clip.data).hexdigest(),
             "picture_sha256": [hashlib.sha256(p.tobytes()).hexdigest() for p in pics],
         }
-        if clip.width * clip.height <= 128 * 96 and clip.samp == 2:
+        if clip.width * clip.height <= 128 * 96 and clip.samp == 2 and clip.samp_v == 2:
             # display epilogue: RGB of every picture through the reference's own dumpRGB (h4m:901-926)
             entry["rgb_sha256"] = [hashlib.sha256(bridge.ref_rgb(p, clip.width, clip.height).tobytes()).hexdigest() for p in pics]
         if (name, cfg) in clips.SMALL:

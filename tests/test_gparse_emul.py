@@ -57,7 +57,7 @@ def compare_clip(emul, clip, mode=FLAT_ONLY):
     from hvqm4_amd._lib import lib
     l = lib()
     is15 = 1 if clip.version == "1.5" else 0
-    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp, clip.samp, is15)
+    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp_h, clip.samp_v, is15)
     assert prs
     bound = l.hvq_parser_blob_bound(prs)
     a = np.zeros(bound, dtype=np.uint8)
@@ -69,7 +69,7 @@ def compare_clip(emul, clip, mode=FLAT_ONLY):
         assert l.hvq_parse_picture(prs, ft, pic + b"\0" * 8, len(pic), a.ctypes.data, bound, C.byref(n)) == 0
         b[:] = 0xEE
         res = Result()
-        assert emul.gparse_emul2(pic, len(pic), ft, clip.width, clip.height, clip.samp, clip.samp, is15,
+        assert emul.gparse_emul2(pic, len(pic), ft, clip.width, clip.height, clip.samp_h, clip.samp_v, is15,
                                  b.ctypes.data, bound, nest.ctypes.data, C.byref(res), mode) == 0, (idx, "flat path gave up")
         assert res.status == 0, (idx, res.status)
         ha, hb = header(a.tobytes()), header(b.tobytes())
@@ -114,12 +114,12 @@ def test_gpu_parse_core_random_geometries(emul):
         cfg = SynthConfig(width=int(rng.integers(1, 30)) * 8, height=int(rng.integers(1, 24)) * 8,
                           version=str(rng.choice(["1.3", "1.5"])), gop=str(rng.choice(["IPB", "IPBBPBB", "IPPP"])),
                           seed=int(rng.integers(0, 1 << 30)), preset=str(rng.choice(["dense", "realistic", "flat", "natural"])),
-                          sampling=str(rng.choice(["420", "444"])), weird_kinds=bool(rng.random() < 0.3),
+                          sampling=str(rng.choice(["420", "444", "422"])), weird_kinds=bool(rng.random() < 0.3),
                           runoff_prob=float(rng.choice([0.0, 0.3])))
         compare_clip(emul, make_clip(cfg))
 
 
-@pytest.mark.parametrize("w,h,samp", [(1920, 1088, "420"), (2048, 8, "420"), (8, 2048, "420"), (1024, 16, "444")])
+@pytest.mark.parametrize("w,h,samp", [(1920, 1088, "420"), (2048, 8, "420"), (8, 2048, "420"), (1024, 16, "444"), (16, 1024, "422")])
 def test_gpu_parse_core_large_and_extreme_geometries(emul, w, h, samp):
     from hvqm4_amd.synth import SynthConfig, make_clip
     compare_clip(emul, make_clip(SynthConfig(width=w, height=h, gop="IPB", seed=w + h, sampling=samp, runoff_prob=0.2)))
@@ -143,7 +143,7 @@ def test_flat_path_hands_unusual_pictures_to_the_chains(emul):
         pics.append((ft, bytes(p)))
     from hvqm4_amd._lib import lib
     l = lib()
-    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp, clip.samp, 1 if clip.version == "1.5" else 0)
+    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp_h, clip.samp_v, 1 if clip.version == "1.5" else 0)
     bound = l.hvq_parser_blob_bound(prs)
     a = np.zeros(bound, dtype=np.uint8)
     b = np.zeros(bound, dtype=np.uint8)
@@ -153,7 +153,7 @@ def test_flat_path_hands_unusual_pictures_to_the_chains(emul):
         n = C.c_size_t(0)
         rc = l.hvq_parse_picture(prs, ft, pic + b"\0" * 8, len(pic), a.ctypes.data, bound, C.byref(n))
         res = Result()
-        assert emul.gparse_emul2(pic, len(pic), ft, clip.width, clip.height, clip.samp, clip.samp, 1 if clip.version == "1.5" else 0,
+        assert emul.gparse_emul2(pic, len(pic), ft, clip.width, clip.height, clip.samp_h, clip.samp_v, 1 if clip.version == "1.5" else 0,
                                  b.ctypes.data, bound, nest.ctypes.data, C.byref(res), FLAT) == 0
         assert (rc == 0) == (res.status == 0)
         if rc == 0:
@@ -198,8 +198,8 @@ def test_flat_path_equals_the_chains_on_corrupted_pictures(emul):
                 q = bytes(q)
                 a[:] = 0; b[:] = 0; na[:] = 0; nb[:] = 0
                 ra, rb = Result(), Result()
-                assert emul.gparse_emul2(q, len(q), ft, w, h, clip.samp, clip.samp, is15, a.ctypes.data, cap, na.ctypes.data, C.byref(ra), CHAINS) == 0
-                assert emul.gparse_emul2(q, len(q), ft, w, h, clip.samp, clip.samp, is15, b.ctypes.data, cap, nb.ctypes.data, C.byref(rb), FLAT) == 0
+                assert emul.gparse_emul2(q, len(q), ft, w, h, clip.samp_h, clip.samp_v, is15, a.ctypes.data, cap, na.ctypes.data, C.byref(ra), CHAINS) == 0
+                assert emul.gparse_emul2(q, len(q), ft, w, h, clip.samp_h, clip.samp_v, is15, b.ctypes.data, cap, nb.ctypes.data, C.byref(rb), FLAT) == 0
                 total += 1; fell_back += rb.pad[0]
                 assert ra.status == rb.status, (seed, hex(ft), v)
                 if ra.status == 0:

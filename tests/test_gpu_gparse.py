@@ -127,7 +127,7 @@ def test_corrupted_streams_do_not_fault_the_gpu_parser(gpu_ctx):
     test_nest_of_the_last_I_picture_survives_flushes(gpu_ctx, 2)
 
 
-@pytest.mark.parametrize("w,h,samp", [(1920, 1088, "420"), (2048, 8, "420"), (8, 2048, "420"), (1024, 16, "444"), (720, 576, "444")])
+@pytest.mark.parametrize("w,h,samp", [(1920, 1088, "420"), (2048, 8, "420"), (8, 2048, "420"), (1024, 16, "444"), (720, 576, "444"), (720, 576, "422"), (8, 1024, "422")])
 def test_large_and_extreme_geometries(gpu_ctx, w, h, samp):
     """full-HD, one-macroblock-high strips (longest DC row buffer, ragged last tiles) and wide 4:4:4, through both
     parsers; the oracle is the checker"""

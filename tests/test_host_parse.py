@@ -21,7 +21,7 @@ def decode_via_descriptors(clip, truncate=None):
     o.hvqd_recon.argtypes = [C.c_void_p] * 4 + [C.c_uint32]
     ps = clip.picsize
     slot = ps + 64
-    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp, clip.samp, 1 if clip.version == "1.5" else 0)
+    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp_h, clip.samp_v, 1 if clip.version == "1.5" else 0)
     assert prs
     bound = l.hvq_parser_blob_bound(prs)
     blob = np.zeros(bound, dtype=np.uint8)
@@ -91,7 +91,11 @@ def test_unsupported_geometry_is_rejected():
     from hvqm4_amd._lib import lib
     l = lib()
     assert not l.hvq_parser_create(60, 48, 2, 2, 1)       # width not a multiple of 8 (h4m:1749-1752)
-    assert not l.hvq_parser_create(64, 48, 2, 1, 1)       # sampling the reference itself handles inconsistently
+    assert not l.hvq_parser_create(64, 48, 1, 2, 1)       # the sampling the reference's own tables cannot decode (h4m:863-870)
+    assert not l.hvq_parser_create(64, 48, 4, 2, 1)
+    prs = l.hvq_parser_create(64, 48, 2, 1, 1)           # 4:2:2 as the reference spells it
+    assert prs and l.hvq_parser_pic_bytes(prs) == 64 * 48 * 2
+    l.hvq_parser_destroy(prs)
     assert not l.hvq_parser_create(0, 0, 2, 2, 1)
 
 
