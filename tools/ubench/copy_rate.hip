@@ -21,6 +21,18 @@ __global__ __launch_bounds__(256) void k(const u32x4 *__restrict__ a, const u32x
     }
 }
 
+// mode 5: copy, four 16-byte loads in flight per lane, non-temporal stores (a tuned streaming copy)
+__global__ __launch_bounds__(256) void k5(const u32x4 *__restrict__ a, u32x4 *__restrict__ o, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+        const u32x4 v0 = __builtin_nontemporal_load(a + i), v1 = __builtin_nontemporal_load(a + i + stride),
+                    v2 = __builtin_nontemporal_load(a + i + 2 * stride), v3 = __builtin_nontemporal_load(a + i + 3 * stride);
+        __builtin_nontemporal_store(v0, o + i); __builtin_nontemporal_store(v1, o + i + stride);
+        __builtin_nontemporal_store(v2, o + i + 2 * stride); __builtin_nontemporal_store(v3, o + i + 3 * stride);
+    }
+}
+
 template <int MODE> void run(const u32x4 *a, const u32x4 *b, u32x4 *o, size_t n, double bytes_per_elem, const char *name)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -45,5 +57,24 @@ int main()
     run<2>(a, b, o, n, 16, "read only");
     run<3>(a, b, o, n, 16, "write only");
     run<4>(a, b, o, n, 32, "copy, reads in 64-byte pieces at scattered places");
+    {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int blocks : { 256 * 4, 256 * 8, 256 * 16, 256 * 32 }) {
+            k5<<<blocks, 256>>>(a, o, n);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            for (int r = 0; r < 5; ++r) k5<<<blocks, 256>>>(a, o, n);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("copy, 4 x 16 B in flight per lane, non-temporal, %5d workgroups %8.3f ms per pass  %7.1f GB/s\n", blocks, ms / 5, 32.0 * (double)n * 5 / (ms * 1e-3) / 1e9);
+        }
+        hipMemcpyAsync(o, a, n * 16, hipMemcpyDeviceToDevice, 0);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) hipMemcpyAsync(o, a, n * 16, hipMemcpyDeviceToDevice, 0);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-58s %8.3f ms per pass  %7.1f GB/s\n", "hipMemcpyAsync device to device (the runtime's own copy)", ms / 5, 32.0 * (double)n * 5 / (ms * 1e-3) / 1e9);
+    }
     return 0;
 }
