@@ -19,7 +19,7 @@ def draw(rng) -> SynthConfig:
         width=int(rng.integers(1, 42)) * 8, height=int(rng.integers(1, 32)) * 8,
         version=str(rng.choice(["1.3", "1.5"])), gop=str(rng.choice(GOPS)), n_gops=int(rng.integers(1, 3)),
         seed=int(rng.integers(0, 1 << 30)), preset=str(rng.choice(["dense", "realistic", "flat", "natural"])),
-        sampling=str(rng.choice(["420", "420", "444"])), runoff_prob=float(rng.choice([0.0, 0.05, 0.4])),
+        sampling=str(rng.choice(["420", "420", "444", "422"])), runoff_prob=float(rng.choice([0.0, 0.05, 0.4])),
         weird_kinds=bool(rng.random() < 0.3),
         dc_shifts=tuple(int(x) for x in rng.choice([0, 1, 2], 2)),
         unk_shifts=tuple(int(x) for x in rng.choice([6, 7, 8, 9], 2)),
