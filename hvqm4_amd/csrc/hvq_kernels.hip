@@ -22,10 +22,11 @@
  *   - reference pictures are addressed LINEARLY inside the Y|U|V buffer exactly like the reference's pointer arithmetic
  *      as ring base + 32-bit offset; every address is clamped to the picture slot so malformed vectors cannot
  *     fault the GPU.
- * What bounds the reconstruction (profiles/r03_ablation.txt): latency.  At the hardware's 8 waves per SIMD every unit is at most
- * half busy; a wave's life is three dependent round trips (records, rows, stores).  Round 3 therefore cut instructions AND
- * dependent hops: nothing is derived in the kernel that can be derived once per picture, and everything a round trip can
- * carry is requested in the same round trip.
+ * What bounds the reconstruction (profiles/r03_ablation.txt): the number of gather requests -- four row segments
+ * per 4x4 block in four cache lines, a window per AOT basis at its own place -- beside a VALU that is two fifths busy and a store
+ * path that holds a wave's slot until its lines are acknowledged.  Not HBM bytes (a quarter less descriptor traffic: nothing),
+ * not latency alone (a round trip less per wave: nothing).  Round 3 cut instructions and dependent hops: nothing is derived in
+ * the kernel that can be derived once per picture, and everything a round trip can carry is requested in the same round trip.
  *
  * Reference behaviour restated per device function (h4m: = h4m_audio_decode.c).
  */
