@@ -60,7 +60,8 @@ class HvqStats(C.Structure):
     _fields_ = [("pictures", C.c_uint64), ("luma_pixels", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("descriptor_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32),
                 ("parse_seconds", C.c_double), ("flags_or", C.c_uint32), ("gpu_parsed", C.c_uint32),
-                ("gpu_parse_ms", C.c_double), ("gpu_parse_retried", C.c_uint32), ("dropped", C.c_uint32)]
+                ("gpu_parse_ms", C.c_double), ("gpu_parse_retried", C.c_uint32), ("dropped", C.c_uint32),
+                ("pad0", C.c_uint32), ("queue_bytes", C.c_uint64)]
 
 
 # every symbol include/hvqm4.h and include/hvqm4_amd.h declare: (restype, argtypes)
@@ -91,6 +92,7 @@ SYMBOLS = {
     "hvq_flush_end": (C.c_int, [C.c_void_p]),
     "hvq_sync": (C.c_int, [C.c_void_p]),
     "hvq_replay": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "hvq_replay_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "hvq_read_picture": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "hvq_stream_pic_bytes": (C.c_uint32, [C.c_void_p, C.c_int]),
     "hvq_read_picture_rgb": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),

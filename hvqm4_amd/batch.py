@@ -64,6 +64,12 @@ class Context:
         check(lib().hvq_replay(self._h, reps, C.byref(ms)))
         return float(ms.value)
 
+    def replay_stage(self, reps: int, what: int = 1) -> float:
+        """hvq_replay_stage: what = 1 queue build + reconstruction per repetition, 2 queue build only, 0 = replay"""
+        ms = C.c_float(0)
+        check(lib().hvq_replay_stage(self._h, reps, what, C.byref(ms)))
+        return float(ms.value)
+
     def pic_bytes(self, sid: int) -> int:
         return int(lib().hvq_stream_pic_bytes(self._h, sid))
 

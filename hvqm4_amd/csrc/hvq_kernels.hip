@@ -380,6 +380,43 @@ typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 /* not `volatile`: a volatile asm counts as a store to anything, and every scalar load after it would become a vector load */
 #define HVQ_PIN(x) do { x = (u32)__builtin_amdgcn_readfirstlane((int)(x)); asm("" : "+s"(x)); } while (0)
 
+/* What the owning lane of a block does, with its operands resolved, from the block's descriptors (hvq_desc.h "records"): shared by
+ * the queue build (hvq_tileq_kernel) and the reconstruction kernel that derives its queues itself (hvq_recon_inline_kernel). */
+struct BlkSrc { u32 e16, nt, nbt, nlf, nr, mvw; };          /* map entry {value, type << 8}, the four neighbours' entries, the macroblock vector */
+__device__ __forceinline__ u32x2 block_record(u32 tc, bool flat, bool is_pb, bool is15, const BlkSrc &s, i32 bx, i32 by, i32 ws, i32 hs,
+                                              i32 pw, i32 plane_off, i32 slot, u32 ref0_off, u32 ref1_off)
+{
+    const u32 T = s.e16 >> 8;
+    const i32 V = s.e16 & 0xFF;
+    u32 w0 = 0, w1 = (u32)V;
+    if (tc & HVQ_TC_MC) {
+        /* plain MC and the MC part of MC-residual blocks (h4m:1327-1355): half-sample rule per version (h4m:1337-1343) */
+        const i32 rx = (i32)(int16_t)(s.mvw & 0xFFFF), ry = (i32)(int16_t)(s.mvw >> 16);
+        const u32 roff = (((T >> 5) & 3u) == 1u) ? ref0_off : ref1_off;
+        const i32 pdx = rx >> ws, pdy = ry >> hs;
+        const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
+        i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
+        /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
+        a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
+        w0 = roff + (u32)a;
+        w1 |= (HVQ_BR_MC << 8) | ((u32)hx << 10) | ((u32)hy << 11);
+    } else if (tc & HVQ_TC_WDC) {
+        /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
+         * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
+        const u32 Tt = (s.nt & 0x7700u) ? (u32)V : (s.nt & 0xFF);
+        const u32 Bb = (s.nbt & 0x7700u) ? (u32)V : (s.nbt & 0xFF);
+        const u32 Rr = (s.nr & 0x7700u) ? (u32)V : (s.nr & 0xFF);
+        const bool lexp = is_pb ? !(s.nlf & 0x7700u) : ((s.nlf >> 8) == 0 || (s.nlf >> 8) == 8);
+        const u32 Ll = lexp ? (s.nlf & 0xFF) : (u32)V;
+        w0 = Tt | (Bb << 8) | (Ll << 16) | (Rr << 24);
+        w1 |= HVQ_BR_WDC << 8;
+    } else if (flat) {
+        w1 |= HVQ_BR_FLAT << 8;
+    }
+    const u32x2 br = { w0, w1 };
+    return br;
+}
+
 /* ------------------------------------------------------------------------------------------------------
  * Tile queues (hvq_desc.h): once per picture, when its descriptors arrive -- part of the parse stage, not of the
  * reconstruction launches.  One workgroup = one tile; lane = block.  Everything the reconstruction kernel used to derive
@@ -395,16 +432,23 @@ struct TqLoad {                  /* what a lane requests first for its block of 
     u32 e16, nt, nbt, nlf, nr, mvw, wbase, hbvb, pw_sub;
 };
 
+/* LOOP = false: grid (tile pairs, pictures), one pair of tiles per workgroup.  LOOP = true: grid (pictures, splits): workgroup
+ * (p, s) walks the tile pairs s, s + splits, ... of picture p -- the picture's job record, map and vectors stay in the scalar
+ * cache / the L2 of the one XCD all its workgroups run on, and a batch is a single generation of workgroups instead of dozens.
+ * `qbytes` (may be null): bytes of queue data a reconstruction pass reads, summed over the tiles (HvqStats.queue_bytes). */
+template <bool LOOP>
 __global__ __launch_bounds__(HVQ_WG)
-void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
+void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job, unsigned long long *__restrict__ qbytes)
 {
     __shared__ u32 s_cnt[HVQ_TQ_TILES][HVQ_NW][5];
     __shared__ u32 s_meta[HVQ_TQ_TILES][HVQ_TILE_BLOCKS][3];          /* per item: pool index of its first basis | MC flag, window origin, ring offset of its reference */
     __shared__ u32 s_pref[HVQ_TQ_TILES][HVQ_PAIR_CAP_MAX];            /* per pair: item | basis number << 9 */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const HvqJob *__restrict__ J = jobs + first_job + blockIdx.y;
+    const HvqJob *__restrict__ J = jobs + first_job + (LOOP ? blockIdx.x : blockIdx.y);
     const u32 total_tiles = J->total_tiles;
-    if (blockIdx.x * HVQ_TQ_TILES >= total_tiles) return;
+    const u32 wg_step = LOOP ? gridDim.y : 0x40000000u;
+    u32 qb_sum = 0;
+  for (u32 wgx = LOOP ? blockIdx.y : blockIdx.x; wgx * HVQ_TQ_TILES < total_tiles; wgx += wg_step) {
     const u32 flags = J->flags;
     const bool is_pb = ((flags >> HVQ_JOB_KIND_SHIFT) & 3u) != HVQ_PIC_I;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
@@ -417,7 +461,7 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
     TqLoad L[HVQ_TQ_TILES];
 #pragma unroll
     for (int h = 0; h < HVQ_TQ_TILES; ++h) {
-        const u32 tile = blockIdx.x * HVQ_TQ_TILES + (u32)h;
+        const u32 tile = wgx * HVQ_TQ_TILES + (u32)h;
         TqLoad &l = L[h];
         l.live = tile < total_tiles;
         const u32 t = l.live ? tile : total_tiles - 1u;
@@ -445,7 +489,7 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
 #pragma unroll
     for (int h = 0; h < HVQ_TQ_TILES; ++h) {
         const TqLoad &l = L[h];
-        const u32 tile = blockIdx.x * HVQ_TQ_TILES + (u32)h;
+        const u32 tile = wgx * HVQ_TQ_TILES + (u32)h;
         const int p = l.p;
         const i32 bx = l.bx, by = l.by;
         const i32 ws = (i32)((l.pw_sub >> 16) & 0xFFu), hs = (i32)(l.pw_sub >> 24);
@@ -457,35 +501,9 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
         cls[h] = HVQ_TC_CLS(tc); nb[h] = HVQ_TC_NB(tc);
         lit[h] = tc & HVQ_TC_LIT;
         if (l.live) {   /* the block's record: what its owning lane does, operands resolved */
-            const i32 V = e16 & 0xFF;
-            u32 w0 = 0, w1 = (u32)V;
-            if (tc & HVQ_TC_MC) {
-                /* plain MC and the MC part of MC-residual blocks (h4m:1327-1355): half-sample rule per version (h4m:1337-1343) */
-                const bool is15 = flags & HVQ_F_IS15;
-                const i32 pw = (i32)(l.pw_sub & 0xFFFFu);
-                const i32 rx = (i32)(int16_t)(mvw & 0xFFFF), ry = (i32)(int16_t)(mvw >> 16);
-                const u32 roff = (((T >> 5) & 3u) == 1u) ? J->ref0_off : J->ref1_off;
-                const i32 pdx = rx >> ws, pdy = ry >> hs;
-                const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
-                i32 a = (i32)J->plane[p].plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
-                /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
-                a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
-                w0 = roff + (u32)a;
-                w1 |= (HVQ_BR_MC << 8) | ((u32)hx << 10) | ((u32)hy << 11);
-            } else if (tc & HVQ_TC_WDC) {
-                /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
-                 * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
-                const u32 Tt = (l.nt & 0x7700u) ? (u32)V : (l.nt & 0xFF);
-                const u32 Bb = (l.nbt & 0x7700u) ? (u32)V : (l.nbt & 0xFF);
-                const u32 Rr = (l.nr & 0x7700u) ? (u32)V : (l.nr & 0xFF);
-                const bool lexp = is_pb ? !(l.nlf & 0x7700u) : ((l.nlf >> 8) == 0 || (l.nlf >> 8) == 8);
-                const u32 Ll = lexp ? (l.nlf & 0xFF) : (u32)V;
-                w0 = Tt | (Bb << 8) | (Ll << 16) | (Rr << 24);
-                w1 |= HVQ_BR_WDC << 8;
-            } else if (valid && cls[h] == 0 && !lit[h]) {
-                w1 |= HVQ_BR_FLAT << 8;
-            }
-            const u32x2 br = { w0, w1 };
+            const BlkSrc src = { e16, l.nt, l.nbt, l.nlf, l.nr, mvw };
+            const u32x2 br = block_record(tc, valid && cls[h] == 0 && !lit[h], is_pb, (flags & HVQ_F_IS15) != 0, src, bx, by, ws, hs,
+                                          (i32)(l.pw_sub & 0xFFFFu), (i32)J->plane[p].plane_off, slot, J->ref0_off, J->ref1_off);
             ((GLB u32x2 *)(q + J->q_recs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = br;
         }
         off[h] = l.wbase + wave_incl_scan(npay) - npay;
@@ -504,7 +522,7 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
 #pragma unroll
     for (int h = 0; h < HVQ_TQ_TILES; ++h) {
         const TqLoad &l = L[h];
-        const u32 tile = blockIdx.x * HVQ_TQ_TILES + (u32)h;
+        const u32 tile = wgx * HVQ_TQ_TILES + (u32)h;
         u32 tot[5] = { 0, 0, 0, 0, 0 }, mine[5] = { 0, 0, 0, 0, 0 };
 #pragma unroll
         for (int v = 0; v < HVQ_NW; ++v)
@@ -519,6 +537,7 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
             GLB HvqTileQ *t = (GLB HvqTileQ *)q + tile;
             t->w0 = (serial[h] ? 0u : npairs[h]) | (nitems << 16) | (nI ? HVQ_TQ_INTRA : 0u) | (serial[h] ? HVQ_TQ_SERIAL : 0u);
             t->w1 = nlit;
+            qb_sum += 8u + HVQ_TILE_BLOCKS * 8u + nlit * 20u + nitems * 8u + (serial[h] ? 0u : npairs[h] * 8u);
         }
         if (lit[h]) ((GLB u32 *)(q + J->q_lits_off))[(size_t)tile * HVQ_TILE_BLOCKS + mine[4] + lanes_below(ml[h])] = (u32)tid | (off[h] << 8);
         if (J->q_offs_off) ((GLB u32 *)(q + J->q_offs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = off[h];     /* for hvq_selfref_kernel */
@@ -561,7 +580,7 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
     for (int h = 0; h < HVQ_TQ_TILES; ++h) {
         const TqLoad &l = L[h];
         if (!l.live) continue;
-        const u32 tile = blockIdx.x * HVQ_TQ_TILES + (u32)h;
+        const u32 tile = wgx * HVQ_TQ_TILES + (u32)h;
         if (cls[h] && it_of[h] < cap_items) {                        /* always: the cap is the picture's largest tile queue */
             /* 8 bytes: owner | map entry, and the two scalars of an MC-residual block as 16-bit values (h4m:1405-1406: the first is
              * (s >> dc_shift) << unk_shift, kept unshifted).  Scalars that do not fit, and every item of a serial tile (whose owner
@@ -597,14 +616,24 @@ void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job)
             dst[pi] = pw01;
         }
     }
+  }     /* no barrier between pairs of tiles: the lists in LDS are rewritten behind the next pair's first barrier, which every thread reaches after its phase 3 */
+    if (qbytes && tid == 0 && qb_sum) atomicAdd(qbytes, (unsigned long long)qb_sum);
 }
 
-extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, hipStream_t stream)
+/* splits = 0: one workgroup per pair of tiles; otherwise `splits` workgroups per picture, each walking its share of the tile pairs */
+extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, uint32_t splits,
+                                       unsigned long long *qbytes_dev, hipStream_t stream)
 {
     if (njobs == 0 || max_tiles == 0) return hipSuccess;
+    const uint32_t npairs = (max_tiles + HVQ_TQ_TILES - 1) / HVQ_TQ_TILES;
+    if (splits) {
+        if (splits > npairs) splits = npairs;
+        hipLaunchKernelGGL(hvq_tileq_kernel<true>, dim3(njobs, splits), dim3(HVQ_WG), 0, stream, jobs_dev, first_job, qbytes_dev);
+        return hipGetLastError();
+    }
     for (uint32_t at = 0; at < njobs; at += 32768u) {
         const uint32_t n = njobs - at < 32768u ? njobs - at : 32768u;
-        hipLaunchKernelGGL(hvq_tileq_kernel, dim3((max_tiles + HVQ_TQ_TILES - 1) / HVQ_TQ_TILES, n), dim3(HVQ_WG), 0, stream, jobs_dev, first_job + at);
+        hipLaunchKernelGGL(hvq_tileq_kernel<false>, dim3(npairs, n), dim3(HVQ_WG), 0, stream, jobs_dev, first_job + at, qbytes_dev);
     }
     return hipGetLastError();
 }
@@ -1208,6 +1237,399 @@ extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_bu
         else if (items_cap <= 128) launch_recon<128, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
         else if (items_cap <= 192) launch_recon<192, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
         else launch_recon<256, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
+    }
+    return hipGetLastError();
+}
+
+
+/* ------------------------------------------------------------------------------------------------------
+ * Reconstruction WITHOUT a queue-build pass (round 4): the workgroup derives its block records, item queue and pair list from
+ * the picture's descriptors itself -- in registers and LDS, nothing of it touches HBM.  The separate hvq_tileq_kernel costs
+ * 0.70 ms per 2048 dense pictures (it writes and the reconstruction re-reads ~0.8 GB) against 1.02 ms for the reconstruction it
+ * feeds; derived in place the same work is a few hundred vector instructions per wave (profiles/r04*).
+ *
+ *   trip 1  the picture's job record (scalar)
+ *   trip 2  per block: map entry with both horizontal neighbours (one unaligned 8-byte load), the vertical neighbours, the
+ *           macroblock vector; per wave: its pool offset (wave_base); the picture's nest share
+ *   then    class from the type byte (computed), block record (block_record), payload offset and pair count by wave scans,
+ *           item and pair slots from two LDS counters (intra items fill the accumulator rows from the bottom, MC-residual items
+ *           from the top: no total is needed before a slot can be handed out -- one barrier instead of two)
+ *   trip 3  motion-compensation rows; the tile's whole pool range, coalesced, into LDS: basis dwords, literal blocks and the
+ *           scalars of MC-residual blocks are read from there, so the pair phase does not start with an HBM miss of its own
+ *   barrier 1, phase B1 (lane = pair: basis dword from LDS, decoded here, nest rows from LDS or window rows from the
+ *   reference), barrier 2, phase B2 (lane = item), barrier 3, phase C exactly as in hvq_recon_kernel.
+ */
+#define HVQ_INL_POOL_ROUNDS 6            /* staged pool dwords per lane (6 x 256 = 1536 dwords at most; the rest is read from HBM) */
+
+template <int ITEMS_CAP, int TPW>
+__global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
+void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 pool_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];       /* [pair_cap] item | pool index << 9, then [pool_cap] staged pool dwords */
+    __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];
+    __shared__ __attribute__((aligned(16))) u32 s_out[TPW][4][HVQ_WG];
+    __shared__ __attribute__((aligned(16))) u32 s_acc[16 * ITEMS_CAP];
+    __shared__ u32 s_item0[ITEMS_CAP];   /* owner (tile of the workgroup * 256 + lane) | map entry << 10 */
+    __shared__ u32 s_item1[ITEMS_CAP];   /* pool index of the block's payload */
+    __shared__ u32 s_item2[ITEMS_CAP];   /* MC-residual items: ring offset of the origin of the 70x38 window (h4m:1865-1868), unclamped part + reference */
+    __shared__ u32 s_ctr[4];             /* intra items, MC-residual items, pairs handed out */
+    u32 *const s_pair = s_dyn;
+    u32 *const s_pool = s_dyn + pair_cap;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
+    const u32 wg = blockIdx.y;
+    const HvqJob *__restrict__ J = jobs + slot_id;
+    const u32 *__restrict__ PW = (const u32 *)&J->plane[0];
+    u32 w0[8], w1[8], w2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w0[i] = PW[i]; w1[i] = PW[8 + i]; w2[i] = PW[16 + i]; }
+    const u32 *__restrict__ CW = (const u32 *)J;
+    u32 cw[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) cw[i] = CW[i];
+    u32 wb_lo = CW[46], wb_hi = CW[47], q_offs_off = CW[49];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { HVQ_PIN(w0[i]); HVQ_PIN(w1[i]); HVQ_PIN(w2[i]); }
+#pragma unroll
+    for (int i = 0; i < 18; ++i) HVQ_PIN(cw[i]);
+    HVQ_PIN(wb_lo); HVQ_PIN(wb_hi); HVQ_PIN(q_offs_off);
+    const u32 total_tiles = cw[17];
+    const u32 n0 = w1[5] - w0[5], n1 = w2[5] - w1[5], n2 = total_tiles - w2[5];
+    const u32 pf1 = (n0 + TPW - 1) / TPW, pf2 = pf1 + (n1 + TPW - 1) / TPW, pend = pf2 + (n2 + TPW - 1) / TPW;
+    if (total_tiles == 0 || wg >= pend) return;                              /* picture dropped by the flush */
+    const int p = (wg >= pf1) + (wg >= pf2);
+    u32 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = p == 0 ? w0[i] : p == 1 ? w1[i] : w2[i];
+    const u32 hbvb = w[6], pw_sub = w[7], tile_first = w[5];
+    const u32 nplane_tiles = p == 0 ? n0 : p == 1 ? n1 : n2;
+    const u32 pairw = wg - (p == 0 ? 0u : p == 1 ? pf1 : pf2);
+    const u32 tile0 = tile_first + (u32)TPW * pairw;
+    const int ntl = (int)min((u32)TPW, nplane_tiles - (u32)TPW * pairw);
+    const uint64_t map_a = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    const uint64_t dst_a = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    const i32 plane_off = (i32)w[4];
+    const i32 hb = (i32)(hbvb & 0xFFFFu);
+    const u32 flags = cw[13];
+    const u32 pic_kind = (flags >> HVQ_JOB_KIND_SHIFT) & 3u;
+    const i32 unk = (i32)((flags >> HVQ_JOB_UNK_SHIFT) & 31u);
+    const bool is_pb = pic_kind != HVQ_PIC_I;
+    const bool landscape = flags & HVQ_F_LANDSCAPE;
+    const bool is15 = flags & HVQ_F_IS15;
+    const u32 nblocks = (u32)hb * (hbvb >> 16);
+    const u32 b0 = (u32)TPW * pairw * HVQ_TILE_BLOCKS;
+    const i32 ws = (i32)((pw_sub >> 16) & 0xFFu), hs = (i32)(pw_sub >> 24);
+    const i32 pw = (i32)(pw_sub & 0xFFFFu);
+    const i32 mstride = hb + 2;
+    const float rhb = 1.0f / (float)hb;
+    const GLB uint8_t *map = (const GLB uint8_t *)map_a;
+    const GLB uint8_t *ring = (const GLB uint8_t *)HVQ_W64(0);
+    const u32 ref0_off = cw[2], ref1_off = cw[3];
+    const GLB u32 *__restrict__ pool = (const GLB u32 *)HVQ_W64(4);
+    const GLB u32 *__restrict__ mvs = (const GLB u32 *)HVQ_W64(6);
+    const GLB uint8_t *__restrict__ qb = (const GLB uint8_t *)HVQ_W64(8);
+    const GLB u32 *__restrict__ nestp = (const GLB u32 *)HVQ_W64(10);
+    const GLB u32 *__restrict__ wave_base = (const GLB u32 *)((uint64_t)wb_lo | ((uint64_t)wb_hi << 32));
+    GLB uint8_t *plane = (GLB uint8_t *)dst_a;
+    const i32 slot = (i32)cw[12];
+    const i32 lw = (i32)cw[14];
+    const i32 mcb_w = (i32)cw[15];
+    const u32 pool_dwords = cw[16];
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane(tid >> 6);
+
+    /* ---- trip 2: the blocks' descriptors, the waves' pool offsets, the tile range of the pool ---- */
+    bool valid[TPW];
+    i32 bx[TPW], by[TPW];
+    uint64_t row8[TPW];
+    u32 nt[TPW], nbt[TPW], mvw[TPW], wbase[TPW];
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        const u32 b = b0 + (u32)(h * HVQ_TILE_BLOCKS + tid);
+        valid[h] = h < ntl && b < nblocks;
+        block_coords(valid[h] ? b : 0u, hb, rhb, bx[h], by[h]);
+        const GLB uint8_t *ent = map + 2 * ((by[h] + 1) * mstride + bx[h] + 1);
+        row8[h] = *(const GLB u64u *)(ent - 2);                       /* left, own, right entries (the map has a border) */
+        nt[h] = *(const GLB uint16_t *)(ent - 2 * mstride); nbt[h] = *(const GLB uint16_t *)(ent + 2 * mstride);
+        mvw[h] = 0;
+        if (is_pb) mvw[h] = mvs[(by[h] >> (1 - hs)) * mcb_w + (bx[h] >> (1 - ws))];
+        wbase[h] = h < ntl ? wave_base[(tile0 + (u32)h) * HVQ_NW + wave] : 0u;
+    }
+    u32 plo = wave_base[tile0 * HVQ_NW];
+    u32 phi = tile0 + (u32)ntl < total_tiles ? wave_base[(tile0 + (u32)ntl) * HVQ_NW] : pool_dwords;
+    const bool has_nest = (HVQ_W64(10) != 0);
+    const bool nest_second = tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4;
+    u32 nq0 = 0, nq1 = 0;
+    if (has_nest) { nq0 = nestp[tid]; if (nest_second) nq1 = nestp[tid + HVQ_WG]; }
+    if (tid < 4) s_ctr[tid] = 0;
+    __syncthreads();                    /* barrier 0: the slot counters are zero before any wave asks them (everything below needs trip 2 anyway) */
+
+    /* ---- classes, records, scans (needs trip 2) ---- */
+    u32x2 brec[TPW];
+    u32 off[TPW], cls[TPW], nb[TPW], e16v[TPW], pincl[TPW];
+    bool lit[TPW];
+    unsigned long long m1[TPW], m2[TPW];
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        const u32 e16 = (u32)(row8[h] >> 16) & 0xFFFFu;
+        e16v[h] = e16;
+        const u32 tc = valid[h] ? hvq_type_class(e16 >> 8, is_pb ? 2 : p == 0 ? 0 : 1) : 0u;
+        const u32 npay = HVQ_TC_NPAY(tc);
+        cls[h] = HVQ_TC_CLS(tc); nb[h] = HVQ_TC_NB(tc);
+        lit[h] = tc & HVQ_TC_LIT;
+        const BlkSrc src = { e16, nt[h], nbt[h], (u32)row8[h] & 0xFFFFu, (u32)(row8[h] >> 32) & 0xFFFFu, mvw[h] };
+        brec[h] = block_record(tc, valid[h] && cls[h] == 0 && !lit[h], is_pb, is15, src, bx[h], by[h], ws, hs, pw, plane_off, slot, ref0_off, ref1_off);
+        off[h] = wbase[h] + wave_incl_scan(npay) - npay;
+        pincl[h] = wave_incl_scan(cls[h] ? nb[h] : 0u);
+        m1[h] = __ballot(cls[h] == 1); m2[h] = __ballot(cls[h] == 2);
+    }
+    if (q_offs_off) {                                                   /* self-referencing P picture: hvq_selfref_kernel wants the pool offsets */
+#pragma unroll
+        for (int h = 0; h < TPW; ++h)
+            if (h < ntl) ((GLB u32 *)(qb + q_offs_off))[(size_t)(tile0 + (u32)h) * HVQ_TILE_BLOCKS + (u32)tid] = off[h];
+    }
+
+    /* ---- trip 3: motion-compensation rows, the tile range of the pool ---- */
+    McRows rows[TPW];
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        if (((brec[h].y >> 8) & 3u) == HVQ_BR_MC) {
+            const u32 vo = brec[h].x;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(y * pw)));
+            rows[h].q[4] = 0;
+            if (brec[h].y & 0x800u) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(4 * pw)));
+        }
+    }
+    phi = max(phi, plo);
+    const u32 nst = min(min(phi - plo, pool_cap), (u32)(HVQ_INL_POOL_ROUNDS * HVQ_WG));     /* staged dwords */
+    u32 sp[HVQ_INL_POOL_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < HVQ_INL_POOL_ROUNDS; ++r) {
+        sp[r] = 0;
+        const u32 j = (u32)(r * HVQ_WG + tid);
+        if (j < nst) sp[r] = pool[plo + j];
+    }
+
+    /* ---- slots: one lane per wave asks the counters (intra items upwards, MC-residual items downwards, pairs) ---- */
+    u32 slotq[TPW], pstart[TPW];
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        const u32 c1 = (u32)__popcll(m1[h]), c2 = (u32)__popcll(m2[h]);
+        const u32 np = (u32)__builtin_amdgcn_readlane((int)pincl[h], 63);
+        u32 b1 = 0, b2 = 0, bp = 0;
+        if (c1 | c2) {
+            if (lane == 0) {
+                if (c1) b1 = __hip_atomic_fetch_add(&s_ctr[0], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (c2) b2 = __hip_atomic_fetch_add(&s_ctr[1], c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                bp = __hip_atomic_fetch_add(&s_ctr[2], np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            b1 = (u32)__builtin_amdgcn_readfirstlane((int)b1); b2 = (u32)__builtin_amdgcn_readfirstlane((int)b2); bp = (u32)__builtin_amdgcn_readfirstlane((int)bp);
+        }
+        slotq[h] = cls[h] == 1 ? b1 + lanes_below(m1[h]) : (u32)ITEMS_CAP - 1u - (b2 + lanes_below(m2[h]));
+        pstart[h] = bp + pincl[h] - nb[h];
+    }
+    /* accumulators zeroed: 16 * ITEMS_CAP dwords, ITEMS_CAP a multiple of 32 */
+    {
+        typedef u32 u32x4z __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (u32 i = (u32)tid; i < 4u * ITEMS_CAP; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
+    }
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        if (cls[h] && slotq[h] < (u32)ITEMS_CAP) {
+            s_item0[slotq[h]] = (u32)(h * HVQ_WG + tid) | (e16v[h] << 10);
+            s_item1[slotq[h]] = off[h];
+            if (cls[h] == 2) {
+                const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFF), ry = (i32)(int16_t)(mvw[h] >> 16);
+                s_item2[slotq[h]] = (u32)(landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16);   /* h4m:1865-1868 */
+            }
+            const u32 bidx = off[h] + (cls[h] == 2 ? 2u : 0u);
+            u32 ent = slotq[h] | (bidx << 9);
+#pragma clang loop unroll(disable) vectorize(disable)
+            for (u32 k = 0; k < nb[h]; ++k, ent += 1u << 9)
+                if (pstart[h] + k < pair_cap) s_pair[pstart[h] + k] = ent;
+        }
+    }
+    if (has_nest) {
+        ((u32 *)s_nest)[tid] = nq0;
+        if (nest_second) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
+    }
+#pragma unroll
+    for (int r = 0; r < HVQ_INL_POOL_ROUNDS; ++r) {
+        const u32 j = (u32)(r * HVQ_WG + tid);
+        if (j < nst) s_pool[j] = sp[r];
+    }
+
+    /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        const u32 act = (brec[h].y >> 8) & 3u;
+        const i32 V = brec[h].y & 0xFF;
+        Blk o;
+        if (act == HVQ_BR_MC) {
+            o = mc_filter(rows[h], (brec[h].y >> 10) & 1, (brec[h].y >> 11) & 1);
+        } else if (act == HVQ_BR_WDC) {
+            const u32 nb4 = brec[h].x;
+            o = weight_block(V, (i32)(nb4 & 0xFF), (i32)((nb4 >> 8) & 0xFF), (i32)((nb4 >> 16) & 0xFF), (i32)(nb4 >> 24));
+        } else if (act == HVQ_BR_FLAT) {
+            const u32 v = (u32)V * 0x01010101u;
+            o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
+        } else continue;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
+    }
+    __syncthreads();                                                           /* barrier 1: queues, staged pool, nest, zeroed accumulators */
+
+    auto pool_at = [&](u32 idx) -> u32 {                                       /* a dword of the payload pool: staged, or (beyond the staging cap) from HBM */
+        const u32 j = idx - plo;
+        return j < nst ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
+    };
+    /* literal blocks (h4m:543-549): the owner copies its 16 samples from the staged pool */
+#pragma unroll
+    for (int h = 0; h < TPW; ++h)
+        if (lit[h]) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) s_out[h][y][tid] = pool_at(off[h] + (u32)y);
+        }
+    const u32 nI = min(s_ctr[0], (u32)ITEMS_CAP), nP = min(s_ctr[1], (u32)ITEMS_CAP - nI), npairs_all = s_ctr[2];
+    const u32 nitems = nI + nP;
+    const bool serial = npairs_all > pair_cap;                                  /* more pairs than the launch reserved (pathological): items walk their bases */
+    const u32 npairs = serial ? 0u : npairs_all;
+
+    if (nitems) {
+        /* ---- phase B1: one lane per (item, basis) pair ---- */
+        const i32 nstride = landscape ? 70 : 38;
+        for (u32 pi = (u32)tid; pi < npairs; pi += HVQ_WG) {
+            const u32 pr = s_pair[pi];
+            const u32 it = pr & 511u;
+            const u32 d = pool_at(pr >> 9);
+            const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;                       /* h4m:683-711 */
+            const u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
+            const bool x2 = landscape ? sl : ss;
+            const u32 y2 = landscape ? ss : sl;
+            const u32 wq0 = (d >> 14) | ((d & 0x2000u) ? HVQ_PQ_NEG : 0u);
+            u32 e[16], lo, hi;
+            if (it >= nI) {
+                const u32 t16 = s_item0[it] >> 10;
+                const u32 roff = ((t16 >> 13) & 3u) == 1u ? ref0_off : ref1_off;
+                const i32 o = landscape ? lw * os + ol : lw * ol + os;
+                const i32 ys = lw << y2;
+                const u32 voff = roff + (u32)clampi((i32)s_item2[it] + o, 0, slot - 8 - 3 * ys);     /* one clamp: legal windows lie inside the slot */
+                uint64_t wq[4];
+                window_load(ring, voff, (u32)ys, wq);
+                window_finish(wq, x2, e, lo, hi);
+            } else {
+                const i32 o = landscape ? nstride * os + ol : nstride * ol + os;
+                gather_nest_q(o, x2, nstride << y2, s_nest, e, lo, hi);
+            }
+            basis_scatter<ITEMS_CAP>(gain_q(wq0, lo, hi), e, s_acc + it);
+        }
+        __syncthreads();                                                       /* barrier 2: accumulators complete */
+        /* ---- phase B2: one lane per item ---- */
+        for (u32 v = (u32)tid; v < nitems; v += HVQ_WG) {
+            const u32 it = v < nI ? v : (u32)ITEMS_CAP - 1u - (v - nI);
+            const u32 item = s_item0[it];
+            const u32 owner = item & 1023u, q16 = item >> 10;
+            const bool item_mc = v >= nI;
+            const u32 poff = s_item1[it];
+            u32 r[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i] = s_acc[i * ITEMS_CAP + it];
+            if (serial) {
+                const u32 kind = (q16 >> 8) & ((is_pb || p != 0) ? 0xFu : 0xFFu);   /* I-picture luma: the kind is the whole byte (h4m:1093) */
+                const u32 n = item_mc ? (kind & 0xFu) - 1u : kind;
+                const u32 bases = poff + (item_mc ? 2u : 0u);
+                const i32 origin = item_mc ? (i32)s_item2[it] : 0;
+                const u32 roff = ((q16 >> 13) & 3u) == 1u ? ref0_off : ref1_off;
+                for (u32 k = 0; k < n; ++k) {
+                    const u32 d = pool_at(bases + k);
+                    u32 e[16], lo, hi;
+                    if (!item_mc) gather_nest(d, landscape, s_nest, e, lo, hi);
+                    else gather_window(d, landscape, ring + roff, origin, lw, slot, e, lo, hi);
+                    const u32 g = basis_gain(d, lo, hi);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) r[i] += g * e[i];
+                }
+            }
+            u32 *so = &s_out[0][0][0] + (owner >> 8) * (4 * HVQ_WG) + (owner & 255u);
+            Blk o;
+            if (item_mc) {
+                Blk m;                                       /* the owner left the MC block in the tile */
+#pragma unroll
+                for (int y = 0; y < 4; ++y) m.r[y] = so[y * HVQ_WG];
+                o = predi_finish(r, m, pool_at(poff), pool_at(poff + 1u), unk);
+            } else {
+                o = intra_finish(r, (i32)(q16 & 0xFF), unk);
+            }
+#pragma unroll
+            for (int y = 0; y < 4; ++y) so[y * HVQ_WG] = o.r[y];
+        }
+    }
+    __syncthreads();                                                           /* barrier 3: tiles complete in LDS */
+
+    /* ---- phase C: tiles -> HBM ---- */
+    const int wv = tid >> 6;
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) {
+        if (h >= ntl) continue;
+        if ((hb & 3) == 0) {
+            const int g = wv * 16 + (lane & 15), rr = lane >> 4;
+            const u32 gb = b0 + (u32)(h * HVQ_TILE_BLOCKS) + 4u * (u32)g;
+            if (gb < nblocks) {
+                i32 gx, gy;
+                block_coords(gb, hb, rhb, gx, gy);
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = *(const u32x4 *)&s_out[h][rr][4 * g];
+                if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
+                else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
+            }
+        } else if (b0 + (u32)(h * HVQ_TILE_BLOCKS + tid) < nblocks) {
+            i32 sx, sy;
+            block_coords(b0 + (u32)(h * HVQ_TILE_BLOCKS + tid), hb, rhb, sx, sy);
+            GLB uint8_t *dst = plane + (size_t)(sy * 4) * pw + sx * 4;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[h][y][tid];
+        }
+    }
+}
+
+template <int ITEMS_CAP, int TPW>
+static void launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_t max_wgs, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream)
+{
+    const dim3 grid = nslots >= 8 ? dim3(8, max_wgs, nslots / 8) : dim3(nslots, max_wgs, 1);
+    hipLaunchKernelGGL((hvq_recon_inline_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), (size_t)(pair_cap + pool_cap) * 4u, stream, jobs_dev, pair_cap, pool_cap);
+}
+
+/* static LDS of hvq_recon_inline_kernel<items_cap, tpw> (the host sizes the dynamic part against the CU's 160 KB) */
+extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t items_cap)
+{
+    return (uint32_t)(HVQ_NESTP_BYTES + 8 + 15) / 16u * 16u + tiles_per_wg * 4u * HVQ_WG * 4u + 64u * items_cap + 12u * items_cap + 16u;
+}
+
+/* as hvq_launch_recon, for pictures without tile queues; pair_cap / pool_cap: dwords of dynamic LDS for the pair list and the staged pool */
+extern "C" hipError_t hvq_launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_t max_wgs, uint32_t tiles_per_wg,
+                                              uint32_t items_cap, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream)
+{
+    if (nslots == 0 || max_wgs == 0) return hipSuccess;
+    if (pair_cap == 0) pair_cap = 1;
+    if (tiles_per_wg >= 2) {
+        if (items_cap <= 32) launch_recon_inline<32, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 64) launch_recon_inline<64, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 96) launch_recon_inline<96, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 128) launch_recon_inline<128, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 192) launch_recon_inline<192, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 256) launch_recon_inline<256, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 384) launch_recon_inline<384, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else launch_recon_inline<512, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+    } else {
+        if (items_cap <= 32) launch_recon_inline<32, 1>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 64) launch_recon_inline<64, 1>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 96) launch_recon_inline<96, 1>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 128) launch_recon_inline<128, 1>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else if (items_cap <= 192) launch_recon_inline<192, 1>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
+        else launch_recon_inline<256, 1>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
     }
     return hipGetLastError();
 }

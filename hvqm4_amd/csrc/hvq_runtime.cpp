@@ -44,7 +44,11 @@ extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
 extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
                                        uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream);
-extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, hipStream_t stream);
+extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, uint32_t splits,
+                                       unsigned long long *qbytes_dev, hipStream_t stream);
+extern "C" hipError_t hvq_launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_t max_wgs, uint32_t tiles_per_wg,
+                                              uint32_t items_cap, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream);
+extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t items_cap);
 extern "C" hipError_t hvq_launch_gather(const uint64_t *src_dev, uint8_t *dst_dev, uint32_t n, uint32_t pic_bytes, hipStream_t stream);
 extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *side, uint8_t *dst, hipStream_t stream);
 extern "C" hipError_t hvq_upload_tables(void);
@@ -167,7 +171,18 @@ struct Launch {
     uint32_t max_wg[2], wgs[2];        /* the same for one / two tiles per workgroup (chosen at flush_end, when the queues are known) */
     uint32_t tpw;
     uint32_t items_cap;                /* LDS sizing of the launch: max over its pictures */
+    bool inline_queues;                /* hvq_recon_inline_kernel: the workgroups derive their queues themselves (no hvq_tileq_kernel pass) */
+    uint32_t pair_cap, pool_cap;       /* its dynamic LDS: pair list entries, staged pool dwords */
 };
+
+/* HVQM4_AMD_TILE_QUEUES=1: round 3's two-pass reconstruction (hvq_tileq_kernel builds tile queues in HBM once per picture,
+ * hvq_recon_kernel reads them); default: hvq_recon_inline_kernel derives the queues inside the workgroup (round 4: the queue
+ * build pass cost 0.70 ms per 2048 dense pictures beside 1.02 ms of reconstruction, profiles/r04a_*) */
+static bool use_tile_queues()
+{
+    static const bool on = getenv("HVQM4_AMD_TILE_QUEUES") && atoi(getenv("HVQM4_AMD_TILE_QUEUES")) > 0;
+    return on;
+}
 
 /* a P picture with future-referencing macroblocks, behind the launch of its level: previous content into the destination slot
  * (unless it is there already), then the raster-order walk (hvq_selfref_kernel) from the side buffer */
@@ -224,6 +239,8 @@ struct HvqContext {
     size_t jobs_cap = 0;
     uint8_t *tq_dev = nullptr;         /* tile queues of the resident batch (hvq_tileq_kernel), read by every (re)play */
     size_t tq_cap = 0;
+    uint32_t tq_njobs = 0, tq_max_tiles = 0;   /* the queue build of the resident batch: job table entries, most tiles of a picture */
+    unsigned long long *qbytes_dev = nullptr;  /* bytes of queue data one reconstruction pass reads (summed by the queue build) */
     uint8_t *rb_dev = nullptr;         /* bulk readback: pictures gathered into one buffer, then few large copies */
     size_t rb_cap = 0;
     uint64_t *rb_tab_dev = nullptr, *rb_tab_host = nullptr;   /* their slot addresses (device table, pinned staging) */
@@ -374,6 +391,7 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->ev_read) (void)hipEventDestroy(c->ev_read);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tq_dev) (void)hipFree(c->tq_dev);
+    if (c->qbytes_dev) (void)hipFree(c->qbytes_dev);
     if (c->selfref_dev) (void)hipFree(c->selfref_dev);
     if (c->rb_dev) (void)hipFree(c->rb_dev);
     if (c->rb_tab_dev) (void)hipFree(c->rb_tab_dev);
@@ -926,6 +944,29 @@ static int device_parse_finish(HvqContext *c)
     return HVQ_OK;
 }
 
+/* The queue build of the resident batch (hvq_tileq_kernel).  HVQM4_AMD_TILEQ_SPLITS=n: n workgroups per picture, each walking
+ * its share of the picture's tile pairs (0: one workgroup per pair of tiles); by default a batch of few pictures gets one
+ * workgroup per tile pair (latency of a lone picture) and a large batch a few workgroups per picture. */
+static uint32_t tileq_splits(uint32_t njobs, uint32_t max_tiles)
+{
+    static const int forced = getenv("HVQM4_AMD_TILEQ_SPLITS") ? atoi(getenv("HVQM4_AMD_TILEQ_SPLITS")) : -1;
+    if (forced >= 0) return (uint32_t)forced;
+    (void)njobs; (void)max_tiles;
+    return 0u;
+}
+
+static int run_queue_build(HvqContext *c, bool count_bytes)
+{
+    if (!c->tq_njobs || !use_tile_queues()) return HVQ_OK;
+    if (count_bytes) {
+        if (!c->qbytes_dev) HIPCHK(hipMalloc((void **)&c->qbytes_dev, sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(c->qbytes_dev, 0, sizeof(unsigned long long), c->stream));
+    }
+    HIPCHK(hvq_launch_tileq(c->jobs_dev, 0, c->tq_njobs, c->tq_max_tiles, tileq_splits(c->tq_njobs, c->tq_max_tiles),
+                            count_bytes ? c->qbytes_dev : nullptr, c->stream));
+    return HVQ_OK;
+}
+
 /* enqueue all launches of the resident batch once: the second queue forks from / joins into the main stream */
 static int run_launches(HvqContext *c)
 {
@@ -939,7 +980,8 @@ static int run_launches(HvqContext *c)
     }
     for (auto &L : c->launches) {
         hipStream_t st = L.queue ? c->stream2 : c->stream;
-        HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, st));
+        if (L.inline_queues) HIPCHK(hvq_launch_recon_inline(c->jobs_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, L.pool_cap, st));
+        else HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, st));
         for (const SelfRef &sr : c->selfrefs) {
             if (sr.level != L.level || sr.queue != L.queue) continue;
             if (sr.old_host) HIPCHK(hipMemcpyAsync(sr.dst, sr.old_host, sr.pic_bytes, hipMemcpyHostToDevice, st));
@@ -1125,6 +1167,7 @@ static int flush_end(HvqContext *c)
     const std::vector<HvqTileRef> &slots = c->tiles_host;          /* launch slots in launch order (build_tiles) */
     jobs.assign(slots.size(), HvqJob{});
     std::vector<size_t> tq_off(slots.size(), 0);
+    std::vector<char> has_tq(slots.size(), 0);
     std::vector<uint32_t> slot_of(c->fl_pending.size(), 0);
     size_t tq_bytes = 0, side_bytes = 0;
     uint32_t max_tiles = 0;
@@ -1163,20 +1206,25 @@ static int flush_end(HvqContext *c)
         j.pool_dwords = p.dev ? p.pool_dwords : hd->pool_dwords;
         j.total_tiles = p.dropped ? 0u : hd->tile_first[3];          /* 0: the tile records of this picture become padding entries */
         if (p.dropped) continue;
-        {   /* the picture's tile queues: per tile a record, a literal list, and item and pair lists sized for its fullest tile */
+        {   /* the picture's tile queues (HVQM4_AMD_TILE_QUEUES=1): per tile a record, a literal list, and item and pair lists sized
+             * for its fullest tile.  Without them only a self-referencing P picture needs a section: its blocks' pool offsets */
             const uint32_t nt = hd->tile_first[3];
+            const bool tqm = use_tile_queues();
             /* at least one entry each: the reconstruction kernel requests the first round of every list before it knows the counts */
             /* HVQM4_AMD_PAIR_CAP (tests): a smaller pair list, so that ordinary clips reach the tiles-with-too-many-pairs path
              * (HVQ_TQ_SERIAL: no pair list, the items walk their bases) */
             static const uint32_t pair_cap = getenv("HVQM4_AMD_PAIR_CAP") ? std::min(HVQ_PAIR_CAP_MAX, (uint32_t)std::max(1, atoi(getenv("HVQM4_AMD_PAIR_CAP")))) : HVQ_PAIR_CAP_MAX;
             const uint32_t cap_items = std::max(1u, std::min(256u, (uint32_t)p.max_items)), cap_pairs = std::max(1u, std::min(pair_cap, p.max_pairs));
-            tq_bytes = align_up(tq_bytes, 256);
-            tq_off[k] = tq_bytes;
             const bool selfref = p.kind == HVQ_PIC_P && (hd->flags & HVQ_F_SELF_REF);
-            const size_t recs = align_up((size_t)nt * sizeof(HvqTileQ), 16), lits = recs + (size_t)nt * HVQ_TILE_BLOCKS * 8,
-                         items = lits + (size_t)nt * HVQ_TILE_BLOCKS * 4,
-                         pairs = items + (size_t)nt * cap_items * 8, offs = pairs + (size_t)nt * cap_pairs * 8,
+            const size_t recs = tqm ? align_up((size_t)nt * sizeof(HvqTileQ), 16) : 16, lits = recs + (tqm ? (size_t)nt * HVQ_TILE_BLOCKS * 8 : 0),
+                         items = lits + (tqm ? (size_t)nt * HVQ_TILE_BLOCKS * 4 : 0),
+                         pairs = items + (tqm ? (size_t)nt * cap_items * 8 : 0), offs = pairs + (tqm ? (size_t)nt * cap_pairs * 8 : 0),
                          end = offs + (selfref ? (size_t)nt * HVQ_TILE_BLOCKS * 4 : 0);
+            if (tqm || selfref) {
+                tq_bytes = align_up(tq_bytes, 256);
+                tq_off[k] = tq_bytes;
+                has_tq[k] = 1;
+            }
             if (selfref) {
                 /* the data-parallel pass writes a side buffer; the walk behind this level's launch merges it into the slot */
                 j.q_offs_off = (uint32_t)offs;
@@ -1192,9 +1240,11 @@ static int flush_end(HvqContext *c)
                 c->selfrefs.push_back(sr);
             }
             if (end >= ((size_t)1 << 32)) return fail(HVQ_E_OVERFLOW, "stream %d picture %d: tile queues exceed 4 GiB", p.stream, p.ordinal);
-            j.q_recs_off = (uint32_t)recs; j.q_lits_off = (uint32_t)lits; j.q_items_off = (uint32_t)items; j.q_pairs_off = (uint32_t)pairs;
-            j.q_caps = cap_items | (cap_pairs << 16);
-            tq_bytes += end;
+            if (tqm) {
+                j.q_recs_off = (uint32_t)recs; j.q_lits_off = (uint32_t)lits; j.q_items_off = (uint32_t)items; j.q_pairs_off = (uint32_t)pairs;
+                j.q_caps = cap_items | (cap_pairs << 16);
+            }
+            if (tqm || selfref) tq_bytes += end;
             max_tiles = std::max(max_tiles, nt);
         }
         for (int k = 0; k < 3; ++k) {
@@ -1231,8 +1281,34 @@ static int flush_end(HvqContext *c)
          * two tiles' items would need more than 192 accumulator rows (LDS: fewer than 7 workgroups per CU). */
         static const int force_tpw = getenv("HVQM4_AMD_TILES_PER_WG") ? atoi(getenv("HVQM4_AMD_TILES_PER_WG")) : 0;
         (void)payload; (void)ntl;
-        L.tpw = force_tpw ? (force_tpw >= 2 ? 2u : 1u) : (2u * mi <= 192u ? 2u : 1u);
-        L.items_cap = std::min(256u * L.tpw, std::max(32u, L.tpw * mi));
+        L.inline_queues = !use_tile_queues();
+        if (!L.inline_queues) {
+            L.tpw = force_tpw ? (force_tpw >= 2 ? 2u : 1u) : (2u * mi <= 192u ? 2u : 1u);
+            L.items_cap = std::min(256u * L.tpw, std::max(32u, L.tpw * mi));
+        } else {
+            /* hvq_recon_inline_kernel keeps its item queue, pair list and the tile range of the pool in LDS: accumulator rows
+             * for the fullest tile (x tiles per workgroup), a pair list for its pairs, the staged pool for its bases, scalars and a
+             * few literal blocks (what does not fit is read from HBM; more pairs than the list holds: the items walk their bases).
+             * Two tiles per workgroup when that keeps more tiles resident on a CU (8 workgroups by waves, 160 KB of LDS). */
+            static const uint32_t pair_lim = getenv("HVQM4_AMD_PAIR_CAP") ? (uint32_t)std::max(1, atoi(getenv("HVQM4_AMD_PAIR_CAP"))) : 4096u;
+            auto sized = [&](uint32_t t, uint32_t *cap, uint32_t *pairs, uint32_t *pool) -> uint32_t {
+                static const uint32_t steps2[] = { 32, 64, 96, 128, 192, 256, 384, 512 }, steps1[] = { 32, 64, 96, 128, 192, 256 };
+                const uint32_t want = std::min(256u * t, std::max(32u, t * mi));
+                uint32_t ic = t == 2 ? 512u : 256u;
+                for (uint32_t v : steps2) if (t == 2 && v >= want) { ic = v; break; }
+                for (uint32_t v : steps1) if (t == 1 && v >= want) { ic = v; break; }
+                *cap = ic;
+                *pairs = std::max(1u, std::min(pair_lim, t * mp));
+                *pool = std::min(1536u, t * (mp + 2u * mi + 128u));
+                return (hvq_recon_inline_static_lds(t, ic) + 4u * (*pairs + *pool) + 511u) & ~511u;
+            };
+            uint32_t cap1, pr1, po1, cap2, pr2, po2;
+            const uint32_t lds1 = sized(1, &cap1, &pr1, &po1), lds2 = sized(2, &cap2, &pr2, &po2);
+            const uint32_t res1 = std::min(8u, 163840u / lds1), res2 = 2u * std::min(8u, 163840u / lds2);
+            const bool two = lds2 <= 65536u && (force_tpw ? force_tpw >= 2 : res2 > res1);
+            L.tpw = two ? 2u : 1u;
+            L.items_cap = two ? cap2 : cap1; L.pair_cap = two ? pr2 : pr1; L.pool_cap = two ? po2 : po1;
+        }
         (void)mp;
         L.max_tiles = L.max_wg[L.tpw - 1]; L.workgroups = L.wgs[L.tpw - 1];
         st.workgroups += L.workgroups;
@@ -1255,7 +1331,7 @@ static int flush_end(HvqContext *c)
         c->tq_cap = ncap;
     }
     for (size_t k = 0; k < jobs.size(); ++k)
-        if (jobs[k].total_tiles) jobs[k].tq = (uint64_t)(uintptr_t)(c->tq_dev + tq_off[k]);
+        if (jobs[k].total_tiles && has_tq[k]) jobs[k].tq = (uint64_t)(uintptr_t)(c->tq_dev + tq_off[k]);
     if (side_bytes > c->selfref_cap) {
         if (c->selfref_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->selfref_dev)); c->selfref_dev = nullptr; c->selfref_cap = 0; }
         HIPCHK(hipMalloc((void **)&c->selfref_dev, side_bytes));
@@ -1269,7 +1345,8 @@ static int flush_end(HvqContext *c)
     /* stream-ordered after whatever still reads the previous table */
     { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return rcu; }
     /* 2b. tile queues: once per picture, from the descriptors (type bytes, vectors, basis words) that are now all in HBM */
-    HIPCHK(hvq_launch_tileq(c->jobs_dev, 0, (uint32_t)jobs.size(), max_tiles, c->stream));
+    c->tq_njobs = (uint32_t)jobs.size(); c->tq_max_tiles = max_tiles;
+    { int rcq = run_queue_build(c, true); if (rcq) return rcq; }
     /* 3. one launch per level */
     { int rc = run_launches(c); if (rc) return rc; }
     if (!c->fl_nest_pairs.empty()) {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
@@ -1358,6 +1435,31 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
         }
     }
 #endif
+    return HVQ_OK;
+}
+
+/* hvq_replay with the per-picture queue build inside the repeated region: what = 0 reconstruction launches only (hvq_replay),
+ * 1 queue build + reconstruction launches per repetition (what a new batch costs behind its parse), 2 queue build only */
+HVQ_EXPORT int hvq_replay_stage(HvqContext *c, int reps, int what, float *gpu_ms)
+{
+    if (!c || reps < 0 || what < 0 || what > 2) return fail(HVQ_E_ARG, "bad arguments");
+    if (what == 0) return hvq_replay(c, reps, gpu_ms);
+    { int rc = flush_end(c); if (rc) return rc; }
+    if (c->launches.empty()) return fail(HVQ_E_STATE, "nothing flushed yet");
+    if (!c->selfrefs.empty())
+        return fail(HVQ_E_STATE, "the resident batch holds self-referencing P pictures: their previous buffer content is gone after the first pass");
+    if (!c->pending.empty()) return fail(HVQ_E_STATE, "pictures queued since the last flush");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; ++r) {
+        { int rc = run_queue_build(c, false); if (rc) return rc; }
+        if (what == 1) { int rc = run_launches(c); if (rc) return rc; }
+    }
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (gpu_ms) *gpu_ms = ms;
     return HVQ_OK;
 }
 
@@ -1579,6 +1681,13 @@ HVQ_EXPORT int hvq_get_stats(HvqContext *c, HvqStats *out)
     { int rc = flush_end(c); if (rc) return rc; }
     *out = c->stats;
     out->parse_seconds = c->parse_seconds;
+    if (c->qbytes_dev && c->stats.pictures) {      /* summed on the device by the batch's queue build */
+        unsigned long long q = 0;
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipMemcpyAsync(&q, c->qbytes_dev, sizeof q, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        out->queue_bytes = q;
+    }
     return HVQ_OK;
 }
 
@@ -1660,6 +1769,10 @@ SdkBinding *sdk_bind(SeqObj *seq)
 void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, const void *past, const void *future)
 {
     std::lock_guard<std::mutex> lk(g_sdk_mu);
+    /* HVQM4_AMD_SDK_TIMING=1: where a call's time goes, on stderr (development aid) */
+    static const bool timing = getenv("HVQM4_AMD_SDK_TIMING") != nullptr;
+    double tm[6] = { 0, 0, 0, 0, 0, 0 };
+    if (timing) tm[0] = now_ms();
     SdkBinding *b = sdk_bind(seq);
     if (!b) return;
     HvqContext *c = b->ctx;
@@ -1704,14 +1817,22 @@ void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, con
     s.ring = dst;                                        /* alloc_slot takes the first slot from here that is no anchor */
     b->valid[dst] = false;
     s.sdk_present = ftype == HVQ_FRAME_P ? present : nullptr;   /* a self-referencing P picture reads the caller's buffer (h4m:2058-2061) */
+    if (timing) tm[1] = now_ms();
     int ord = hvq_stream_submit(c, b->stream, ftype, frame, len);
     c->streams[(size_t)b->stream].sdk_present = nullptr;
     if (ord < 0) { sdk_fail(ord); return; }
+    if (timing) tm[2] = now_ms();
     int rc = hvq_flush(c);
     if (rc) { sdk_fail(rc); return; }
+    if (timing) tm[3] = now_ms();
     rc = hvq_read_picture(c, b->stream, ord, present, s.pic_bytes);
     if (rc) { sdk_fail(rc); return; }
     b->host[dst] = present; b->valid[dst] = true;        /* host and device copies are the same now */
+    if (timing) {
+        tm[4] = now_ms();
+        fprintf(stderr, "sdk_decode 0x%x: bind + reference uploads %.3f | host parse %.3f | flush (uploads, launches) %.3f | wait + download %.3f | total %.3f ms\n",
+                ftype, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[4] - tm[0]);
+    }
 }
 
 }  // namespace

@@ -55,6 +55,9 @@ typedef struct HvqStats {
     uint32_t gpu_parse_retried; /* of those, pictures the flat parse path handed to the chain decoder (unusual section layout,
                                    capacities, overflow groups at the caps) -- same result, slower */
     uint32_t dropped;           /* pictures of the batch that were not reconstructed: rejected, or behind a rejected picture of their stream */
+    uint32_t pad0;
+    uint64_t queue_bytes;       /* tile-queue bytes (block records, literal / item / pair lists actually filled) one reconstruction pass
+                                   reads beside the blobs' payload pools: descriptor traffic, not credited in the roofline */
 } HvqStats;
 
 int  hvq_context_create(int device, HvqContext **out);
@@ -99,6 +102,10 @@ int  hvq_sync(HvqContext *ctx);
 /* Re-run the launches of the last flush `reps` times (descriptors already resident in HBM).
  * *gpu_ms = elapsed time between HIP events recorded on the launch stream around all reps. */
 int  hvq_replay(HvqContext *ctx, int reps, float *gpu_ms);
+/* The same with the per-picture queue build (hvq_tileq_kernel: block records, literal / item / pair lists from the descriptors)
+ * inside the repeated region -- what a NEW batch costs behind its parse.  what = 0: reconstruction launches only (= hvq_replay);
+ * 1: queue build + reconstruction launches per repetition; 2: queue build only. */
+int  hvq_replay_stage(HvqContext *ctx, int reps, int what, float *gpu_ms);
 
 /* Copy a still-resident picture (Y|U|V, pic_bytes) to host memory; synchronises. */
 int  hvq_read_picture(HvqContext *ctx, int stream, int ordinal, void *dst, size_t cap);
