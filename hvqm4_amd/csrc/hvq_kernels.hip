@@ -1259,7 +1259,6 @@ extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_bu
  *   barrier 1, phase B1 (lane = pair: basis dword from LDS, decoded here, nest rows from LDS or window rows from the
  *   reference), barrier 2, phase B2 (lane = item), barrier 3, phase C exactly as in hvq_recon_kernel.
  */
-#define HVQ_INL_POOL_ROUNDS 6            /* staged pool dwords per lane (6 x 256 = 1536 dwords at most; the rest is read from HBM) */
 
 template <int ITEMS_CAP, int TPW>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
@@ -1273,6 +1272,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     __shared__ u32 s_item1[ITEMS_CAP];   /* pool index of the block's payload */
     __shared__ u32 s_item2[ITEMS_CAP];   /* MC-residual items: ring offset of the origin of the 70x38 window (h4m:1865-1868), unclamped part + reference */
     __shared__ u32 s_ctr[4];             /* intra items, MC-residual items, pairs handed out */
+    __shared__ u32 s_class[256];         /* block class by type byte for this plane's context (hvq_type_class) */
     u32 *const s_pair = s_dyn;
     u32 *const s_pool = s_dyn + pair_cap;
 
@@ -1339,11 +1339,18 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const u32 pool_dwords = cw[16];
     const u32 wave = (u32)__builtin_amdgcn_readfirstlane(tid >> 6);
 
-    /* ---- trip 2: the blocks' descriptors, the waves' pool offsets, the tile range of the pool ---- */
+    /* ---- trip 2: the blocks' descriptors into registers; the tile range of the pool, the nest and the class table straight
+     * into LDS (LDS-DMA: no registers, and barrier 0 below waits for them with the rest) ---- */
+    if (tid < 4) s_ctr[tid] = 0;
+    u32 plo = wave_base[tile0 * HVQ_NW];
+    u32 phi = tile0 + (u32)ntl < total_tiles ? wave_base[(tile0 + (u32)ntl) * HVQ_NW] : pool_dwords;
+    u32 wbase[TPW];
+#pragma unroll
+    for (int h = 0; h < TPW; ++h) wbase[h] = h < ntl ? wave_base[(tile0 + (u32)h) * HVQ_NW + wave] : 0u;
     bool valid[TPW];
     i32 bx[TPW], by[TPW];
     uint64_t row8[TPW];
-    u32 nt[TPW], nbt[TPW], mvw[TPW], wbase[TPW];
+    u32 nt[TPW], nbt[TPW], mvw[TPW];
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
         const u32 b = b0 + (u32)(h * HVQ_TILE_BLOCKS + tid);
@@ -1354,18 +1361,25 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         nt[h] = *(const GLB uint16_t *)(ent - 2 * mstride); nbt[h] = *(const GLB uint16_t *)(ent + 2 * mstride);
         mvw[h] = 0;
         if (is_pb) mvw[h] = mvs[(by[h] >> (1 - hs)) * mcb_w + (bx[h] >> (1 - ws))];
-        wbase[h] = h < ntl ? wave_base[(tile0 + (u32)h) * HVQ_NW + wave] : 0u;
     }
-    u32 plo = wave_base[tile0 * HVQ_NW];
-    u32 phi = tile0 + (u32)ntl < total_tiles ? wave_base[(tile0 + (u32)ntl) * HVQ_NW] : pool_dwords;
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    {   /* block classes by type byte for this plane's context (hvq_type_class): one LDS read per block instead of ~40 selects */
+        const GLB u32 *tclass = (const GLB u32 *)g_type_class + (is_pb ? 512 : p == 0 ? 0 : 256);
+        __builtin_amdgcn_global_load_lds(tclass + tid, (lds_u32 *)(s_class + wave * 64u), 4, 0, 0);
+    }
     const bool has_nest = (HVQ_W64(10) != 0);
-    const bool nest_second = tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4;
-    u32 nq0 = 0, nq1 = 0;
-    if (has_nest) { nq0 = nestp[tid]; if (nest_second) nq1 = nestp[tid + HVQ_WG]; }
-    if (tid < 4) s_ctr[tid] = 0;
-    __syncthreads();                    /* barrier 0: the slot counters are zero before any wave asks them (everything below needs trip 2 anyway) */
+    if (has_nest) {
+        __builtin_amdgcn_global_load_lds(nestp + tid, (lds_u32 *)((u32 *)s_nest + wave * 64u), 4, 0, 0);
+        if (tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4)
+            __builtin_amdgcn_global_load_lds(nestp + HVQ_WG + tid, (lds_u32 *)((u32 *)s_nest + HVQ_WG + wave * 64u), 4, 0, 0);
+    }
+    phi = max(phi, plo);
+    const u32 nst = min(phi - plo, pool_cap);                          /* staged dwords */
+    for (u32 r0 = 0; r0 < nst; r0 += HVQ_WG)
+        if (r0 + (u32)tid < nst) __builtin_amdgcn_global_load_lds(pool + plo + r0 + (u32)tid, (lds_u32 *)(s_pool + r0 + wave * 64u), 4, 0, 0);
+    __syncthreads();                    /* barrier 0: trip 2 has landed; the slot counters are zero before any wave asks them */
 
-    /* ---- classes, records, scans (needs trip 2) ---- */
+    /* ---- classes, records, scans ---- */
     u32x2 brec[TPW];
     u32 off[TPW], cls[TPW], nb[TPW], e16v[TPW], pincl[TPW];
     bool lit[TPW];
@@ -1374,7 +1388,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     for (int h = 0; h < TPW; ++h) {
         const u32 e16 = (u32)(row8[h] >> 16) & 0xFFFFu;
         e16v[h] = e16;
-        const u32 tc = valid[h] ? hvq_type_class(e16 >> 8, is_pb ? 2 : p == 0 ? 0 : 1) : 0u;
+        const u32 tc = valid[h] ? s_class[e16 >> 8] : 0u;
         const u32 npay = HVQ_TC_NPAY(tc);
         cls[h] = HVQ_TC_CLS(tc); nb[h] = HVQ_TC_NB(tc);
         lit[h] = tc & HVQ_TC_LIT;
@@ -1390,7 +1404,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             if (h < ntl) ((GLB u32 *)(qb + q_offs_off))[(size_t)(tile0 + (u32)h) * HVQ_TILE_BLOCKS + (u32)tid] = off[h];
     }
 
-    /* ---- trip 3: motion-compensation rows, the tile range of the pool ---- */
+    /* ---- trip 3: motion-compensation rows ---- */
     McRows rows[TPW];
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
@@ -1401,15 +1415,6 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             rows[h].q[4] = 0;
             if (brec[h].y & 0x800u) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(4 * pw)));
         }
-    }
-    phi = max(phi, plo);
-    const u32 nst = min(min(phi - plo, pool_cap), (u32)(HVQ_INL_POOL_ROUNDS * HVQ_WG));     /* staged dwords */
-    u32 sp[HVQ_INL_POOL_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < HVQ_INL_POOL_ROUNDS; ++r) {
-        sp[r] = 0;
-        const u32 j = (u32)(r * HVQ_WG + tid);
-        if (j < nst) sp[r] = pool[plo + j];
     }
 
     /* ---- slots: one lane per wave asks the counters (intra items upwards, MC-residual items downwards, pairs) ---- */
@@ -1452,15 +1457,10 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                 if (pstart[h] + k < pair_cap) s_pair[pstart[h] + k] = ent;
         }
     }
-    if (has_nest) {
-        ((u32 *)s_nest)[tid] = nq0;
-        if (nest_second) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
-    }
-#pragma unroll
-    for (int r = 0; r < HVQ_INL_POOL_ROUNDS; ++r) {
-        const u32 j = (u32)(r * HVQ_WG + tid);
-        if (j < nst) s_pool[j] = sp[r];
-    }
+    auto pool_at = [&](u32 idx) -> u32 {                                       /* a dword of the payload pool: staged, or (beyond the staging cap) from HBM */
+        const u32 j = idx - plo;
+        return j < nst ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
+    };
 
     /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
 #pragma unroll
@@ -1476,23 +1476,15 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         } else if (act == HVQ_BR_FLAT) {
             const u32 v = (u32)V * 0x01010101u;
             o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
+        } else if (lit[h]) {                                                   /* literal block (h4m:543-549): 16 samples from the staged pool */
+#pragma unroll
+            for (int y = 0; y < 4; ++y) o.r[y] = pool_at(off[h] + (u32)y);
         } else continue;
 #pragma unroll
         for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
     }
-    __syncthreads();                                                           /* barrier 1: queues, staged pool, nest, zeroed accumulators */
+    __syncthreads();                                                           /* barrier 1: queues, zeroed accumulators */
 
-    auto pool_at = [&](u32 idx) -> u32 {                                       /* a dword of the payload pool: staged, or (beyond the staging cap) from HBM */
-        const u32 j = idx - plo;
-        return j < nst ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
-    };
-    /* literal blocks (h4m:543-549): the owner copies its 16 samples from the staged pool */
-#pragma unroll
-    for (int h = 0; h < TPW; ++h)
-        if (lit[h]) {
-#pragma unroll
-            for (int y = 0; y < 4; ++y) s_out[h][y][tid] = pool_at(off[h] + (u32)y);
-        }
     const u32 nI = min(s_ctr[0], (u32)ITEMS_CAP), nP = min(s_ctr[1], (u32)ITEMS_CAP - nI), npairs_all = s_ctr[2];
     const u32 nitems = nI + nP;
     const bool serial = npairs_all > pair_cap;                                  /* more pairs than the launch reserved (pathological): items walk their bases */
@@ -1605,7 +1597,7 @@ static void launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_
 /* static LDS of hvq_recon_inline_kernel<items_cap, tpw> (the host sizes the dynamic part against the CU's 160 KB) */
 extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t items_cap)
 {
-    return (uint32_t)(HVQ_NESTP_BYTES + 8 + 15) / 16u * 16u + tiles_per_wg * 4u * HVQ_WG * 4u + 64u * items_cap + 12u * items_cap + 16u;
+    return (uint32_t)(HVQ_NESTP_BYTES + 8 + 15) / 16u * 16u + tiles_per_wg * 4u * HVQ_WG * 4u + 64u * items_cap + 12u * items_cap + 16u + 1024u;
 }
 
 /* as hvq_launch_recon, for pictures without tile queues; pair_cap / pool_cap: dwords of dynamic LDS for the pair list and the staged pool */

@@ -1305,7 +1305,8 @@ static int flush_end(HvqContext *c)
             uint32_t cap1, pr1, po1, cap2, pr2, po2;
             const uint32_t lds1 = sized(1, &cap1, &pr1, &po1), lds2 = sized(2, &cap2, &pr2, &po2);
             const uint32_t res1 = std::min(8u, 163840u / lds1), res2 = 2u * std::min(8u, 163840u / lds2);
-            const bool two = lds2 <= 65536u && (force_tpw ? force_tpw >= 2 : res2 > res1);
+            /* measured (profiles/r04b_*): two tiles pay when they double the resident tiles (natural, flat), not for +25 % (dense) */
+            const bool two = lds2 <= 65536u && (force_tpw ? force_tpw >= 2 : 2u * res2 >= 3u * res1);
             L.tpw = two ? 2u : 1u;
             L.items_cap = two ? cap2 : cap1; L.pair_cap = two ? pr2 : pr1; L.pool_cap = two ? po2 : po1;
         }
