@@ -82,6 +82,7 @@ SYMBOLS = {
     "hvq_context_destroy": (None, [C.c_void_p]),
     "hvq_stream_open": (C.c_int, [C.c_void_p] + [C.c_int] * 6),
     "hvq_stream_close": (C.c_int, [C.c_void_p, C.c_int]),
+    "hvq_stream_ring_bytes": (C.c_uint64, [C.c_int] * 5),
     "hvq_stream_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "hvq_submit_many": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p),
                                   C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)]),

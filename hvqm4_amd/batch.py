@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional
 
 import numpy as np
@@ -105,14 +106,14 @@ class Context:
         return out
 
     def pinned_array(self, shape) -> np.ndarray:
-        """uint8 array in pinned host memory (hvq_pinned_alloc); freed with the context"""
+        """uint8 array in pinned host memory (hvq_pinned_alloc).  The memory lives as long as the array or any view of it: it is
+        freed when the last of them is collected, not when the context closes."""
         nbytes = int(np.prod(shape))
         p = lib().hvq_pinned_alloc(nbytes)
         if not p:
-            raise MemoryError("hvq_pinned_alloc failed")
-        self._pinned = getattr(self, "_pinned", [])
-        self._pinned.append(p)
+            raise MemoryError("hvq_pinned_alloc failed: " + lib().hvq_last_error_string().decode(errors="replace"))
         buf = (C.c_uint8 * nbytes).from_address(p)
+        weakref.finalize(buf, lib().hvq_pinned_free, p)         # numpy views keep `buf` alive through their base
         return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
 
     def picture_device_ptr(self, sid: int, ordinal: int) -> int:
@@ -133,9 +134,6 @@ class Context:
 
     def close(self):
         if self._h:
-            for p in getattr(self, "_pinned", []):
-                lib().hvq_pinned_free(p)
-            self._pinned = []
             lib().hvq_context_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -1271,7 +1271,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     __shared__ u32 s_item0[ITEMS_CAP];   /* owner (tile of the workgroup * 256 + lane) | map entry << 10 */
     __shared__ u32 s_item1[ITEMS_CAP];   /* pool index of the block's payload */
     __shared__ u32 s_item2[ITEMS_CAP];   /* MC-residual items: ring offset of the origin of the 70x38 window (h4m:1865-1868), unclamped part + reference */
-    __shared__ u32 s_ctr[4];             /* intra items, MC-residual items, pairs handed out */
+    __shared__ unsigned long long s_ctr64;   /* intra items | MC-residual items << 10 | intra pairs << 20 | MC-residual pairs << 42 handed out */
     __shared__ u32 s_class[256];         /* block class by type byte for this plane's context (hvq_type_class) */
     u32 *const s_pair = s_dyn;
     u32 *const s_pool = s_dyn + pair_cap;
@@ -1341,7 +1341,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 
     /* ---- trip 2: the blocks' descriptors into registers; the tile range of the pool, the nest and the class table straight
      * into LDS (LDS-DMA: no registers, and barrier 0 below waits for them with the rest) ---- */
-    if (tid < 4) s_ctr[tid] = 0;
+    if (tid == 0) s_ctr64 = 0;
     u32 plo = wave_base[tile0 * HVQ_NW];
     u32 phi = tile0 + (u32)ntl < total_tiles ? wave_base[(tile0 + (u32)ntl) * HVQ_NW] : pool_dwords;
     u32 wbase[TPW];
@@ -1381,7 +1381,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 
     /* ---- classes, records, scans ---- */
     u32x2 brec[TPW];
-    u32 off[TPW], cls[TPW], nb[TPW], e16v[TPW], pincl[TPW];
+    u32 off[TPW], cls[TPW], nb[TPW], e16v[TPW], pincl[TPW], pincl2[TPW];
     bool lit[TPW];
     unsigned long long m1[TPW], m2[TPW];
 #pragma unroll
@@ -1395,8 +1395,11 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         const BlkSrc src = { e16, nt[h], nbt[h], (u32)row8[h] & 0xFFFFu, (u32)(row8[h] >> 32) & 0xFFFFu, mvw[h] };
         brec[h] = block_record(tc, valid[h] && cls[h] == 0 && !lit[h], is_pb, is15, src, bx[h], by[h], ws, hs, pw, plane_off, slot, ref0_off, ref1_off);
         off[h] = wbase[h] + wave_incl_scan(npay) - npay;
-        pincl[h] = wave_incl_scan(cls[h] ? nb[h] : 0u);
         m1[h] = __ballot(cls[h] == 1); m2[h] = __ballot(cls[h] == 2);
+        /* pairs of intra items and of MC-residual items are kept apart (intra pairs fill the list from the bottom, the others from
+         * the top): a wave of the pair phase then mostly runs ONE of the two gathers instead of both */
+        pincl[h] = m1[h] ? wave_incl_scan(cls[h] == 1 ? nb[h] : 0u) : 0u;
+        pincl2[h] = m2[h] ? wave_incl_scan(cls[h] == 2 ? nb[h] : 0u) : 0u;
     }
     if (q_offs_off) {                                                   /* self-referencing P picture: hvq_selfref_kernel wants the pool offsets */
 #pragma unroll
@@ -1422,18 +1425,21 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
         const u32 c1 = (u32)__popcll(m1[h]), c2 = (u32)__popcll(m2[h]);
-        const u32 np = (u32)__builtin_amdgcn_readlane((int)pincl[h], 63);
-        u32 b1 = 0, b2 = 0, bp = 0;
+        const u32 np1 = (u32)__builtin_amdgcn_readlane((int)pincl[h], 63), np2 = (u32)__builtin_amdgcn_readlane((int)pincl2[h], 63);
+        /* ONE returning LDS atomic per wave and tile hands out all four ranges: intra items [9:0], MC-residual items [19:10],
+         * intra pairs [41:20], MC-residual pairs [63:42] */
+        u32 b1 = 0, b2 = 0, bp1 = 0, bp2 = 0;
         if (c1 | c2) {
-            if (lane == 0) {
-                if (c1) b1 = __hip_atomic_fetch_add(&s_ctr[0], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (c2) b2 = __hip_atomic_fetch_add(&s_ctr[1], c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                bp = __hip_atomic_fetch_add(&s_ctr[2], np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            b1 = (u32)__builtin_amdgcn_readfirstlane((int)b1); b2 = (u32)__builtin_amdgcn_readfirstlane((int)b2); bp = (u32)__builtin_amdgcn_readfirstlane((int)bp);
+            unsigned long long got = 0;
+            if (lane == 0)
+                got = __hip_atomic_fetch_add(&s_ctr64, (unsigned long long)c1 | ((unsigned long long)c2 << 10) | ((unsigned long long)np1 << 20) | ((unsigned long long)np2 << 42),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32 glo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)got), ghi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(got >> 32));
+            b1 = glo & 1023u; b2 = (glo >> 10) & 1023u;
+            bp1 = (glo >> 20) | ((ghi & 1023u) << 12); bp2 = ghi >> 10;
         }
         slotq[h] = cls[h] == 1 ? b1 + lanes_below(m1[h]) : (u32)ITEMS_CAP - 1u - (b2 + lanes_below(m2[h]));
-        pstart[h] = bp + pincl[h] - nb[h];
+        pstart[h] = cls[h] == 1 ? bp1 + pincl[h] - nb[h] : bp2 + pincl2[h] - nb[h];      /* MC-residual pairs: counted from the top */
     }
     /* accumulators zeroed: 16 * ITEMS_CAP dwords, ITEMS_CAP a multiple of 32 */
     {
@@ -1452,13 +1458,18 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             }
             const u32 bidx = off[h] + (cls[h] == 2 ? 2u : 0u);
             u32 ent = slotq[h] | (bidx << 9);
+            /* list index of the item's first pair and the step to its next one; an index beyond the list wraps to a huge value */
+            u32 pidx = cls[h] == 1 ? pstart[h] : pair_cap - 1u - pstart[h];
+            const u32 pstep = cls[h] == 1 ? 1u : 0xFFFFFFFFu;
 #pragma clang loop unroll(disable) vectorize(disable)
-            for (u32 k = 0; k < nb[h]; ++k, ent += 1u << 9)
-                if (pstart[h] + k < pair_cap) s_pair[pstart[h] + k] = ent;
+            for (u32 k = 0; k < nb[h]; ++k, ent += 1u << 9, pidx += pstep)
+                if (pidx < pair_cap) s_pair[pidx] = ent;
         }
     }
+    const bool all_staged = phi - plo <= pool_cap;                             /* uniform, and true unless a tile's payload exceeds the launch's LDS share */
     auto pool_at = [&](u32 idx) -> u32 {                                       /* a dword of the payload pool: staged, or (beyond the staging cap) from HBM */
         const u32 j = idx - plo;
+        if (all_staged) return s_pool[j];                                       /* every index the descriptors produce lies inside the tile's range */
         return j < nst ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
     };
 
@@ -1485,16 +1496,18 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     }
     __syncthreads();                                                           /* barrier 1: queues, zeroed accumulators */
 
-    const u32 nI = min(s_ctr[0], (u32)ITEMS_CAP), nP = min(s_ctr[1], (u32)ITEMS_CAP - nI), npairs_all = s_ctr[2];
+    const unsigned long long ctr = s_ctr64;
+    const u32 nI = min((u32)ctr & 1023u, (u32)ITEMS_CAP), nP = min((u32)(ctr >> 10) & 1023u, (u32)ITEMS_CAP - nI);
+    const u32 npI = (u32)(ctr >> 20) & 0x3FFFFFu, npM = (u32)(ctr >> 42);
     const u32 nitems = nI + nP;
-    const bool serial = npairs_all > pair_cap;                                  /* more pairs than the launch reserved (pathological): items walk their bases */
-    const u32 npairs = serial ? 0u : npairs_all;
+    const bool serial = npI + npM > pair_cap;                                   /* more pairs than the launch reserved (pathological): items walk their bases */
+    const u32 npairs = serial ? 0u : npI + npM;
 
     if (nitems) {
-        /* ---- phase B1: one lane per (item, basis) pair ---- */
+        /* ---- phase B1: one lane per (item, basis) pair: intra pairs first, then the MC-residual ones ---- */
         const i32 nstride = landscape ? 70 : 38;
-        for (u32 pi = (u32)tid; pi < npairs; pi += HVQ_WG) {
-            const u32 pr = s_pair[pi];
+        for (u32 v = (u32)tid; v < npairs; v += HVQ_WG) {
+            const u32 pr = s_pair[v < npI ? v : pair_cap - 1u - (v - npI)];
             const u32 it = pr & 511u;
             const u32 d = pool_at(pr >> 9);
             const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;                       /* h4m:683-711 */

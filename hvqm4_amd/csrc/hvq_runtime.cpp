@@ -175,13 +175,14 @@ struct Launch {
     uint32_t pair_cap, pool_cap;       /* its dynamic LDS: pair list entries, staged pool dwords */
 };
 
-/* HVQM4_AMD_TILE_QUEUES=1: round 3's two-pass reconstruction (hvq_tileq_kernel builds tile queues in HBM once per picture,
- * hvq_recon_kernel reads them); default: hvq_recon_inline_kernel derives the queues inside the workgroup (round 4: the queue
- * build pass cost 0.70 ms per 2048 dense pictures beside 1.02 ms of reconstruction, profiles/r04a_*) */
-static bool use_tile_queues()
+/* HVQM4_AMD_TILE_QUEUES=1 (read when a context is created): round 3's two-pass reconstruction -- hvq_tileq_kernel builds tile
+ * queues in HBM once per picture, hvq_recon_kernel reads them.  Default: hvq_recon_inline_kernel derives the queues inside the
+ * workgroup (round 4: the queue-build pass cost 0.70 ms per 2048 dense pictures beside 1.02 ms of reconstruction,
+ * profiles/r04a_*). */
+static bool env_tile_queues()
 {
-    static const bool on = getenv("HVQM4_AMD_TILE_QUEUES") && atoi(getenv("HVQM4_AMD_TILE_QUEUES")) > 0;
-    return on;
+    const char *e = getenv("HVQM4_AMD_TILE_QUEUES");
+    return e && atoi(e) > 0;
 }
 
 /* a P picture with future-referencing macroblocks, behind the launch of its level: previous content into the destination slot
@@ -198,6 +199,7 @@ struct SelfRef {
 
 struct HvqContext {
     int device = 0;
+    bool tile_queues = false;          /* two-pass reconstruction over tile queues in HBM (HVQM4_AMD_TILE_QUEUES=1) */
     hipStream_t stream = nullptr, stream2 = nullptr;   /* dependency levels of two halves of the clips overlap */
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     std::vector<Stream> streams;
@@ -305,6 +307,7 @@ static int arena_upload(HvqContext *c, size_t upto)
 }
 
 static int flush_end(HvqContext *c);
+static int flush_abandon(HvqContext *c, int rc);
 
 /* HVQM4_AMD_FLUSH_TIMING=1: host-side timeline of the flush halves on stderr (development aid) */
 static bool flush_timing() { static const bool on = getenv("HVQM4_AMD_FLUSH_TIMING") != nullptr; return on; }
@@ -341,6 +344,7 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     HIPCHK(hipSetDevice(device));
     HvqContext *c = new HvqContext();
     c->device = device;
+    c->tile_queues = env_tile_queues();
     struct Guard { HvqContext *c; ~Guard() { if (c) hvq_context_destroy(c); } } guard{ c };     /* a failing step below frees what exists */
     HIPCHK(hvq_upload_tables());
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -407,6 +411,18 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     delete c;
 }
 
+/* bytes of a stream's picture ring ((nslots + 1) slots: the last one stays zero), 0 for a geometry the parser refuses.  Host only.
+ * Every reference read of the kernels is ring base + 32-bit offset (HvqJob::ref0_off, block records, pair entries): the ring
+ * must stay below 4 GiB, which hvq_stream_open enforces with this number. */
+HVQ_EXPORT uint64_t hvq_stream_ring_bytes(int width, int height, int h_samp, int v_samp, int nslots)
+{
+    HvqParser *p = hvq_parser_create(width, height, h_samp, v_samp, 1);
+    if (!p || nslots < 0) { if (p) hvq_parser_destroy(p); return 0; }
+    const uint64_t slot = align_up((size_t)hvq_parser_pic_bytes(p) + 64, 256);
+    hvq_parser_destroy(p);
+    return ((uint64_t)nslots + 1u) * slot;
+}
+
 HVQ_EXPORT int hvq_stream_open(HvqContext *c, int width, int height, int h_samp, int v_samp, int is15, int nslots)
 {
     if (!c) return fail(HVQ_E_ARG, "null context");
@@ -421,6 +437,11 @@ HVQ_EXPORT int hvq_stream_open(HvqContext *c, int width, int height, int h_samp,
     s.slot_bytes = (uint32_t)align_up((size_t)s.pic_bytes + 64, 256);
     s.slots.resize((size_t)nslots);
     size_t bytes = (size_t)(nslots + 1) * s.slot_bytes;
+    if (bytes >= ((size_t)1 << 32)) {
+        hvq_parser_destroy(p);
+        return fail(HVQ_E_OVERFLOW, "picture ring of %d + 1 slots x %u bytes exceeds 4 GiB (reference reads are ring base + 32-bit offset): open the stream with fewer slots",
+                    nslots, s.slot_bytes);
+    }
     hipError_t e = hipMalloc((void **)&s.dev, bytes);
     if (e != hipSuccess) { hvq_parser_destroy(p); return fail(HVQ_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     e = hipMemsetAsync(s.dev, 0, bytes, c->stream);
@@ -957,7 +978,7 @@ static uint32_t tileq_splits(uint32_t njobs, uint32_t max_tiles)
 
 static int run_queue_build(HvqContext *c, bool count_bytes)
 {
-    if (!c->tq_njobs || !use_tile_queues()) return HVQ_OK;
+    if (!c->tq_njobs || !c->tile_queues) return HVQ_OK;
     if (count_bytes) {
         if (!c->qbytes_dev) HIPCHK(hipMalloc((void **)&c->qbytes_dev, sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(c->qbytes_dev, 0, sizeof(unsigned long long), c->stream));
@@ -1089,10 +1110,36 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
     c->arena_used = 0; c->arena_uploaded = 0; c->arena_waited = false;
     c->fl_active = true;
     if (!rc) rc = build_tiles(c);
-    if (rc) { c->fl_active = false; c->fl_pending.clear(); c->fl_idx.clear(); return rc; }
+    if (rc) return flush_abandon(c, rc);
     if (flush_timing()) fprintf(stderr, "flush_begin %.3f -> %.3f ms\n", tb0, now_ms());
     return HVQ_OK;
 }
+
+/* a flush that fails half way: the pictures of the batch in flight were never reconstructed -- they must not read as resident
+ * (hvq_read_pictures / hvq_picture_device_ptr would otherwise hand out whatever their slots held), and nothing is in flight */
+static int flush_abandon(HvqContext *c, int rc)
+{
+    for (auto &p : c->fl_pending) {
+        Stream &s = c->streams[(size_t)p.stream];
+        if ((size_t)p.ordinal < s.pic_slot.size() && s.pic_slot[(size_t)p.ordinal] == p.dst) {
+            s.pic_slot[(size_t)p.ordinal] = -1;
+            if (p.dst >= 0 && s.slots[(size_t)p.dst].pic == p.ordinal) s.slots[(size_t)p.dst].pic = -1;
+        }
+        s.anchor_old = s.anchor_new = -1;          /* the stream's references are gone with them: it resumes at its next I picture */
+        s.need_I = true;
+    }
+    for (auto &s : c->streams) s.inflight_from = 0x7FFFFFFF;
+    c->fl_active = false;
+    c->fl_pending.clear();
+    c->fl_idx.clear();
+    c->launches.clear();                           /* nothing coherent to replay */
+    return rc;
+}
+#define HIPCHK_FL(expr)                                                                                              \
+    do {                                                                                                             \
+        hipError_t e_ = (expr);                                                                                      \
+        if (e_ != hipSuccess) return flush_abandon(c, fail(HVQ_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)));      \
+    } while (0)
 
 /* Second half: take the parse results, build the job and tile tables, launch the reconstruction. */
 static int flush_end(HvqContext *c)
@@ -1100,7 +1147,7 @@ static int flush_end(HvqContext *c)
     if (!c->fl_active) return HVQ_OK;
     c->fl_active = false;
     const double te0 = now_ms();
-    { int rc = device_parse_finish(c); if (rc) { c->fl_pending.clear(); c->fl_idx.clear(); return rc; } }
+    { int rc = device_parse_finish(c); if (rc) return flush_abandon(c, rc); }
     const double te1 = now_ms();
     /* Judge the GPU-parsed pictures one by one.  A picture the parser could not take (status) or that this back end refuses
      * (unsupported_reason) is dropped together with every later picture of ITS stream in the batch; all other streams are
@@ -1209,7 +1256,7 @@ static int flush_end(HvqContext *c)
         {   /* the picture's tile queues (HVQM4_AMD_TILE_QUEUES=1): per tile a record, a literal list, and item and pair lists sized
              * for its fullest tile.  Without them only a self-referencing P picture needs a section: its blocks' pool offsets */
             const uint32_t nt = hd->tile_first[3];
-            const bool tqm = use_tile_queues();
+            const bool tqm = c->tile_queues;
             /* at least one entry each: the reconstruction kernel requests the first round of every list before it knows the counts */
             /* HVQM4_AMD_PAIR_CAP (tests): a smaller pair list, so that ordinary clips reach the tiles-with-too-many-pairs path
              * (HVQ_TQ_SERIAL: no pair list, the items walk their bases) */
@@ -1239,7 +1286,7 @@ static int flush_end(HvqContext *c)
                 side_bytes += s.slot_bytes;
                 c->selfrefs.push_back(sr);
             }
-            if (end >= ((size_t)1 << 32)) return fail(HVQ_E_OVERFLOW, "stream %d picture %d: tile queues exceed 4 GiB", p.stream, p.ordinal);
+            if (end >= ((size_t)1 << 32)) return flush_abandon(c, fail(HVQ_E_OVERFLOW, "stream %d picture %d: tile queues exceed 4 GiB", p.stream, p.ordinal));
             if (tqm) {
                 j.q_recs_off = (uint32_t)recs; j.q_lits_off = (uint32_t)lits; j.q_items_off = (uint32_t)items; j.q_pairs_off = (uint32_t)pairs;
                 j.q_caps = cap_items | (cap_pairs << 16);
@@ -1281,7 +1328,7 @@ static int flush_end(HvqContext *c)
          * two tiles' items would need more than 192 accumulator rows (LDS: fewer than 7 workgroups per CU). */
         static const int force_tpw = getenv("HVQM4_AMD_TILES_PER_WG") ? atoi(getenv("HVQM4_AMD_TILES_PER_WG")) : 0;
         (void)payload; (void)ntl;
-        L.inline_queues = !use_tile_queues();
+        L.inline_queues = !c->tile_queues;
         if (!L.inline_queues) {
             L.tpw = force_tpw ? (force_tpw >= 2 ? 2u : 1u) : (2u * mi <= 192u ? 2u : 1u);
             L.items_cap = std::min(256u * L.tpw, std::max(32u, L.tpw * mi));
@@ -1299,7 +1346,10 @@ static int flush_end(HvqContext *c)
                 for (uint32_t v : steps1) if (t == 1 && v >= want) { ic = v; break; }
                 *cap = ic;
                 *pairs = std::max(1u, std::min(pair_lim, t * mp));
-                *pool = std::min(1536u, t * (mp + 2u * mi + 128u));
+                /* HVQM4_AMD_POOL_CAP (tests): a smaller staging area, so that ordinary clips reach the read-from-HBM path of tiles
+                 * whose payload exceeds it */
+                static const uint32_t pool_lim = getenv("HVQM4_AMD_POOL_CAP") ? (uint32_t)std::max(0, atoi(getenv("HVQM4_AMD_POOL_CAP"))) : 1536u;
+                *pool = std::min(pool_lim, t * (mp + 2u * mi + 128u));
                 return (hvq_recon_inline_static_lds(t, ic) + 4u * (*pairs + *pool) + 511u) & ~511u;
             };
             uint32_t cap1, pr1, po1, cap2, pr2, po2;
@@ -1321,21 +1371,21 @@ static int flush_end(HvqContext *c)
     st.gpu_parse_retried = st.gpu_parsed ? c->gpu_parse_retried : 0u;
     st.dropped = n_dropped;
     if (jobs.size() > c->jobs_cap) {
-        if (c->jobs_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->jobs_dev)); }
+        if (c->jobs_dev) { HIPCHK_FL(hipStreamSynchronize(c->stream)); HIPCHK_FL(hipFree(c->jobs_dev)); }
         c->jobs_cap = jobs.size() * 2;
-        HIPCHK(hipMalloc((void **)&c->jobs_dev, c->jobs_cap * sizeof(HvqJob)));
+        HIPCHK_FL(hipMalloc((void **)&c->jobs_dev, c->jobs_cap * sizeof(HvqJob)));
     }
     if (tq_bytes > c->tq_cap) {
-        if (c->tq_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->tq_dev)); c->tq_dev = nullptr; c->tq_cap = 0; }
+        if (c->tq_dev) { HIPCHK_FL(hipStreamSynchronize(c->stream)); HIPCHK_FL(hipFree(c->tq_dev)); c->tq_dev = nullptr; c->tq_cap = 0; }
         const size_t ncap = align_up(tq_bytes + tq_bytes / 4, 4096);
-        HIPCHK(hipMalloc((void **)&c->tq_dev, ncap));
+        HIPCHK_FL(hipMalloc((void **)&c->tq_dev, ncap));
         c->tq_cap = ncap;
     }
     for (size_t k = 0; k < jobs.size(); ++k)
         if (jobs[k].total_tiles && has_tq[k]) jobs[k].tq = (uint64_t)(uintptr_t)(c->tq_dev + tq_off[k]);
     if (side_bytes > c->selfref_cap) {
-        if (c->selfref_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->selfref_dev)); c->selfref_dev = nullptr; c->selfref_cap = 0; }
-        HIPCHK(hipMalloc((void **)&c->selfref_dev, side_bytes));
+        if (c->selfref_dev) { HIPCHK_FL(hipStreamSynchronize(c->stream)); HIPCHK_FL(hipFree(c->selfref_dev)); c->selfref_dev = nullptr; c->selfref_cap = 0; }
+        HIPCHK_FL(hipMalloc((void **)&c->selfref_dev, side_bytes));
         c->selfref_cap = side_bytes;
     }
     for (const SelfRef &sr : c->selfrefs)
@@ -1344,18 +1394,18 @@ static int flush_end(HvqContext *c)
             r.dst = (uint64_t)(uintptr_t)(c->selfref_dev + sr.side_off) + r.plane_off;
         }
     /* stream-ordered after whatever still reads the previous table */
-    { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return rcu; }
+    { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return flush_abandon(c, rcu); }
     /* 2b. tile queues: once per picture, from the descriptors (type bytes, vectors, basis words) that are now all in HBM */
     c->tq_njobs = (uint32_t)jobs.size(); c->tq_max_tiles = max_tiles;
-    { int rcq = run_queue_build(c, true); if (rcq) return rcq; }
+    { int rcq = run_queue_build(c, true); if (rcq) return flush_abandon(c, rcq); }
     /* 3. one launch per level */
-    { int rc = run_launches(c); if (rc) return rc; }
+    { int rc = run_launches(c); if (rc) return flush_abandon(c, rc); }
     if (!c->fl_nest_pairs.empty()) {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
-        { int rcu = staged_upload(c, c->fl_arena_id, 3, c->np_dev, c->fl_nest_pairs.data(), c->fl_nest_pairs.size() * sizeof(uint64_t)); if (rcu) return rcu; }
-        HIPCHK(hvq_launch_nest_commit(c->np_dev, (uint32_t)(c->fl_nest_pairs.size() / 2), c->stream));
+        { int rcu = staged_upload(c, c->fl_arena_id, 3, c->np_dev, c->fl_nest_pairs.data(), c->fl_nest_pairs.size() * sizeof(uint64_t)); if (rcu) return flush_abandon(c, rcu); }
+        HIPCHK_FL(hvq_launch_nest_commit(c->np_dev, (uint32_t)(c->fl_nest_pairs.size() / 2), c->stream));
     }
-    HIPCHK(hipEventRecord(c->ev_arena_free[c->fl_arena_id], c->stream));    /* this batch's arena may be refilled after this */
-    HIPCHK(hipEventRecord(c->ev_read, c->stream));                           /* every picture flushed so far is complete behind this */
+    HIPCHK_FL(hipEventRecord(c->ev_arena_free[c->fl_arena_id], c->stream));    /* this batch's arena may be refilled after this */
+    HIPCHK_FL(hipEventRecord(c->ev_read, c->stream));                           /* every picture flushed so far is complete behind this */
     for (auto &s : c->streams) s.inflight_from = 0x7FFFFFFF;
     c->stats = st;
     c->fl_pending.clear();

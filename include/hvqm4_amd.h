@@ -67,6 +67,9 @@ void hvq_context_destroy(HvqContext *ctx);
  * reference rotates exactly 3, h4m:2340-2350; more slots let later pictures start earlier). */
 int  hvq_stream_open(HvqContext *ctx, int width, int height, int h_samp, int v_samp, int is_1_5, int nslots);
 int  hvq_stream_close(HvqContext *ctx, int stream);
+/* Host only: bytes of the picture ring hvq_stream_open would allocate ((nslots + 1) slots; 0: geometry refused).  The kernels
+ * address reference pictures as ring base + 32-bit offset, so hvq_stream_open fails with HVQ_E_OVERFLOW from 4 GiB on. */
+uint64_t hvq_stream_ring_bytes(int width, int height, int h_samp, int v_samp, int nslots);
 
 /* Parse one picture (host) and queue it.  `pic` = picture data after the 4-byte disp_id,
  * `len` its length.  Returns the picture's ordinal in the stream (decode order). */

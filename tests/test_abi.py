@@ -90,3 +90,17 @@ def test_product_does_not_reference_the_oracle():
                 assert "hvqo_" not in text and "hvqd_recon" not in text and "libhvqoracle" not in text, f
                 if f.endswith(".py"):
                     assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_ring_size_is_host_computable_and_bounded():
+    """every reference read of the kernels is ring base + 32-bit offset: hvq_stream_open refuses rings of 4 GiB and more
+    (advisor finding of round 3); the size is computable without a GPU"""
+    from hvqm4_amd._lib import lib
+    l = lib()
+    slot = (640 * 480 * 3 // 2 + 64 + 255) // 256 * 256
+    assert l.hvq_stream_ring_bytes(640, 480, 2, 2, 6) == 7 * slot
+    big = (8192 * 8192 * 3 + 64 + 255) // 256 * 256
+    assert l.hvq_stream_ring_bytes(8192, 8192, 1, 1, 20) == 21 * big < 1 << 32
+    assert l.hvq_stream_ring_bytes(8192, 8192, 1, 1, 21) == 22 * big >= 1 << 32          # hvq_stream_open: HVQ_E_OVERFLOW
+    assert l.hvq_stream_ring_bytes(8192, 8192, 2, 2, 42) >= 1 << 32
+    assert l.hvq_stream_ring_bytes(100, 100, 2, 2, 3) == 0                                # refused geometry

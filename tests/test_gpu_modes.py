@@ -38,6 +38,30 @@ def test_parity_suites_with_tiles_beyond_the_pair_list(cap):
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("cap", ["0", "40"])
+def test_parity_suites_with_tiles_beyond_the_staged_pool(cap):
+    """hvq_recon_inline_kernel stages a tile's range of the payload pool in LDS; a tile whose payload exceeds the launch's share
+    reads the rest from HBM.  With the share capped at 40 dwords most tiles of the parity clips mix both, at 0 nothing is staged."""
+    env = dict(os.environ, HVQM4_AMD_POOL_CAP=cap)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "tests/test_gpu_parity.py", "tests/test_gpu_gparse.py"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("extra", [{}, {"HVQM4_AMD_PAIR_CAP": "24"}, {"HVQM4_AMD_TILES_PER_WG": "1"}], ids=["default", "pair_cap_24", "one_tile"])
+def test_parity_suites_with_the_two_pass_reconstruction(extra):
+    """HVQM4_AMD_TILE_QUEUES=1 keeps round 3's two-pass reconstruction (hvq_tileq_kernel builds tile queues in HBM,
+    hvq_recon_kernel reads them) selectable beside the default hvq_recon_inline_kernel: same pictures."""
+    env = dict(os.environ, HVQM4_AMD_TILE_QUEUES="1", **extra)
+    suites = ["tests/test_gpu_parity.py", "tests/test_gpu_batch.py"] + (["tests/test_gpu_gparse.py", "tests/test_gpu_configs.py"] if not extra else [])
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + suites,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert " passed" in r.stdout
+
+
 def test_gpu_parse_suite_with_the_chains_only():
     """The device entropy parse has two ways to a blob: the flat path (all sections at once, scans) and round 1's chains,
     which the flat path also falls back to per picture.  The default run exercises the flat path; here the GPU-parse suite

@@ -197,3 +197,15 @@ def test_rejection_while_the_next_batch_of_the_stream_is_already_queued(gpu_ctx)
     gpu_ctx.submit_many_device([sb], [gp[1][0]], [gp[1][1]])     # and takes P pictures again without an I picture first
     gpu_ctx.flush()
     gpu_ctx.close_stream(sb); gpu_ctx.close_stream(so)
+
+
+@pytest.mark.gpu
+def test_ring_of_4_gib_is_refused_before_anything_is_allocated(gpu_ctx):
+    """ring-relative 32-bit offsets (HvqJob::ref0_off, MC source offsets, window offsets) must not wrap: 22 slots of an
+    8192x8192 4:4:4 stream are 4.4 GB -- refused with HVQ_E_OVERFLOW, and the context stays usable"""
+    from hvqm4_amd._lib import HVQ_E_OVERFLOW, HvqError
+    with pytest.raises(HvqError) as e:
+        gpu_ctx.open_stream(8192, 8192, 1, 1, True, 21)
+    assert e.value.code == HVQ_E_OVERFLOW
+    sid = gpu_ctx.open_stream(64, 48, 2, 2, True, 4)
+    gpu_ctx.close_stream(sid)

@@ -31,7 +31,9 @@ for lvl in range(nlev):
           f"wait% {100*a['SQ_WAIT_ANY']/a['SQ_WAVE_CYCLES']:3.0f} valu_busy {busy:.2f} ldsconf% {100*b['SQ_LDS_BANK_CONFLICT']/max(1,b['SQ_LDS_IDX_ACTIVE']):3.0f}", end="")
     if d3:
         c = d3[len(d3) - nlev + lvl]
-        clk = c['GRBM_GUI_ACTIVE'] if c.get('GRBM_GUI_ACTIVE') else t[i] * 2400
+        # GRBM_GUI_ACTIVE comes back SUMMED over the 8 XCDs (profiles/r04_ta_calibration.txt: GRBM / (us x 2400) = 8.0 on every
+        # kernel); round 3 divided by it as if it were one clock and printed TA busy 8x too small (0.03-0.10 for what is 0.3-0.8)
+        clk = c['GRBM_GUI_ACTIVE'] / 8.0 if c.get('GRBM_GUI_ACTIVE') else t[i] * 2400
         # TA_*_sum: summed over the 256 texture addressers (one per CU)
         print(f" | TA busy {c['TA_TA_BUSY_sum']/(256*clk):.2f} rd wavefronts/w {c['TA_FLAT_READ_WAVEFRONTS_sum']/w:5.1f} L1 accesses/w {c['TCP_TOTAL_CACHE_ACCESSES_sum']/w:6.0f} "
               f"TCP pending-stall {c['TCP_PENDING_STALL_CYCLES_sum']/(256*clk):.2f}")

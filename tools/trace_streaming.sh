@@ -19,7 +19,7 @@ for f in glob.glob(O+"/t/**/*memory_copy_trace.csv", recursive=True):
 ev.sort()
 # the last 10 parse kernels and what lies between them
 idx=[i for i,e in enumerate(ev) if e[2].startswith("hvq_parse_kernel")]
-lo=idx[-8]
+lo=idx[max(0, len(idx) - 8)]
 t0=ev[lo][0]
 for s,e,n in ev[lo:]:
     if (e-s) > 200000 or n.startswith("hvq_parse"):
