@@ -262,7 +262,6 @@ struct HvqContext {
     uint8_t *gp_dev = nullptr;
     size_t gp_cap = 0;
     HvqParseJob *pj_dev = nullptr;
-    HvqParseResult *pr_dev = nullptr;
     uint64_t *np_dev = nullptr;
     size_t pj_cap = 0;
     double gpu_parse_ms = 0;           /* device time of the parse kernel of the last flush */
@@ -378,7 +377,6 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     }
     if (c->gp_dev) (void)hipFree(c->gp_dev);
     if (c->pj_dev) (void)hipFree(c->pj_dev);
-    if (c->pr_dev) (void)hipFree(c->pr_dev);
     if (c->np_dev) (void)hipFree(c->np_dev);
     if (c->host_arena) (void)hipHostFree(c->host_arena);
     if (c->redo_dev) (void)hipFree(c->redo_dev);
@@ -816,10 +814,9 @@ static int device_parse_launch(HvqContext *c)
         c->gp_cap = need;
     }
     if (idx.size() > c->pj_cap) {
-        if (c->pj_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pj_dev)); HIPCHK(hipFree(c->pr_dev)); HIPCHK(hipFree(c->np_dev)); }
+        if (c->pj_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pj_dev)); HIPCHK(hipFree(c->np_dev)); }
         c->pj_cap = idx.size() * 2;
         HIPCHK(hipMalloc((void **)&c->pj_dev, c->pj_cap * sizeof(HvqParseJob)));
-        HIPCHK(hipMalloc((void **)&c->pr_dev, c->pj_cap * sizeof(HvqParseResult)));
         HIPCHK(hipMalloc((void **)&c->np_dev, c->pj_cap * 2 * sizeof(uint64_t)));
     }
     if (idx.size() > c->pr_host_cap) {
@@ -860,9 +857,12 @@ static int device_parse_launch(HvqContext *c)
     /* HVQM4_AMD_PARSE_FLAT=0: round 1's chains only (the flat path falls back to them by itself where it has to) */
     static const bool use_flat = !(getenv("HVQM4_AMD_PARSE_FLAT") && atoi(getenv("HVQM4_AMD_PARSE_FLAT")) == 0);
     c->fl_rowbuf = rowbuf;
-    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, (uint32_t)jobs.size(), rowbuf, use_flat ? 1u : 0u, nullptr, c->timing_dev, c->stream));
+    /* The parse workgroups write their result records straight into pinned host memory (one 48-byte record per picture).  A
+     * read-back copy queued behind the parse kernel would sit on a DMA engine for the whole parse -- and every second batch the
+     * NEXT batch's bitstream uploads (copy stream) were dealt to that same engine and started only when the parse ended: periods
+     * of 6.2 and 8.4 ms alternating (kernel and copy trace, profiles/r04g_streaming_timeline.txt). */
+    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_host, (uint32_t)jobs.size(), rowbuf, use_flat ? 1u : 0u, nullptr, c->timing_dev, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
-    HIPCHK(hipMemcpyAsync(c->pr_host, c->pr_dev, idx.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev_parse, c->stream));
     return HVQ_OK;
 }
@@ -892,9 +892,8 @@ static int device_parse_finish(HvqContext *c)
             }
             HIPCHK(hipMemcpyAsync(c->redo_dev, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             HIPCHK(hipEventRecord(c->ev0, c->stream));
-            HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_dev, n_redo, c->fl_rowbuf, 0u, c->redo_dev, nullptr, c->stream));
+            HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_host, n_redo, c->fl_rowbuf, 0u, c->redo_dev, nullptr, c->stream));
             HIPCHK(hipEventRecord(c->ev1, c->stream));
-            HIPCHK(hipMemcpyAsync(c->pr_host, c->pr_dev, idx.size() * sizeof(HvqParseResult), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));       /* also keeps `redo` alive until its upload is done */
             float ms2 = 0;
             HIPCHK(hipEventElapsedTime(&ms2, c->ev0, c->ev1));
