@@ -334,6 +334,11 @@ static int staged_upload(HvqContext *c, int id, int which, void *dst, const void
 HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
 {
     if (!out) return fail(HVQ_E_ARG, "null out");
+#if defined(__x86_64__)
+    /* the host entropy parse (hvq_parse.c) is built for x86-64-v3 (csrc/Makefile) */
+    if (!__builtin_cpu_supports("avx2") || !__builtin_cpu_supports("bmi2"))
+        return fail(HVQ_E_ARG, "this build's host entropy parse needs an x86-64-v3 CPU (AVX2, BMI2); rebuild with HOST_ARCH= for older hosts");
+#endif
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -1747,6 +1752,7 @@ namespace {
 constexpr uint64_t SDK_MAGIC = 0x4856514d34414d44ull;   /* "HVQM4AMD" */
 
 struct SdkBinding {
+    std::mutex mu;                     /* one decode at a time per SeqObj; different SeqObjs decode concurrently (each has its own context) */
     HvqContext *ctx = nullptr;
     int stream = -1;
     int w = 0, h = 0, hs = 0, vs = 0, is15 = -1;
@@ -1755,6 +1761,9 @@ struct SdkBinding {
     /* what the three device slots hold: the host buffer whose content was last written there by this library */
     const void *host[3] = { nullptr, nullptr, nullptr };
     bool valid[3] = { false, false, false };
+    /* pinned staging, one picture each: [0], [1] reference pictures on their way up (their DMA runs beside the host parse),
+     * [2] the decoded picture on its way down (one DMA, then one memcpy into the caller's pageable buffer) */
+    uint8_t *stage[3] = { nullptr, nullptr, nullptr };
 };
 
 struct SdkHeader {          /* lives at the start of the caller's work buffer */
@@ -1762,7 +1771,7 @@ struct SdkHeader {          /* lives at the start of the caller's work buffer */
     SdkBinding *binding;
 };
 
-std::mutex g_sdk_mu;
+std::mutex g_sdk_mu;                    /* the registry of bindings and the probe context only */
 HvqContext *g_sdk_ctx = nullptr;
 std::set<SdkBinding *> g_bindings;
 
@@ -1772,59 +1781,93 @@ void sdk_fail(int code)
     fprintf(stderr, "hvqm4_amd: %s\n", g_err.c_str());
 }
 
-HvqContext *sdk_context()
+int sdk_device()
+{
+    const char *dev = getenv("HVQM4_AMD_DEVICE");
+    return dev ? atoi(dev) : 0;
+}
+
+HvqContext *sdk_context()              /* HVQM4InitDecoder: a missing GPU is reported at init time */
 {
     if (g_sdk_ctx) return g_sdk_ctx;
-    const char *dev = getenv("HVQM4_AMD_DEVICE");
-    int rc = hvq_context_create(dev ? atoi(dev) : 0, &g_sdk_ctx);
+    int rc = hvq_context_create(sdk_device(), &g_sdk_ctx);
     if (rc) { sdk_fail(rc); g_sdk_ctx = nullptr; }
     return g_sdk_ctx;
+}
+
+void sdk_free_binding(SdkBinding *b)
+{
+    if (b->ctx) {
+        (void)hipSetDevice(b->ctx->device);
+        (void)hvq_sync(b->ctx);
+        for (auto &p : b->stage) if (p) { (void)hipHostFree(p); p = nullptr; }
+        hvq_context_destroy(b->ctx);            /* closes its stream */
+    }
+    delete b;
 }
 
 void sdk_release_locked(SdkHeader *hd)
 {
     if (hd->magic == SDK_MAGIC && g_bindings.count(hd->binding)) {
         SdkBinding *b = hd->binding;
-        if (b->ctx && b->stream >= 0) hvq_stream_close(b->ctx, b->stream);
         g_bindings.erase(b);
-        delete b;
+        { std::lock_guard<std::mutex> lk(b->mu); }      /* a decode in flight on another thread ends first */
+        sdk_free_binding(b);
     }
     hd->magic = 0; hd->binding = nullptr;
 }
 
-/* (re)open the device stream when the 1.3/1.5 switch byte changed (h4m:2414-2417) */
-SdkBinding *sdk_bind(SeqObj *seq)
+/* the SeqObj's binding, or nullptr + error */
+SdkBinding *sdk_lookup(SeqObj *seq)
 {
+    std::lock_guard<std::mutex> lk(g_sdk_mu);
     if (!seq || !seq->state) { fail(HVQ_E_ARG, "SeqObj has no work buffer (call HVQM4SetBuffer)"); sdk_fail(HVQ_E_ARG); return nullptr; }
     SdkHeader *hd = (SdkHeader *)seq->state;
     if (hd->magic != SDK_MAGIC || !g_bindings.count(hd->binding)) { fail(HVQ_E_STATE, "work buffer was not initialised by HVQM4SetBuffer"); sdk_fail(HVQ_E_STATE); return nullptr; }
-    SdkBinding *b = hd->binding;
-    int is15 = seq->state->padding[0] != 0;
-    if (b->stream >= 0 && b->is15 != is15) { hvq_stream_close(b->ctx, b->stream); b->stream = -1; }
-    if (b->stream < 0) {
-        HvqContext *ctx = sdk_context();
-        if (!ctx) return nullptr;
-        int sid = hvq_stream_open(ctx, b->w, b->h, b->hs, b->vs, is15, 3);
-        if (sid < 0) { sdk_fail(sid); return nullptr; }
-        b->ctx = ctx; b->stream = sid; b->is15 = is15;
-        b->pic_bytes = hvq_stream_pic_bytes(ctx, sid);
-    }
-    return b;
+    return hd->binding;
 }
 
-/* One synchronous picture: upload the caller's reference pictures, reconstruct, read back.
+/* (re)open the device stream when the 1.3/1.5 switch byte changed (h4m:2414-2417); called with the binding's lock held */
+bool sdk_open(SdkBinding *b, SeqObj *seq)
+{
+    const int is15 = seq->state->padding[0] != 0;
+    if (b->stream >= 0 && b->is15 != is15) { hvq_stream_close(b->ctx, b->stream); b->stream = -1; }
+    if (b->stream < 0) {
+        if (!b->ctx) {
+            {   /* the context HVQM4InitDecoder probed the device with serves the first SeqObj */
+                std::lock_guard<std::mutex> lk(g_sdk_mu);
+                b->ctx = g_sdk_ctx; g_sdk_ctx = nullptr;
+            }
+            if (!b->ctx) {
+                int rc = hvq_context_create(sdk_device(), &b->ctx);
+                if (rc) { b->ctx = nullptr; sdk_fail(rc); return false; }
+            }
+        }
+        int sid = hvq_stream_open(b->ctx, b->w, b->h, b->hs, b->vs, is15, 3);
+        if (sid < 0) { sdk_fail(sid); return false; }
+        b->stream = sid; b->is15 = is15;
+        b->pic_bytes = hvq_stream_pic_bytes(b->ctx, sid);
+        for (auto &p : b->stage)
+            if (!p && hipHostMalloc((void **)&p, b->pic_bytes, hipHostMallocDefault) != hipSuccess) p = nullptr;   /* without staging: plain copies */
+        for (int i = 0; i < 3; ++i) b->valid[i] = false;
+    }
+    return true;
+}
+
+/* One synchronous picture: upload the caller's reference pictures, reconstruct, read back.  ONE wait on the GPU per call.
  * HVQM4_AMD_TRUST_PICTURES=1: a reference picture is not uploaded again when `past` / `future` is a host buffer this
  * library itself filled last (as `present` of an earlier call on the same SeqObj) and its device copy is still in place --
  * valid for players that do not touch decoded pictures, which the SDK contract does not promise (hence opt-in). */
 void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, const void *past, const void *future)
 {
-    std::lock_guard<std::mutex> lk(g_sdk_mu);
+    SdkBinding *b = sdk_lookup(seq);
+    if (!b) return;
+    std::lock_guard<std::mutex> lk(b->mu);
     /* HVQM4_AMD_SDK_TIMING=1: where a call's time goes, on stderr (development aid) */
     static const bool timing = getenv("HVQM4_AMD_SDK_TIMING") != nullptr;
     double tm[6] = { 0, 0, 0, 0, 0, 0 };
     if (timing) tm[0] = now_ms();
-    SdkBinding *b = sdk_bind(seq);
-    if (!b) return;
+    if (!sdk_open(b, seq)) return;
     HvqContext *c = b->ctx;
     Stream &s = c->streams[(size_t)b->stream];
     /* the SDK signatures carry no length: it comes from the picture's own section table (hvq_picture_length), so that the
@@ -1832,10 +1875,12 @@ void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, con
     size_t len = 0;
     { int rc = hvq_picture_length(frame, ftype, b->max_frame, &len);
       if (rc) { fail(rc, "malformed picture: a section lies outside the frame"); sdk_fail(rc); return; } }
-    const char *te = getenv("HVQM4_AMD_TRUST_PICTURES");
-    const bool trust = te && atoi(te) > 0;
+    static const bool trust = getenv("HVQM4_AMD_TRUST_PICTURES") && atoi(getenv("HVQM4_AMD_TRUST_PICTURES")) > 0;
     int used[2] = { -1, -1 };
-    /* device slot that holds `src`: the resident copy if trusted, else a slot not already taken, refreshed from the host */
+    /* a call that fails half way leaves uploads in flight and slots half written: nothing on the device is trusted afterwards */
+    struct Undo { SdkBinding *b; HvqContext *c; bool ok; ~Undo() { if (!ok) { (void)hipStreamSynchronize(c->stream); for (auto &v : b->valid) v = false; } } } undo{ b, c, false };
+    /* device slot that holds `src`: the resident copy if trusted, else a slot not already taken, refreshed from the host.  The
+     * upload goes through pinned staging and is asynchronous: it runs while the host parses the picture */
     auto bring = [&](const void *src, int k) -> int {
         int slot = -1;
         if (trust)
@@ -1843,7 +1888,9 @@ void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, con
         if (slot < 0) {
             for (int i = 0; i < 3 && slot < 0; ++i) if (i != used[0] && !(b->valid[i] && trust && (b->host[i] == past || b->host[i] == future))) slot = i;
             if (slot < 0) slot = used[0] == 0 ? 1 : 0;
-            hipError_t e = hipMemcpyAsync(s.slot_ptr(slot), src, s.pic_bytes, hipMemcpyHostToDevice, c->stream);
+            const void *from = src;
+            if (b->stage[k]) { memcpy(b->stage[k], src, s.pic_bytes); from = b->stage[k]; }
+            hipError_t e = hipMemcpyAsync(s.slot_ptr(slot), from, s.pic_bytes, hipMemcpyHostToDevice, c->stream);
             if (e != hipSuccess) { fail(HVQ_E_HIP, "upload of reference picture: %s", hipGetErrorString(e)); sdk_fail(HVQ_E_HIP); return -1; }
             b->host[slot] = src; b->valid[slot] = true;
         }
@@ -1875,9 +1922,19 @@ void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, con
     int rc = hvq_flush(c);
     if (rc) { sdk_fail(rc); return; }
     if (timing) tm[3] = now_ms();
-    rc = hvq_read_picture(c, b->stream, ord, present, s.pic_bytes);
-    if (rc) { sdk_fail(rc); return; }
+    if (b->stage[2]) {
+        /* the picture's DMA is queued behind its launches: one wait for both, then one memcpy into the caller's buffer */
+        const int slot = s.pic_slot[(size_t)ord];
+        hipError_t e = slot < 0 ? hipErrorInvalidValue : hipMemcpyAsync(b->stage[2], s.slot_ptr(slot), s.pic_bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { fail(HVQ_E_HIP, "download of the decoded picture: %s", hipGetErrorString(e)); sdk_fail(HVQ_E_HIP); return; }
+        memcpy(present, b->stage[2], s.pic_bytes);
+    } else {
+        rc = hvq_read_picture(c, b->stream, ord, present, s.pic_bytes);
+        if (rc) { sdk_fail(rc); return; }
+    }
     b->host[dst] = present; b->valid[dst] = true;        /* host and device copies are the same now */
+    undo.ok = true;
     if (timing) {
         tm[4] = now_ms();
         fprintf(stderr, "sdk_decode 0x%x: bind + reference uploads %.3f | host parse %.3f | flush (uploads, launches) %.3f | wait + download %.3f | total %.3f ms\n",

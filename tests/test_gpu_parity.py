@@ -41,6 +41,42 @@ def test_sdk_entry_points_match_oracle(case):
     assert np.array_equal(got, want), _first_diff(got, want)
 
 
+def test_sdk_entry_points_on_four_threads_each_with_its_own_seqobj():
+    """The SDK calls are reentrant per SeqObj: every SeqObj has its own device context and lock, so players on
+    different threads decode concurrently (ctypes releases the GIL inside the calls).  Four clips of different geometry and
+    version, three passes each, every picture against the oracle."""
+    import threading
+    from hvqm4_amd import sdk
+    from hvqm4_amd.container import parse_header, video_pictures
+    from oracle import bridge
+    cases = [clips.SMALL[3], clips.SMALL[4], clips.SMALL[5], clips.MEDIUM[1]]
+    work = []
+    for case in cases:
+        clip = clips.get(case)
+        work.append((clip, bridge.oracle_decode(clip.data, clip.n_pictures), parse_header(clip.data),
+                     [(ft, bytes(pic)) for ft, _d, pic in video_pictures(clip.data)]))
+    errors = []
+
+    def run(k):
+        try:
+            clip, want, hdr, pics = work[k]
+            pl = sdk.Player(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15)
+            for _ in range(3):
+                for i, (ft, pic) in enumerate(pics):
+                    if not np.array_equal(pl.decode(ft, pic), want[i]):
+                        errors.append((cases[k][0], i))
+            pl.close()
+        except Exception as e:                      # noqa: BLE001 -- reported below, on the main thread
+            errors.append((cases[k][0], repr(e)))
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(len(work))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_ring_of_three_slots_matches_reference_rotation(gpu_ctx):
     """nslots=3 reproduces the reference's past/present/future rotation; last pictures stay readable."""
     from hvqm4_amd.container import parse_header, video_pictures
