@@ -8,12 +8,13 @@
  * exists and the whole batch is data-parallel.
  *
  * Integer/byte work, no dense contraction: no MFMA.  Kernels (measurements in DESIGN.md section 5):
- *   hvq_tileq_kernel   once per picture, part of the parse stage: classifies the blocks and leaves per tile a record per block
- *                      (action + resolved operands), the literal list, the AOT items and the fully decoded (item, basis) pairs
- *   hvq_recon_kernel   per dependency level: block records -> flat / weighted-DC / motion-compensated blocks by the owning lane,
- *                      pairs -> nest or window gather, gain, 16 products -> LDS accumulators (ds_add), items -> samples;
+ *   hvq_recon_inline_kernel   per dependency level, the default: descriptors (map, vectors, payload pool) -> block records, item
+ *                      queue and pair list in registers and LDS -> flat / weighted-DC / motion-compensated blocks by the owning
+ *                      lane, pairs -> nest or window gather, gain, 16 products -> LDS accumulators (ds_add), items -> samples;
  *                      the tile is assembled in LDS and leaves as 16-byte row segments (every store instruction of a wave
  *                      writes four complete 256-byte runs, every output line reaches HBM once and whole)
+ *   hvq_tileq_kernel + hvq_recon_kernel   the two-pass variant (HVQM4_AMD_TILE_QUEUES=1): the queues built once per picture
+ *                      into HBM (a record per block, literal list, AOT items, decoded pairs), then read by the reconstruction
  *   hvq_selfref_kernel P pictures with future-referencing macroblocks: the reference's raster-order walk
  *   hvq_yuv420_rgb_kernel, hvq_gather_kernel   display epilogue, bulk readback
  *   - sample arithmetic is SIMD-within-register: v_lerp_u8 for the 2-tap and 4-tap half-sample filters, 16-bit packed math for
@@ -22,11 +23,10 @@
  *   - reference pictures are addressed LINEARLY inside the Y|U|V buffer exactly like the reference's pointer arithmetic
  *      as ring base + 32-bit offset; every address is clamped to the picture slot so malformed vectors cannot
  *     fault the GPU.
- * What bounds the reconstruction (profiles/r03_ablation.txt): the number of gather requests -- four row segments
- * per 4x4 block in four cache lines, a window per AOT basis at its own place -- beside a VALU that is two fifths busy and a store
- * path that holds a wave's slot until its lines are acknowledged.  Not HBM bytes (a quarter less descriptor traffic: nothing),
- * not latency alone (a round trip less per wave: nothing).  Round 3 cut instructions and dependent hops: nothing is derived in
- * the kernel that can be derived once per picture, and everything a round trip can carry is requested in the same round trip.
+ * What bounds the reconstruction: round 3's two-pass kernel, the number of gather requests -- four row segments
+ * per 4x4 block in four cache lines, a window per AOT basis at its own place -- beside a half-busy VALU; round 4's one-pass
+ * kernel, vector-instruction issue (VALU 0.67-0.79 busy on every dependency level, profiles/r04f_levels.txt): it executes the
+ * queue derivation the two-pass variant pays a whole extra kernel for.
  *
  * Reference behaviour restated per device function (h4m: = h4m_audio_decode.c).
  */
@@ -794,10 +794,13 @@ extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *s
 }
 
 /* ------------------------------------------------------------------------------------------------------
- * Reconstruction.
+ * Reconstruction over tile queues in HBM (round 3; since round 4 the opt-in two-pass variant, HVQM4_AMD_TILE_QUEUES=1 -- the
+ * default is hvq_recon_inline_kernel further down, which derives the same queues inside the workgroup).
  *
- * What bounds this kernel is vector-instruction issue and, on vector-heavy streams, the per-lane address rate of the
- * memory path, so the structure is chosen for the fewest vector instructions per block:
+ * With its queues resident this kernel is the fastest reconstruction (nothing is derived in it: 330 vector instructions per 64
+ * blocks, VALU 0.45 busy); what bounds it is the request rate of its gathers beside a store path that holds a wave's slot until
+ * its lines are acknowledged (profiles/r04_ta_calibration.txt).  But the queue build it needs costs 0.68 ms per
+ * 2048 dense pictures against its own 1.0 ms (profiles/r04a_*): as a stage it is slower than deriving the queues in place.
  *
  * Grid = (picture slots of the launch, tiles); workgroup = TPW tiles of 256 consecutive blocks of one plane.
  *   prologue  the picture's job record and the tiles' queue records come through the scalar cache; every lane requests, at
@@ -1687,8 +1690,10 @@ __global__ __launch_bounds__(256)
 void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
 {
     const HvqRgbJob J = jobs[blockIdx.y];                    /* one picture per grid row */
-    const uint8_t *__restrict__ yuv = J.yuv;
-    uint8_t *__restrict__ rgb = J.rgb;
+    /* global-address-space pointers like the rest of the file: generic ones become flat_* accesses, which count on the LDS
+     * counter too -- and this kernel turns its output around in LDS */
+    const GLB uint8_t *__restrict__ yuv = (const GLB uint8_t *)J.yuv;
+    GLB uint8_t *__restrict__ rgb = (GLB uint8_t *)J.rgb;
     const int w = J.w, h = J.h;
     constexpr int S = WIDE ? 16 : 4;
     const int qw = w / S;                                    /* lanes per row */
@@ -1703,11 +1708,12 @@ void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
         const int li = live ? idx : total - 1;
         const int yr = li / qw, xq = li - yr * qw;
         const int y = 2 * yr;
-        const uint8_t *yp = yuv + (size_t)y * w + S * xq;
-        const uint8_t *up = yuv + (size_t)w * h + (size_t)(y >> 1) * (w >> 1) + (S / 2) * xq;
-        const uint8_t *vp = up + (size_t)(w >> 1) * (h >> 1);
-        const uint4 ya = *(const uint4 *)yp, yb = *(const uint4 *)(yp + w);
-        const uint2 u8 = *(const uint2 *)up, v8 = *(const uint2 *)vp;
+        const GLB uint8_t *yp = yuv + (size_t)y * w + S * xq;
+        const GLB uint8_t *up = yuv + (size_t)w * h + (size_t)(y >> 1) * (w >> 1) + (S / 2) * xq;
+        const GLB uint8_t *vp = up + (size_t)(w >> 1) * (h >> 1);
+        typedef u32 u32x4y __attribute__((ext_vector_type(4)));
+        const u32x4y ya = *(const GLB u32x4y *)yp, yb = *(const GLB u32x4y *)(yp + w);
+        const u32x2 u8 = *(const GLB u32x2 *)up, v8 = *(const GLB u32x2 *)vp;
         const u32 us[4] = { u8.x & 0xFFFFu, u8.x >> 16, u8.y & 0xFFFFu, u8.y >> 16 };
         const u32 vs[4] = { v8.x & 0xFFFFu, v8.x >> 16, v8.y & 0xFFFFu, v8.y >> 16 };
         /* where the three chunks this lane STORES live: chunk c = lane + 64 j belongs to lane c / 3 of the wave */
@@ -1727,7 +1733,7 @@ void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
         typedef u32 u32x4t __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
-            const uint4 y16 = row ? yb : ya;
+            const u32x4y y16 = row ? yb : ya;
             const u32 ys[4] = { y16.x, y16.y, y16.z, y16.w };
             u32 o[12];
 #pragma unroll
@@ -1741,7 +1747,7 @@ void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const u32x4t v = *(const u32x4t *)&s_t[wave][(lane + 64 * j) * 4];
-                if (chunk_live[j]) *(u32x4t *)(rgb + chunk_off[j] + (size_t)row * 3 * w) = v;
+                if (chunk_live[j]) *(GLB u32x4t *)(rgb + chunk_off[j] + (size_t)row * 3 * w) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                 /* the second row overwrites the buffer */
@@ -1750,12 +1756,12 @@ void hvq_yuv420_rgb_kernel(const HvqRgbJob *__restrict__ jobs)
     } else {
         if (idx >= total) return;
         const int yr = idx / qw, xq = idx - yr * qw;
-        const uint8_t *yp = yuv + (size_t)yr * w + S * xq;
-        const uint8_t *up = yuv + (size_t)w * h + (size_t)(yr >> 1) * (w >> 1) + (S / 2) * xq;
-        const uint8_t *vp = up + (size_t)(w >> 1) * (h >> 1);
-        u32 *dst = (u32 *)(rgb + ((size_t)yr * w + S * xq) * 3);
+        const GLB uint8_t *yp = yuv + (size_t)yr * w + S * xq;
+        const GLB uint8_t *up = yuv + (size_t)w * h + (size_t)(yr >> 1) * (w >> 1) + (S / 2) * xq;
+        const GLB uint8_t *vp = up + (size_t)(w >> 1) * (h >> 1);
+        GLB u32 *dst = (GLB u32 *)(rgb + ((size_t)yr * w + S * xq) * 3);
         u32 o[3];
-        rgb4(*(const u32 *)yp, *(const uint16_t *)up, *(const uint16_t *)vp, o);
+        rgb4(*(const GLB u32 *)yp, *(const GLB uint16_t *)up, *(const GLB uint16_t *)vp, o);
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
     }
 }

@@ -64,7 +64,8 @@ class SynthConfig:
     nest_overhang: int = 0            # I pictures: nest window this many columns over the right edge of the block map (<= 2 stays
                                       # inside the reference's bordered array: border entries and the next row's first are read)
     p_future_refs: bool = False       # P pictures may carry type-2 ("future") macroblocks: the reference then reads the
-                                      # picture being written (h4m:2058-2061); this back end rejects such pictures
+                                      # picture being written (h4m:2058-2061); decoded like the reference since round 3
+                                      # (side buffer + raster-order walk, hvq_selfref_kernel)
     seed: int = 0
     preset: str = "dense"             # "dense"  | "realistic" | "flat" | "natural"
     dc_shifts: Sequence[int] = (0, 1, 2)
