@@ -1772,8 +1772,8 @@ __global__ __launch_bounds__(256)
 void hvq_gather_kernel(const uint64_t *__restrict__ src, uint8_t *__restrict__ dst, u32 pic_bytes)
 {
     typedef u32 u32x4g __attribute__((ext_vector_type(4)));
-    const u32x4g *s = (const u32x4g *)(uintptr_t)src[blockIdx.y];
-    u32x4g *d = (u32x4g *)(dst + (size_t)blockIdx.y * pic_bytes);
+    const GLB u32x4g *s = (const GLB u32x4g *)(uintptr_t)src[blockIdx.y];
+    GLB u32x4g *d = (GLB u32x4g *)(dst + (size_t)blockIdx.y * pic_bytes);
     const u32 n16 = pic_bytes / 16u;
     for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) __builtin_nontemporal_store(s[i], d + i);
 }

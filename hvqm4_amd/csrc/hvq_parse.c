@@ -73,8 +73,10 @@ typedef struct {
     int root, next;
     int16_t kid[2][512];
     int32_t leaf[256];
-    uint16_t lut[1 << LUT_BITS];        /* [15:10] bits consumed, [9:0] leaf byte (<256) or node id */
+    uint32_t lut[1 << LUT_BITS];        /* [31:26] bits consumed; bit 25 set: [15:0] the leaf's VALUE (one look-up per symbol);
+                                           bit 25 clear: [24:16] inner node the walk goes on from (codes longer than the table) */
 } Code;
+#define LUT_LEAF (1u << 25)
 
 static int code_node(Code *c, BitRd *b, int is_signed, int scale, int depth)
 {
@@ -98,7 +100,7 @@ static void code_lut(Code *c, int node, int depth, uint32_t prefix)
 {
     if (node < 256 || depth == LUT_BITS) {
         uint32_t lo = prefix << (LUT_BITS - depth), n = 1u << (LUT_BITS - depth);
-        uint16_t e = (uint16_t)((depth << 10) | node);
+        const uint32_t e = ((uint32_t)depth << 26) | (node < 256 ? LUT_LEAF | (uint32_t)(uint16_t)c->leaf[node] : (uint32_t)node << 16);
         for (uint32_t i = 0; i < n; ++i) c->lut[lo + i] = e;
         return;
     }
@@ -116,10 +118,12 @@ static void code_read(Code *c, BitRd *carrier, int is_signed, int scale)     /* 
 static inline int32_t sym(const Code *c, BitRd *b)                            /* h4m:644-651 */
 {
     br_refill(b);
-    uint32_t e = c->lut[b->acc >> (64 - LUT_BITS)];
-    int len = (int)(e >> 10), id = (int)(e & 1023);
+    const uint32_t e = c->lut[b->acc >> (64 - LUT_BITS)];
+    const int len = (int)(e >> 26);
     b->acc <<= len;
     b->cnt -= len;
+    if (__builtin_expect(e & LUT_LEAF, 1)) return (int32_t)(int16_t)e;     /* leaf values are int16 (h4m:613-617) */
+    int id = (int)((e >> 16) & 511u);
     while (id >= 256) {
         if (b->cnt == 0) br_refill(b);
         id = c->kid[b->acc >> 63][id];
