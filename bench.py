@@ -286,6 +286,10 @@ def main():
 
     # One step = what a batch of NEW pictures costs behind its parse: the per-picture queue build (hvq_tileq_kernel: block
     # records, literal / item / pair lists from the descriptors) AND the reconstruction launches of all dependency levels.
+    # untimed pre-roll: the measurement that runs first otherwise reads ~3 % low (the same launches measured a second time come out
+    # faster: clocks still ramping after the host-bound parity check), then the W warm-up steps the contract asks for
+    PREROLL = 20
+    ctx.replay_stage(PREROLL, 1)
     for _ in range(args.warmup):
         ctx.replay_stage(1, 1)
     barrier()
@@ -479,7 +483,7 @@ def main():
             "reconstruction_launches_per_step": launches,
             "workgroups_per_step": int(st.workgroups), "nslots": args.nslots,
             "sharding": "one clip per stream, streams split across GPUs, no collective",
-            "clip_generation_s": round(gen_s, 1),
+            "clip_generation_s": round(gen_s, 1), "untimed_preroll_steps": PREROLL,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

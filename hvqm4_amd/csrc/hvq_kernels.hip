@@ -1536,11 +1536,23 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         }
         __syncthreads();                                                       /* barrier 2: accumulators complete */
         /* ---- phase B2: one lane per item ---- */
-        for (u32 v = (u32)tid; v < nitems; v += HVQ_WG) {
-            const u32 it = v < nI ? v : (u32)ITEMS_CAP - 1u - (v - nI);
+        /* MC-residual items (the expensive epilogue) on the first lanes, intra items on the LAST lanes of the workgroup: with at
+         * most 256 items no wave runs both epilogues unless the two ranges meet inside it, and the two kinds finish side by side */
+        const bool split = nitems <= (u32)HVQ_WG;
+        for (u32 v = (u32)tid; v < (split ? (u32)HVQ_WG : nitems); v += HVQ_WG) {
+            bool item_mc;
+            u32 it;
+            if (split) {
+                const u32 back = (u32)(HVQ_WG - 1) - v;
+                item_mc = v < nP;
+                if (!item_mc && back >= nI) continue;
+                it = item_mc ? (u32)ITEMS_CAP - 1u - v : back;
+            } else {
+                item_mc = v >= nI;
+                it = v < nI ? v : (u32)ITEMS_CAP - 1u - (v - nI);
+            }
             const u32 item = s_item0[it];
             const u32 owner = item & 1023u, q16 = item >> 10;
-            const bool item_mc = v >= nI;
             const u32 poff = s_item1[it];
             u32 r[16];
 #pragma unroll
