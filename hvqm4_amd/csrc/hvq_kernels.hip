@@ -1263,6 +1263,10 @@ extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_bu
  *   reference), barrier 2, phase B2 (lane = item), barrier 3, phase C exactly as in hvq_recon_kernel.
  */
 
+/* BAR0 (two tiles per workgroup): class table in LDS and a barrier behind trip 2.  One tile per workgroup: the class is computed and
+ * the only early barrier stands where nothing is outstanding yet -- dense +1 %; with two tiles the computed classes cost more than the
+ * barrier (natural, flat -3.5 %), profiles/r04_recon_steps.txt */
+#define HVQ_INL_BAR0(TPW) ((TPW) == 2)
 template <int ITEMS_CAP, int TPW>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
 void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 pool_cap)
@@ -1275,7 +1279,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     __shared__ u32 s_item1[ITEMS_CAP];   /* pool index of the block's payload */
     __shared__ u32 s_item2[ITEMS_CAP];   /* MC-residual items: ring offset of the origin of the 70x38 window (h4m:1865-1868), unclamped part + reference */
     __shared__ unsigned long long s_ctr64;   /* intra items | MC-residual items << 10 | intra pairs << 20 | MC-residual pairs << 42 handed out */
-    __shared__ u32 s_class[256];         /* block class by type byte for this plane's context (hvq_type_class) */
+    __shared__ u32 s_class[HVQ_INL_BAR0(TPW) ? 256 : 1];   /* block class by type byte for this plane's context (hvq_type_class) */
     u32 *const s_pair = s_dyn;
     u32 *const s_pool = s_dyn + pair_cap;
 
@@ -1341,10 +1345,16 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const i32 mcb_w = (i32)cw[15];
     const u32 pool_dwords = cw[16];
     const u32 wave = (u32)__builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (!HVQ_INL_BAR0(TPW)) {
+    /* the slot counter is zero before any wave asks it: a barrier HERE, where no vector-memory operation is outstanding yet, instead
+     * of one behind trip 2 that would hold every wave until the slowest wave's loads have landed */
+    if (tid == 0) s_ctr64 = 0;
+    __syncthreads();
+    }
 
     /* ---- trip 2: the blocks' descriptors into registers; the tile range of the pool, the nest and the class table straight
      * into LDS (LDS-DMA: no registers, and barrier 0 below waits for them with the rest) ---- */
-    if (tid == 0) s_ctr64 = 0;
+    if (HVQ_INL_BAR0(TPW) && tid == 0) s_ctr64 = 0;
     u32 plo = wave_base[tile0 * HVQ_NW];
     u32 phi = tile0 + (u32)ntl < total_tiles ? wave_base[(tile0 + (u32)ntl) * HVQ_NW] : pool_dwords;
     u32 wbase[TPW];
@@ -1366,7 +1376,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         if (is_pb) mvw[h] = mvs[(by[h] >> (1 - hs)) * mcb_w + (bx[h] >> (1 - ws))];
     }
     typedef __attribute__((address_space(3))) u32 lds_u32;
-    {   /* block classes by type byte for this plane's context (hvq_type_class): one LDS read per block instead of ~40 selects */
+    if constexpr (HVQ_INL_BAR0(TPW)) {   /* block classes by type byte for this plane's context (hvq_type_class): one LDS read per block instead of ~40 selects */
         const GLB u32 *tclass = (const GLB u32 *)g_type_class + (is_pb ? 512 : p == 0 ? 0 : 256);
         __builtin_amdgcn_global_load_lds(tclass + tid, (lds_u32 *)(s_class + wave * 64u), 4, 0, 0);
     }
@@ -1380,7 +1390,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const u32 nst = min(phi - plo, pool_cap);                          /* staged dwords */
     for (u32 r0 = 0; r0 < nst; r0 += HVQ_WG)
         if (r0 + (u32)tid < nst) __builtin_amdgcn_global_load_lds(pool + plo + r0 + (u32)tid, (lds_u32 *)(s_pool + r0 + wave * 64u), 4, 0, 0);
-    __syncthreads();                    /* barrier 0: trip 2 has landed; the slot counters are zero before any wave asks them */
+    if constexpr (HVQ_INL_BAR0(TPW)) __syncthreads();   /* barrier 0: trip 2 has landed; the slot counters are zero before any wave asks them */
 
     /* ---- classes, records, scans ---- */
     u32x2 brec[TPW];
@@ -1391,9 +1401,12 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     for (int h = 0; h < TPW; ++h) {
         const u32 e16 = (u32)(row8[h] >> 16) & 0xFFFFu;
         e16v[h] = e16;
-        const u32 tc = valid[h] ? s_class[e16 >> 8] : 0u;
+        u32 tc = 0u;
+        if constexpr (HVQ_INL_BAR0(TPW)) tc = valid[h] ? s_class[e16 >> 8] : 0u;
+        else tc = valid[h] ? hvq_type_class(e16 >> 8, is_pb ? 2 : p == 0 ? 0 : 1) : 0u;   /* computed: a table would need a barrier or a dependent load */
         const u32 npay = HVQ_TC_NPAY(tc);
         cls[h] = HVQ_TC_CLS(tc); nb[h] = HVQ_TC_NB(tc);
+        if (HVQ_ABL == 36 || HVQ_ABL == 37) { cls[h] = 0; nb[h] = 0; }          /* timing experiments: no queue derivation, no AOT work at all */
         lit[h] = tc & HVQ_TC_LIT;
         const BlkSrc src = { e16, nt[h], nbt[h], (u32)row8[h] & 0xFFFFu, (u32)(row8[h] >> 32) & 0xFFFFu, mvw[h] };
         brec[h] = block_record(tc, valid[h] && cls[h] == 0 && !lit[h], is_pb, is15, src, bx[h], by[h], ws, hs, pw, plane_off, slot, ref0_off, ref1_off);
@@ -1416,6 +1429,13 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     for (int h = 0; h < TPW; ++h) {
         if (((brec[h].y >> 8) & 3u) == HVQ_BR_MC) {
             const u32 vo = brec[h].x;
+            /* timing experiments (tools/variant.sh <name> -DHVQ_ABL=n; wrong pictures): 31 no phase-A arithmetic, 32 no item epilogues,
+             * 33 no pair work, 34 no motion-compensation row loads, 35 no stores */
+            if (HVQ_ABL == 34 || HVQ_ABL == 37) {
+#pragma unroll
+                for (int y = 0; y < 5; ++y) rows[h].q[y] = (uint64_t)vo * 0x0101010101ull + (uint64_t)y;
+                continue;
+            }
 #pragma unroll
             for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(y * pw)));
             rows[h].q[4] = 0;
@@ -1482,7 +1502,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         const u32 act = (brec[h].y >> 8) & 3u;
         const i32 V = brec[h].y & 0xFF;
         Blk o;
-        if (act == HVQ_BR_MC) {
+        if (HVQ_ABL == 31 && (act == HVQ_BR_MC || act == HVQ_BR_WDC)) {
+            o.r[0] = (u32)rows[h].q[0] ^ brec[h].x; o.r[1] = (u32)rows[h].q[1]; o.r[2] = (u32)rows[h].q[2]; o.r[3] = (u32)(rows[h].q[3] ^ rows[h].q[4]);
+        } else if (act == HVQ_BR_MC) {
             o = mc_filter(rows[h], (brec[h].y >> 10) & 1, (brec[h].y >> 11) & 1);
         } else if (act == HVQ_BR_WDC) {
             const u32 nb4 = brec[h].x;
@@ -1490,21 +1512,30 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         } else if (act == HVQ_BR_FLAT) {
             const u32 v = (u32)V * 0x01010101u;
             o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
-        } else if (lit[h]) {                                                   /* literal block (h4m:543-549): 16 samples from the staged pool */
+        } else if (HVQ_INL_BAR0(TPW) && lit[h]) {                               /* literal block (h4m:543-549): 16 samples from the staged pool */
 #pragma unroll
             for (int y = 0; y < 4; ++y) o.r[y] = pool_at(off[h] + (u32)y);
         } else continue;
 #pragma unroll
         for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
     }
-    __syncthreads();                                                           /* barrier 1: queues, zeroed accumulators */
+    __syncthreads();                                                           /* barrier 1: queues, zeroed accumulators, staged pool and nest */
+    if constexpr (!HVQ_INL_BAR0(TPW)) {
+    /* literal blocks (h4m:543-549): the owner copies its 16 samples from the staged pool (complete only now: other waves staged parts of it) */
+#pragma unroll
+    for (int h = 0; h < TPW; ++h)
+        if (lit[h]) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y) s_out[h][y][tid] = pool_at(off[h] + (u32)y);
+        }
+    }
 
     const unsigned long long ctr = s_ctr64;
     const u32 nI = min((u32)ctr & 1023u, (u32)ITEMS_CAP), nP = min((u32)(ctr >> 10) & 1023u, (u32)ITEMS_CAP - nI);
     const u32 npI = (u32)(ctr >> 20) & 0x3FFFFFu, npM = (u32)(ctr >> 42);
     const u32 nitems = nI + nP;
     const bool serial = npI + npM > pair_cap;                                   /* more pairs than the launch reserved (pathological): items walk their bases */
-    const u32 npairs = serial ? 0u : npI + npM;
+    const u32 npairs = (serial || HVQ_ABL == 33) ? 0u : npI + npM;
 
     if (nitems) {
         /* ---- phase B1: one lane per (item, basis) pair: intra pairs first, then the MC-residual ones ---- */
@@ -1575,7 +1606,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             }
             u32 *so = &s_out[0][0][0] + (owner >> 8) * (4 * HVQ_WG) + (owner & 255u);
             Blk o;
-            if (item_mc) {
+            if (HVQ_ABL == 32) {
+                o.r[0] = r[0] ^ poff; o.r[1] = r[5]; o.r[2] = r[10]; o.r[3] = r[15] ^ q16;
+            } else if (item_mc) {
                 Blk m;                                       /* the owner left the MC block in the tile */
 #pragma unroll
                 for (int y = 0; y < 4; ++y) m.r[y] = so[y * HVQ_WG];
@@ -1590,6 +1623,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     __syncthreads();                                                           /* barrier 3: tiles complete in LDS */
 
     /* ---- phase C: tiles -> HBM ---- */
+    if ((HVQ_ABL == 35 || HVQ_ABL == 37) && s_out[0][0][tid] != 0x12345678u) return;
     const int wv = tid >> 6;
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
@@ -1625,7 +1659,7 @@ static void launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_
 /* static LDS of hvq_recon_inline_kernel<items_cap, tpw> (the host sizes the dynamic part against the CU's 160 KB) */
 extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t items_cap)
 {
-    return (uint32_t)(HVQ_NESTP_BYTES + 8 + 15) / 16u * 16u + tiles_per_wg * 4u * HVQ_WG * 4u + 64u * items_cap + 12u * items_cap + 16u + 1024u;
+    return (uint32_t)(HVQ_NESTP_BYTES + 8 + 15) / 16u * 16u + tiles_per_wg * 4u * HVQ_WG * 4u + 64u * items_cap + 12u * items_cap + 16u + (HVQ_INL_BAR0(tiles_per_wg) ? 1024u : 4u);
 }
 
 /* as hvq_launch_recon, for pictures without tile queues; pair_cap / pool_cap: dwords of dynamic LDS for the pair list and the staged pool */
