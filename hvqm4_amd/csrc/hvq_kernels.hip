@@ -383,13 +383,13 @@ typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 /* What the owning lane of a block does, with its operands resolved, from the block's descriptors (hvq_desc.h "records"): shared by
  * the queue build (hvq_tileq_kernel) and the reconstruction kernel that derives its queues itself (hvq_recon_inline_kernel). */
 struct BlkSrc { u32 e16, nt, nbt, nlf, nr, mvw; };          /* map entry {value, type << 8}, the four neighbours' entries, the macroblock vector */
-__device__ __forceinline__ u32x2 block_record(u32 tc, bool flat, bool is_pb, bool is15, const BlkSrc &s, i32 bx, i32 by, i32 ws, i32 hs,
-                                              i32 pw, i32 plane_off, i32 slot, u32 ref0_off, u32 ref1_off)
+__device__ __forceinline__ u32x2 block_record_b(bool mc, bool wdc, bool flat, bool is_pb, bool is15, const BlkSrc &s, i32 bx, i32 by, i32 ws, i32 hs,
+                                                i32 pw, i32 plane_off, i32 slot, u32 ref0_off, u32 ref1_off)
 {
     const u32 T = s.e16 >> 8;
     const i32 V = s.e16 & 0xFF;
     u32 w0 = 0, w1 = (u32)V;
-    if (tc & HVQ_TC_MC) {
+    if (mc) {
         /* plain MC and the MC part of MC-residual blocks (h4m:1327-1355): half-sample rule per version (h4m:1337-1343) */
         const i32 rx = (i32)(int16_t)(s.mvw & 0xFFFF), ry = (i32)(int16_t)(s.mvw >> 16);
         const u32 roff = (((T >> 5) & 3u) == 1u) ? ref0_off : ref1_off;
@@ -400,7 +400,7 @@ __device__ __forceinline__ u32x2 block_record(u32 tc, bool flat, bool is_pb, boo
         a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
         w0 = roff + (u32)a;
         w1 |= (HVQ_BR_MC << 8) | ((u32)hx << 10) | ((u32)hy << 11);
-    } else if (tc & HVQ_TC_WDC) {
+    } else if (wdc) {
         /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
          * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
         const u32 Tt = (s.nt & 0x7700u) ? (u32)V : (s.nt & 0xFF);
@@ -415,6 +415,11 @@ __device__ __forceinline__ u32x2 block_record(u32 tc, bool flat, bool is_pb, boo
     }
     const u32x2 br = { w0, w1 };
     return br;
+}
+__device__ __forceinline__ u32x2 block_record(u32 tc, bool flat, bool is_pb, bool is15, const BlkSrc &s, i32 bx, i32 by, i32 ws, i32 hs,
+                                              i32 pw, i32 plane_off, i32 slot, u32 ref0_off, u32 ref1_off)
+{
+    return block_record_b(tc & HVQ_TC_MC, tc & HVQ_TC_WDC, flat, is_pb, is15, s, bx, by, ws, hs, pw, plane_off, slot, ref0_off, ref1_off);
 }
 
 /* ------------------------------------------------------------------------------------------------------
@@ -1401,21 +1406,37 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     for (int h = 0; h < TPW; ++h) {
         const u32 e16 = (u32)(row8[h] >> 16) & 0xFFFFu;
         e16v[h] = e16;
-        u32 tc = 0u;
-        if constexpr (HVQ_INL_BAR0(TPW)) tc = valid[h] ? s_class[e16 >> 8] : 0u;
-        else tc = valid[h] ? hvq_type_class(e16 >> 8, is_pb ? 2 : p == 0 ? 0 : 1) : 0u;   /* computed: a table would need a barrier or a dependent load */
-        const u32 npay = HVQ_TC_NPAY(tc);
-        cls[h] = HVQ_TC_CLS(tc); nb[h] = HVQ_TC_NB(tc);
+        u32 npay;
+        bool mcb, wdcb, flatb;
+        if constexpr (HVQ_INL_BAR0(TPW)) {
+            const u32 tc = valid[h] ? s_class[e16 >> 8] : 0u;
+            npay = HVQ_TC_NPAY(tc); cls[h] = HVQ_TC_CLS(tc); nb[h] = HVQ_TC_NB(tc); lit[h] = tc & HVQ_TC_LIT;
+            mcb = tc & HVQ_TC_MC; wdcb = tc & HVQ_TC_WDC; flatb = valid[h] && cls[h] == 0 && !lit[h];
+        } else {
+            /* hvq_type_class, computed without the detour through its packed word (a table would need a barrier or a dependent load) */
+            const u32 T = e16 >> 8;
+            const u32 kind = (!is_pb && p == 0) ? T : (T & 0xFu);                  /* I-picture luma: the whole byte (h4m:1093) */
+            const bool inter = is_pb && (T & 0x60u), proc = T & 0x10u;
+            const bool k0 = kind == 0u, k6 = kind == 6u, k8 = kind == 8u;
+            const bool c1 = valid[h] && !inter && !(k0 | k6 | k8), c2 = valid[h] && inter && !proc && !(k0 | k6);
+            lit[h] = valid[h] && k6 && !(inter && proc);
+            mcb = valid[h] && inter && (proc || !k6); wdcb = valid[h] && !inter && k0; flatb = valid[h] && !inter && k8;
+            cls[h] = c1 ? 1u : c2 ? 2u : 0u;
+            nb[h] = c1 ? kind : c2 ? kind - 1u : 0u;
+            npay = lit[h] ? 4u : c1 ? kind : c2 ? kind + 1u : 0u;
+        }
         if (HVQ_ABL == 36 || HVQ_ABL == 37) { cls[h] = 0; nb[h] = 0; }          /* timing experiments: no queue derivation, no AOT work at all */
-        lit[h] = tc & HVQ_TC_LIT;
         const BlkSrc src = { e16, nt[h], nbt[h], (u32)row8[h] & 0xFFFFu, (u32)(row8[h] >> 32) & 0xFFFFu, mvw[h] };
-        brec[h] = block_record(tc, valid[h] && cls[h] == 0 && !lit[h], is_pb, is15, src, bx[h], by[h], ws, hs, pw, plane_off, slot, ref0_off, ref1_off);
+        brec[h] = block_record_b(mcb, wdcb, flatb, is_pb, is15, src, bx[h], by[h], ws, hs, pw, plane_off, slot, ref0_off, ref1_off);
         off[h] = wbase[h] + wave_incl_scan(npay) - npay;
         m1[h] = __ballot(cls[h] == 1); m2[h] = __ballot(cls[h] == 2);
         /* pairs of intra items and of MC-residual items are kept apart (intra pairs fill the list from the bottom, the others from
-         * the top): a wave of the pair phase then mostly runs ONE of the two gathers instead of both */
-        pincl[h] = m1[h] ? wave_incl_scan(cls[h] == 1 ? nb[h] : 0u) : 0u;
-        pincl2[h] = m2[h] ? wave_incl_scan(cls[h] == 2 ? nb[h] : 0u) : 0u;
+         * the top): a wave of the pair phase then mostly runs ONE of the two gathers instead of both.  One scan for both counts:
+         * intra bases in the low half, MC-residual bases in the high half (a wave's sum stays below 2^16: 64 blocks x 255 bases) */
+        {
+            const u32 packed = (m1[h] | m2[h]) ? wave_incl_scan(cls[h] == 1 ? nb[h] : cls[h] == 2 ? nb[h] << 16 : 0u) : 0u;
+            pincl[h] = packed & 0xFFFFu; pincl2[h] = packed >> 16;
+        }
     }
     if (q_offs_off) {                                                   /* self-referencing P picture: hvq_selfref_kernel wants the pool offsets */
 #pragma unroll

@@ -9,7 +9,7 @@ for p in $P; do
     for v in "$@"; do
       name=${v%%:*}; envs=""; [ "$v" != "$name" ] && envs=$(echo "${v#*:}" | tr ',' ' ')
       f=$O/${p}_${name}_$rep
-      env $envs timeout -k 10 240 python bench.py $C --preset $p > $f.json 2> $f.err || { echo "$p $name FAILED: $(tail -2 $f.err)" | tee -a $O/summary.txt; continue; }
+      env $envs timeout -k 10 240 python bench.py $C $BENCH_EXTRA --preset $p > $f.json 2> $f.err || { echo "$p $name FAILED: $(tail -2 $f.err)" | tee -a $O/summary.txt; continue; }
       python3 - $f.json "$p $name rep $rep" <<'PY' | tee -a $O/summary.txt
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]
