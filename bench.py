@@ -6,8 +6,9 @@ Metric (BASELINE.json): decoded Mpixels/s (bit-exact YUV) and % of the HBM roofl
 Workloads, weak scaling, one rank per GPU, no collective on the data path:
   c5 (default)  the per-GPU share of config C5: 128 concurrent 640x480 HVQM4 1.5 streams, GOP I P B B P B B ...
                 (16 pictures), descriptors pre-parsed and resident in HBM.  One step = every stream decodes one GOP
-                (128 * 16 = 2048 pictures) through the batched path (hvq_replay): the launches of the dependency
-                levels, nothing skipped.
+                (128 * 16 = 2048 pictures) through the batched path (hvq_replay_stage): EVERYTHING a batch of new
+                pictures costs behind its parse -- the launches of the dependency levels, whose workgroups derive their
+                queues from the parser's descriptors themselves; no per-picture pass outside the step (round 3 had one).
   c4            config C4: 64 clips = 32 x 320x240 + 32 x 640x480, HVQM4 1.3 and 1.5 alternating, seeds 0..63,
                 four 16-picture GOPs each, clip i -> rank i mod N.  One step = every clip of the rank decoded once.
 `value` = luma pixels decoded by all ranks / max-over-ranks time.
@@ -16,10 +17,11 @@ Workloads, weak scaling, one rank per GPU, no collective on the d
 anything touches a GPU, and forwards rank 0's line; under torchrun it runs as one of the ranks.
 
 Extra objects on the JSON line:
-  roofline      algorithmic bytes (1.5 B/px written + 1.5 B/px read for P/B) per launch /
-                average launch duration from HIP events on the launch stream, vs 8 TB/s; `traffic` = HBM bytes per
-                launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json), calibrated as
-                MI355X_MICROARCH.md prescribes
+  roofline      algorithmic bytes (1.5 B/px written + 1.5 B/px read for P/B) of a step / HIP-event
+                time of the step on the launch stream (= bytes per launch / average launch duration: the step is its 7
+                launches), vs 8 TB/s; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
+                (profiles/*_pmc_traffic.json), calibrated as MI355X_MICROARCH.md prescribes; `two_pass_tile_queues`
+                (extra object) = the same step with round 3's queue-build kernel + reconstruction over its queues
   cpu_baseline  the reference decoder (oracle/_ref, kind "reference") or this repo's scalar restatement (kind "port")
                 on the host cores: one core on C1, C2, C3 and one process per clip over all cores on a C4 sample
 """

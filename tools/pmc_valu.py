@@ -24,6 +24,6 @@ W = sum(x["waves"] for x in lv)
 res = {"source": root, "levels": lv,
        "insts_per_wave": round(sum(x["valu_per_wave"] * x["waves"] for x in lv) / W, 1),
        "busy_frac": round(sum(x["valu_busy"] * x["us"] for x in lv) / sum(x["us"] for x in lv), 3),
-       "note": "per wave of TWO tiles (128 blocks) when the launch runs two tiles per workgroup; busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x clocks at 2.4 GHz)"}
+       "note": "per wave = 64 blocks of each tile of its workgroup (the dense bench runs one tile per workgroup since round 4, round 3 ran two); busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x clocks at 2.4 GHz)"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res)[:600])
