@@ -45,6 +45,9 @@ class Context:
         a_l = (C.c_size_t * n)(*[len(p) for p in pictures])
         a_o = (C.c_int * n)()
         check(lib().hvq_submit_many_device(self._h, n, a_s, a_t, a_p, a_l, a_o))
+        # while a batch is in flight the library copies the bitstreams on a worker thread and returns at once: the pictures (and
+        # the pointer array) must stay alive until the next flush_begin
+        self._submit_keep = (a_p, pictures)
         return list(a_o)
 
     def flush(self) -> None:

@@ -269,6 +269,11 @@ struct HvqContext {
     uint32_t *redo_dev = nullptr;      /* their indices, for the chains kernel */
     size_t redo_cap = 0;
     uint32_t fl_rowbuf = 0;
+    /* streaming: the bitstream copy of the batch being queued runs on a worker while the batch in flight is finished */
+    std::thread copy_worker;
+    bool copy_active = false;
+    int copy_rc = 0;
+    std::string copy_err;
 };
 
 static int arena_reserve(HvqContext *c, size_t need)
@@ -307,6 +312,27 @@ static int arena_upload(HvqContext *c, size_t upto)
 
 static int flush_end(HvqContext *c);
 static int flush_abandon(HvqContext *c, int rc);
+
+/* wait for the bitstream copy of the batch being queued (hvq_submit_many_device in streaming).  A failed copy (a HIP error in one of
+ * its uploads) takes the queued batch with it: its pictures were never uploaded. */
+static int copy_join(HvqContext *c)
+{
+    if (!c->copy_active) return HVQ_OK;
+    if (c->copy_worker.joinable()) c->copy_worker.join();
+    c->copy_active = false;
+    if (!c->copy_rc) return HVQ_OK;
+    for (auto &p : c->pending) {
+        Stream &s = c->streams[(size_t)p.stream];
+        if ((size_t)p.ordinal < s.pic_slot.size() && s.pic_slot[(size_t)p.ordinal] == p.dst) {
+            s.pic_slot[(size_t)p.ordinal] = -1;
+            if (p.dst >= 0 && s.slots[(size_t)p.dst].pic == p.ordinal) s.slots[(size_t)p.dst].pic = -1;
+        }
+        s.anchor_old = s.anchor_new = -1; s.need_I = true; s.nest_src = -1;
+    }
+    c->pending.clear();
+    c->arena_used = 0; c->arena_uploaded = 0;
+    return fail(c->copy_rc, "bitstream upload of the queued batch failed (%s); the batch was dropped", c->copy_err.c_str());
+}
 
 /* HVQM4_AMD_FLUSH_TIMING=1: host-side timeline of the flush halves on stderr (development aid) */
 static bool flush_timing() { static const bool on = getenv("HVQM4_AMD_FLUSH_TIMING") != nullptr; return on; }
@@ -372,6 +398,7 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)copy_join(c);
     (void)flush_end(c);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -430,6 +457,7 @@ HVQ_EXPORT int hvq_stream_open(HvqContext *c, int width, int height, int h_samp,
 {
     if (!c) return fail(HVQ_E_ARG, "null context");
     if (nslots < 3) return fail(HVQ_E_ARG, "nslots must be >= 3 (past, present, future)");
+    { int rcj = copy_join(c); if (rcj) return rcj; }
     HIPCHK(hipSetDevice(c->device));
     HvqParser *p = hvq_parser_create(width, height, h_samp, v_samp, is15);
     if (!p) return fail(HVQ_E_GEOMETRY, "unsupported geometry %dx%d sampling %dx%d (need multiples of 8, <= 8192; samplings 2x2, 1x1 and 2x1 -- the reference's own tables cannot decode 1x2)",
@@ -458,6 +486,7 @@ HVQ_EXPORT int hvq_stream_close(HvqContext *c, int sid)
     if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
     for (auto &p : c->pending)
         if (p.stream == sid) return fail(HVQ_E_STATE, "stream %d has queued pictures; flush first", sid);
+    { int rcj = copy_join(c); if (rcj) return rcj; }
     { int rc = flush_end(c); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     Stream &s = c->streams[sid];
@@ -562,6 +591,8 @@ HVQ_EXPORT int hvq_stream_submit(HvqContext *c, int sid, int frame_type, const u
 {
     int rc = check_submit_args(c, sid, frame_type, pic, len);
     if (rc) return rc;
+    rc = copy_join(c);
+    if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
     Stream &s = c->streams[sid];
     if (s.parse_mode == 2) return fail(HVQ_E_STATE, "stream %d is parsed on the GPU; use hvq_submit_many_device", sid);
@@ -592,6 +623,7 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
         if (rc) return rc;
     }
     if (n == 0) return HVQ_OK;
+    { int rcj = copy_join(c); if (rcj) return rcj; }
     { int rc = check_resume_order(c, n, streams, frame_types); if (rc) return rc; }
     for (int i = 0; i < n; ++i) {
         Stream &s = c->streams[(size_t)streams[i]];
@@ -691,6 +723,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
 {
     if (!c || n < 0 || !streams || !frame_types || !pics || !lens) return fail(HVQ_E_ARG, "bad arguments");
     size_t need = 0;
+    { int rcj = copy_join(c); if (rcj) return rcj; }
     for (int i = 0; i < n; ++i) {
         int rc = check_submit_args(c, streams[i], frame_types[i], pics[i], lens[i], false);
         if (rc) return rc;
@@ -757,40 +790,67 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
         if (ordinals) ordinals[i] = ord;
     }
     /* bitstreams -> pinned arena -> HBM, pipelined: a few threads copy a chunk of pictures (zero padded: the device
-     * reader sees zeros past the end), its H2D is queued at once and runs while the next chunk is being copied */
-    auto copy_range = [&](int lo, int hi) {
-        for (int i = lo; i < hi; ++i) {
-            uint8_t *dst = c->host_arena + offs[(size_t)i];
-            const size_t span = align_up(lens[i] + 32, 256);
-            memcpy(dst, pics[i], lens[i]);
-            memset(dst + lens[i], 0, span - lens[i]);
+     * reader sees zeros past the end), its H2D is queued at once and runs while the next chunk is being copied.
+     * While a batch is in flight (streaming: hvq_flush_begin ... hvq_flush_end) the copy runs on a worker thread and this call
+     * returns at once, so that the caller reaches hvq_flush_end -- and the in-flight batch its reconstruction launches -- as soon as
+     * the parse results arrive, however long the host takes over 160 MB of memcpy (4-7.5 ms on a shared host, measured); the next
+     * hvq_flush_begin joins the worker.  `pics[i]` must stay readable until then. */
+    struct CopyJob { std::vector<const uint8_t *> pics; std::vector<size_t> lens, offs; size_t end_used; bool early; uint8_t *host; };
+    CopyJob job;
+    job.pics.assign(pics, pics + n); job.lens.assign(lens, lens + n); job.offs = offs;
+    job.end_used = c->arena_used; job.early = c->arena_uploaded == offs[0];          /* nothing older is waiting for the flush-time upload */
+    job.host = c->host_arena;
+    auto run_copy = [c](const CopyJob &j) -> int {
+        const int n = (int)j.pics.size();
+        auto copy_range = [&](int lo, int hi) {
+            for (int i = lo; i < hi; ++i) {
+                uint8_t *dst = j.host + j.offs[(size_t)i];
+                const size_t span = align_up(j.lens[(size_t)i] + 32, 256);
+                memcpy(dst, j.pics[(size_t)i], j.lens[(size_t)i]);
+                memset(dst + j.lens[(size_t)i], 0, span - j.lens[(size_t)i]);
+            }
+        };
+        const size_t chunk_bytes = (size_t)16 << 20;
+        int lo = 0;
+        while (lo < n) {
+            int hi = lo;
+            size_t bytes = 0;
+            while (hi < n && bytes < chunk_bytes) { bytes += align_up(j.lens[(size_t)hi] + 32, 256); ++hi; }
+            /* 8 threads when the host has them: with 4 the copy of a dense batch (160 MB) takes about as long as the GPU leaves
+             * for it */
+            static const int copy_threads = getenv("HVQM4_AMD_COPY_THREADS") ? std::max(1, atoi(getenv("HVQM4_AMD_COPY_THREADS")))
+                                                                             : (std::thread::hardware_concurrency() >= 16 ? 8 : 4);
+            const int nt = bytes >= ((size_t)4 << 20) ? copy_threads : 1;
+            if (nt == 1) copy_range(lo, hi);
+            else {
+                std::vector<std::thread> pool;
+                const int per = (hi - lo + nt - 1) / nt;
+                for (int t = 1; t < nt; ++t) pool.emplace_back(copy_range, std::min(hi, lo + t * per), std::min(hi, lo + (t + 1) * per));
+                copy_range(lo, std::min(hi, lo + per));
+                for (auto &t : pool) t.join();
+            }
+            if (j.early) {
+                int rcu = arena_upload(c, hi < n ? j.offs[(size_t)hi] : j.end_used);
+                if (rcu) return rcu;
+            }
+            lo = hi;
         }
+        return HVQ_OK;
     };
-    const size_t chunk_bytes = (size_t)16 << 20;
-    const bool early = c->arena_uploaded == offs[0];          /* nothing older is waiting for the flush-time upload */
-    int lo = 0;
-    while (lo < n) {
-        int hi = lo;
-        size_t bytes = 0;
-        while (hi < n && bytes < chunk_bytes) { bytes += align_up(lens[hi] + 32, 256); ++hi; }
-        /* 8 threads when the host has them: with 4 the copy of a dense batch (160 MB) takes about as long as the GPU leaves
-         * for it, and every second batch's parse then waits for its bitstreams (period 7.8 instead of 6.9 ms) */
-        static const int copy_threads = getenv("HVQM4_AMD_COPY_THREADS") ? std::max(1, atoi(getenv("HVQM4_AMD_COPY_THREADS")))
-                                                                         : (std::thread::hardware_concurrency() >= 16 ? 8 : 4);
-        const int nt = bytes >= ((size_t)4 << 20) ? copy_threads : 1;
-        if (nt == 1) copy_range(lo, hi);
-        else {
-            std::vector<std::thread> pool;
-            const int per = (hi - lo + nt - 1) / nt;
-            for (int t = 1; t < nt; ++t) pool.emplace_back(copy_range, std::min(hi, lo + t * per), std::min(hi, lo + (t + 1) * per));
-            copy_range(lo, std::min(hi, lo + per));
-            for (auto &t : pool) t.join();
-        }
-        if (early) {
-            int rcu = arena_upload(c, hi < n ? offs[(size_t)hi] : c->arena_used);
-            if (rcu) { rollback(); return rcu; }
-        }
-        lo = hi;
+    static const int async_env = getenv("HVQM4_AMD_ASYNC_SUBMIT") ? atoi(getenv("HVQM4_AMD_ASYNC_SUBMIT")) : -1;
+    if (async_env != 0 && (c->fl_active || async_env > 0)) {
+        c->copy_rc = HVQ_OK;
+        c->copy_err.clear();
+        c->copy_active = true;
+        const int dev = c->device;
+        c->copy_worker = std::thread([c, dev, run_copy, job = std::move(job)]() {
+            (void)hipSetDevice(dev);
+            c->copy_rc = run_copy(job);
+            if (c->copy_rc) c->copy_err = g_err;          /* the worker's thread-local error text */
+        });
+    } else {
+        int rcc = run_copy(job);
+        if (rcc) { rollback(); return rcc; }
     }
 #undef HIPCHK_RB
     return HVQ_OK;
@@ -1071,6 +1131,7 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
     if (!c) return fail(HVQ_E_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
     { int rc = flush_end(c); if (rc) return rc; }            /* at most one batch in flight */
+    { int rcj = copy_join(c); if (rcj) return rcj; }         /* the queued batch's bitstreams are in the arena (streaming: copied by a worker) */
     if (c->pending.empty()) return HVQ_OK;
     const double tb0 = now_ms();
     HIPCHK(hipEventSynchronize(c->ev_arena_free[c->arena_id]));   /* the pinned staging of this arena id is free again */
@@ -1435,6 +1496,7 @@ HVQ_EXPORT int hvq_sync(HvqContext *c)
 {
     if (!c) return fail(HVQ_E_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
+    { int rcj = copy_join(c); if (rcj) return rcj; }
     { int rc = flush_end(c); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     return HVQ_OK;

@@ -86,7 +86,10 @@ int  hvq_submit_many(HvqContext *ctx, int n, const int *streams, const int *fram
  * the device (one workgroup per picture, hvq_gparse.hip), so no host core touches a bit of the stream.  Same
  * queueing semantics as hvq_submit_many.  A stream uses either the host parser or the GPU parser for its whole
  * lifetime (the host parser keeps the nest of the last I picture); lens[] must be the real picture lengths.
- * Errors of the device parse (HVQ_E_OVERFLOW, HVQ_E_ARG) are reported by hvq_flush. */
+ * Errors of the device parse (HVQ_E_OVERFLOW, HVQ_E_ARG) are reported by hvq_flush.
+ * Streaming: called while a batch is in flight (between hvq_flush_begin and hvq_flush_end) it returns at once and the bitstreams
+ * are copied into the pinned arena by a worker thread -- `pics[i]` must then stay readable until the next hvq_flush_begin (or
+ * hvq_sync), which joins the worker; a failed upload is reported there and drops the queued batch. */
 int  hvq_submit_many_device(HvqContext *ctx, int n, const int *streams, const int *frame_types,
                             const uint8_t *const *pics, const size_t *lens, int *ordinals);
 
