@@ -802,40 +802,53 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
     job.host = c->host_arena;
     auto run_copy = [c](const CopyJob &j) -> int {
         const int n = (int)j.pics.size();
-        auto copy_range = [&](int lo, int hi) {
-            for (int i = lo; i < hi; ++i) {
+        /* chunks of ~16 MB: a chunk's H2D is queued as soon as its last picture is in the arena.  The copy threads are started ONCE
+         * per batch and take pictures off a shared counter (round 3 started and joined a set of threads per chunk: 70 thread
+         * starts per 160 MB batch); the calling thread copies too and queues the uploads in chunk order. */
+        const size_t chunk_bytes = (size_t)16 << 20;
+        std::vector<int> chunk_end;                         /* picture index behind each chunk */
+        {
+            size_t bytes = 0;
+            for (int i = 0; i < n; ++i) {
+                bytes += align_up(j.lens[(size_t)i] + 32, 256);
+                if (bytes >= chunk_bytes || i == n - 1) { chunk_end.push_back(i + 1); bytes = 0; }
+            }
+        }
+        std::vector<std::atomic<int>> left(chunk_end.size());
+        for (size_t k = 0; k < chunk_end.size(); ++k) left[k].store(chunk_end[k] - (k ? chunk_end[k - 1] : 0));
+        std::vector<int> chunk_of((size_t)n);
+        for (size_t k = 0, i = 0; k < chunk_end.size(); ++k) for (; (int)i < chunk_end[k]; ++i) chunk_of[i] = (int)k;
+        std::atomic<int> next{ 0 };
+        auto copy_some = [&](int budget) {               /* up to `budget` pictures; returns false when none was left */
+            bool any = false;
+            while (budget-- > 0) {
+                const int i = next.fetch_add(1);
+                if (i >= n) return any;
                 uint8_t *dst = j.host + j.offs[(size_t)i];
                 const size_t span = align_up(j.lens[(size_t)i] + 32, 256);
                 memcpy(dst, j.pics[(size_t)i], j.lens[(size_t)i]);
                 memset(dst + j.lens[(size_t)i], 0, span - j.lens[(size_t)i]);
+                left[(size_t)chunk_of[(size_t)i]].fetch_sub(1, std::memory_order_release);
+                any = true;
             }
+            return true;
         };
-        const size_t chunk_bytes = (size_t)16 << 20;
-        int lo = 0;
-        while (lo < n) {
-            int hi = lo;
-            size_t bytes = 0;
-            while (hi < n && bytes < chunk_bytes) { bytes += align_up(j.lens[(size_t)hi] + 32, 256); ++hi; }
-            /* 8 threads when the host has them: with 4 the copy of a dense batch (160 MB) takes about as long as the GPU leaves
-             * for it */
-            static const int copy_threads = getenv("HVQM4_AMD_COPY_THREADS") ? std::max(1, atoi(getenv("HVQM4_AMD_COPY_THREADS")))
-                                                                             : (std::thread::hardware_concurrency() >= 16 ? 8 : 4);
-            const int nt = bytes >= ((size_t)4 << 20) ? copy_threads : 1;
-            if (nt == 1) copy_range(lo, hi);
-            else {
-                std::vector<std::thread> pool;
-                const int per = (hi - lo + nt - 1) / nt;
-                for (int t = 1; t < nt; ++t) pool.emplace_back(copy_range, std::min(hi, lo + t * per), std::min(hi, lo + (t + 1) * per));
-                copy_range(lo, std::min(hi, lo + per));
-                for (auto &t : pool) t.join();
-            }
-            if (j.early) {
-                int rcu = arena_upload(c, hi < n ? j.offs[(size_t)hi] : j.end_used);
-                if (rcu) return rcu;
-            }
-            lo = hi;
+        size_t total = 0;
+        for (int i = 0; i < n; ++i) total += j.lens[(size_t)i];
+        /* 8 threads when the host has them: with 4 the copy of a dense batch (160 MB) takes about as long as the GPU leaves for it */
+        static const int copy_threads = getenv("HVQM4_AMD_COPY_THREADS") ? std::max(1, atoi(getenv("HVQM4_AMD_COPY_THREADS")))
+                                                                         : (std::thread::hardware_concurrency() >= 16 ? 8 : 4);
+        const int nt = total >= ((size_t)4 << 20) ? copy_threads : 1;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back([&]() { while (copy_some(1 << 30)) {} });
+        int rc = HVQ_OK;
+        for (size_t k = 0; k < chunk_end.size(); ++k) {
+            while (left[k].load(std::memory_order_acquire) > 0)
+                if (!copy_some(4)) std::this_thread::yield();      /* help; when nothing is left to take, wait for the others */
+            if (j.early && !rc) rc = arena_upload(c, k + 1 < chunk_end.size() ? j.offs[(size_t)chunk_end[k]] : j.end_used);
         }
-        return HVQ_OK;
+        for (auto &t : pool) t.join();
+        return rc;
     };
     static const int async_env = getenv("HVQM4_AMD_ASYNC_SUBMIT") ? atoi(getenv("HVQM4_AMD_ASYNC_SUBMIT")) : -1;
     if (async_env != 0 && (c->fl_active || async_env > 0)) {
