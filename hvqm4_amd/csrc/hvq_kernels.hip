@@ -1383,13 +1383,16 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     typedef __attribute__((address_space(3))) u32 lds_u32;
     if constexpr (HVQ_INL_BAR0(TPW)) {   /* block classes by type byte for this plane's context (hvq_type_class): one LDS read per block instead of ~40 selects */
         const GLB u32 *tclass = (const GLB u32 *)g_type_class + (is_pb ? 512 : p == 0 ? 0 : 256);
-        __builtin_amdgcn_global_load_lds(tclass + tid, (lds_u32 *)(s_class + wave * 64u), 4, 0, 0);
+#pragma unroll
+        for (int r0 = 0; r0 < 256; r0 += HVQ_WG)
+            __builtin_amdgcn_global_load_lds(tclass + r0 + tid, (lds_u32 *)(s_class + r0 + wave * 64u), 4, 0, 0);
     }
     const bool has_nest = (HVQ_W64(10) != 0);
     if (has_nest) {
-        __builtin_amdgcn_global_load_lds(nestp + tid, (lds_u32 *)((u32 *)s_nest + wave * 64u), 4, 0, 0);
-        if (tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4)
-            __builtin_amdgcn_global_load_lds(nestp + HVQ_WG + tid, (lds_u32 *)((u32 *)s_nest + HVQ_WG + wave * 64u), 4, 0, 0);
+#pragma unroll
+        for (int r0 = 0; r0 < (HVQ_NESTP_BYTES + 3) / 4; r0 += HVQ_WG)
+            if (r0 + tid < (HVQ_NESTP_BYTES + 3) / 4)
+                __builtin_amdgcn_global_load_lds(nestp + r0 + tid, (lds_u32 *)((u32 *)s_nest + r0 + wave * 64u), 4, 0, 0);
     }
     phi = max(phi, plo);
     const u32 nst = min(phi - plo, pool_cap);                          /* staged dwords */
