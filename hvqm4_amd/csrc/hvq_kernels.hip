@@ -1274,7 +1274,7 @@ extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_bu
 #define HVQ_INL_BAR0(TPW) ((TPW) == 2)
 template <int ITEMS_CAP, int TPW>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
-void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 pool_cap)
+void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 pool_cap HVQ_STAMP_ARG)
 {
     extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];       /* [pair_cap] item | pool index << 9, then [pool_cap] staged pool dwords */
     __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];
@@ -1290,6 +1290,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    STAMP(0, 0);
     const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
     const u32 wg = blockIdx.y;
     const HvqJob *__restrict__ J = jobs + slot_id;
@@ -1350,6 +1351,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const i32 mcb_w = (i32)cw[15];
     const u32 pool_dwords = cw[16];
     const u32 wave = (u32)__builtin_amdgcn_readfirstlane(tid >> 6);
+    STAMP(1, 0);                                                               /* job record here */
     if constexpr (!HVQ_INL_BAR0(TPW)) {
     /* the slot counter is zero before any wave asks it: a barrier HERE, where no vector-memory operation is outstanding yet, instead
      * of one behind trip 2 that would hold every wave until the slowest wave's loads have landed */
@@ -1400,6 +1402,8 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         if (r0 + (u32)tid < nst) __builtin_amdgcn_global_load_lds(pool + plo + r0 + (u32)tid, (lds_u32 *)(s_pool + r0 + wave * 64u), 4, 0, 0);
     if constexpr (HVQ_INL_BAR0(TPW)) __syncthreads();   /* barrier 0: trip 2 has landed; the slot counters are zero before any wave asks them */
 
+    STAMP(2, 0);                                                               /* trip 2 issued (the stamp itself waits for the scalar loads) */
+    STAMP(3, 1);                                                               /* ... and landed (stamped builds wait here) */
     /* ---- classes, records, scans ---- */
     u32x2 brec[TPW];
     u32 off[TPW], cls[TPW], nb[TPW], e16v[TPW], pincl[TPW], pincl2[TPW];
@@ -1447,6 +1451,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             if (h < ntl) ((GLB u32 *)(qb + q_offs_off))[(size_t)(tile0 + (u32)h) * HVQ_TILE_BLOCKS + (u32)tid] = off[h];
     }
 
+    STAMP(4, 0);                                                               /* classes, records, scans */
     /* ---- trip 3: motion-compensation rows ---- */
     McRows rows[TPW];
 #pragma unroll
@@ -1520,6 +1525,8 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         return j < nst ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
     };
 
+    STAMP(5, 0);                                                               /* rows requested, slots, items and pairs in LDS */
+    STAMP(6, 1);                                                               /* rows landed */
     /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
@@ -1543,7 +1550,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 #pragma unroll
         for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
     }
+    STAMP(7, 0);                                                               /* phase A */
     __syncthreads();                                                           /* barrier 1: queues, zeroed accumulators, staged pool and nest */
+    STAMP(8, 0);
     if constexpr (!HVQ_INL_BAR0(TPW)) {
     /* literal blocks (h4m:543-549): the owner copies its 16 samples from the staged pool (complete only now: other waves staged parts of it) */
 #pragma unroll
@@ -1589,7 +1598,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             }
             basis_scatter<ITEMS_CAP>(gain_q(wq0, lo, hi), e, s_acc + it);
         }
+        STAMP(9, 1);                                                           /* pair phase incl. its window rows */
         __syncthreads();                                                       /* barrier 2: accumulators complete */
+        STAMP(10, 0);
         /* ---- phase B2: one lane per item ---- */
         /* MC-residual items (the expensive epilogue) on the first lanes, intra items on the LAST lanes of the workgroup: with at
          * most 256 items no wave runs both epilogues unless the two ranges meet inside it, and the two kinds finish side by side */
@@ -1644,7 +1655,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             for (int y = 0; y < 4; ++y) so[y * HVQ_WG] = o.r[y];
         }
     }
+    STAMP(11, 0);                                                              /* item phase */
     __syncthreads();                                                           /* barrier 3: tiles complete in LDS */
+    STAMP(12, 0);
 
     /* ---- phase C: tiles -> HBM ---- */
     if ((HVQ_ABL == 35 || HVQ_ABL == 37) && s_out[0][0][tid] != 0x12345678u) return;
@@ -1671,13 +1684,19 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[h][y][tid];
         }
     }
+    STAMP(13, 0);                                                              /* stores issued */
+    STAMP(14, 1);                                                              /* stores acknowledged */
 }
 
 template <int ITEMS_CAP, int TPW>
 static void launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_t max_wgs, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream)
 {
     const dim3 grid = nslots >= 8 ? dim3(8, max_wgs, nslots / 8) : dim3(nslots, max_wgs, 1);
+#ifdef HVQ_STAMPS
+    hipLaunchKernelGGL((hvq_recon_inline_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), (size_t)(pair_cap + pool_cap) * 4u, stream, jobs_dev, pair_cap, pool_cap, g_stamps);
+#else
     hipLaunchKernelGGL((hvq_recon_inline_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), (size_t)(pair_cap + pool_cap) * 4u, stream, jobs_dev, pair_cap, pool_cap);
+#endif
 }
 
 /* static LDS of hvq_recon_inline_kernel<items_cap, tpw> (the host sizes the dynamic part against the CU's 160 KB) */

@@ -1534,23 +1534,29 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
 #ifdef HVQ_STAMPS
     if (getenv("HVQM4_AMD_STAMPS")) {
         /* diagnostic build: one more pass with phase stamps, per-launch mean segment lengths on stderr */
-        static const char *seg[10] = { "job + queue records", "prologue loads issue + land", "phase A (MC rows, cheap kinds, literals)", "barrier 1",
-                                       "B1 pairs", "barrier 2 (item record in flight)", "B2 items", "barrier 3", "store issue", "stores land" };
-        static const int from[10] = { 0, 1, 2, 3, 4, 7, 8, 9, 10, 12 }, to[10] = { 1, 2, 3, 4, 7, 8, 9, 10, 12, 13 };
-        const int NS = 10, LAST = 13;
+        static const char *seg_q[10] = { "job + queue records", "prologue loads issue + land", "phase A (MC rows, cheap kinds, literals)", "barrier 1",
+                                         "B1 pairs", "barrier 2 (item record in flight)", "B2 items", "barrier 3", "store issue", "stores land" };
+        static const int from_q[10] = { 0, 1, 2, 3, 4, 7, 8, 9, 10, 12 }, to_q[10] = { 1, 2, 3, 4, 7, 8, 9, 10, 12, 13 };
+        static const char *seg_i[14] = { "job record (+ early barrier)", "trip 2 issue", "trip 2 lands", "classes, records, scans", "rows requested, slots, lists",
+                                         "rows land", "phase A", "barrier 1", "pair phase (B1)", "barrier 2", "item phase (B2)", "barrier 3", "store issue", "stores land" };
+        static const int from_i[14] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13 }, to_i[14] = { 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14 };
         for (auto &L : c->launches) {
+            const char **seg = L.inline_queues ? seg_i : seg_q;
+            const int *from = L.inline_queues ? from_i : from_q, *to = L.inline_queues ? to_i : to_q;
+            const int NS = L.inline_queues ? 14 : 10, LAST = L.inline_queues ? 14 : 13;
             unsigned long long *d = nullptr;
             const size_t n = (size_t)L.ntiles * L.max_tiles * 64;
             HIPCHK(hipMalloc((void **)&d, n * 8));
             HIPCHK(hipMemsetAsync(d, 0, n * 8, c->stream));
             hvq_set_stamps(d);
-            HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, c->stream));
+            if (L.inline_queues) HIPCHK(hvq_launch_recon_inline(c->jobs_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, L.pool_cap, c->stream));
+            else HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, c->stream));
             hvq_set_stamps(nullptr);
             std::vector<unsigned long long> h(n);
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost));
             HIPCHK(hipFree(d));
-            double sum[10] = {}, life = 0; size_t cnt[10] = {}, nw = 0;
+            double sum[14] = {}, life = 0; size_t cnt[14] = {}, nw = 0;
             for (size_t t = 0; t < (size_t)L.ntiles * L.max_tiles; ++t)
                 for (int w = 0; w < 4; ++w) {
                     const unsigned long long *q = &h[t * 64 + w * 16];
