@@ -265,71 +265,102 @@ __device__ static inline uint32_t gfd_dpp_incl(uint32_t v)
     return v;
 }
 
-/* gf_emit_merge with consecutive entries on consecutive lanes: a wave owns the entries of its 64 threads' chunks (whose
- * starting offsets gf_emit_count + the scans have already produced), walks them 64 at a time and gets every entry's
- * position in the coefficient symbols, in the fixed-length section and among the MC-residual blocks from three wave
- * scans.  The lanes of one step read neighbouring symbols and words and write neighbouring pool dwords -- a handful of
- * cache lines per instruction where the chunk-per-thread form touches 64. */
+/* gf_emit_merge on the device.  A wave owns the entries of its 64 threads' chunks (whose starting offsets gf_emit_count + the
+ * scans have already produced), walks them 64 at a time and gets every entry's position in the coefficient symbols, in the
+ * fixed-length section and among the MC-residual blocks from three wave scans.  Most entries carry nothing (a dense 640x480
+ * B picture: 10 000 coefficient symbols over 19 200 luma blocks), so the entries that do are QUEUED -- (entry, symbol index,
+ * fixed-length offset, MC-residual rank) in the wave's 128-record ring in LDS, over the staging slots and trees nobody needs
+ * any more -- and completed 64 at a time with every lane busy: round 4, a third of the vector instructions of the
+ * entry-per-lane form (which was the largest single consumer of vector instructions in the kernel). */
+#define GFD_MQ 128u                                                /* records per wave: 4 arrays of 128 dwords */
+
+__device__ static inline void gfd_merge_one(const GPic *g, GP_G uint32_t *pool, const GP_G int16_t *S, const GP_G uint32_t *V,
+                                            int sh_dc, int sh_unk, uint32_t ent, uint32_t my_si, uint64_t my_fx, uint32_t my_pi)
+{
+    const uint32_t mode = ent >> 30;
+    GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
+    if (mode == GP_MODE_LITERAL) {
+        uint32_t v[4];
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_bswap32(gp_be32(g, my_fx + 4u * (uint32_t)k));
+        for (int k = 0; k < 4; ++k) dst[k] = v[k];
+        return;
+    }
+    const uint32_t nb = (ent >> 22) & 0xFFu;
+    if (mode == GP_MODE_PREDI) {
+        const int32_t s1 = (int32_t)V[2u * my_pi], s2 = (int32_t)V[2u * my_pi + 1u];
+        dst[0] = (uint32_t)(s1 >> sh_dc) << sh_unk;
+        dst[1] = (uint32_t)(s2 >> sh_dc);
+        dst += 2;
+    }
+    uint32_t run = 0;
+    /* eight bases a time from two 16-byte loads (words and symbols lie consecutive; both arrays and the picture are
+     * padded far enough to read a full block) */
+    for (uint32_t k0 = 0; k0 < nb; k0 += 8) {
+        const uint64_t wo = my_fx + 2u * k0;
+        uint32_t wq[4];
+        if (__builtin_expect(wo + 16u <= (uint64_t)g->nd * 4u, 1)) __builtin_memcpy(wq, (const GP_G uint8_t *)g->d + wo, 16);
+        else for (uint32_t j = 0; j < 4; ++j) wq[j] = __builtin_bswap32((gp_be16(g, wo + 4u * j) << 16) | gp_be16(g, wo + 4u * j + 2u));
+        uint32_t sq[4];
+        __builtin_memcpy(sq, S + my_si + k0, 16);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            if (k0 + j >= nb) break;
+            const uint32_t half = (wq[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu;           /* bytes b0 b1 of the word, b0 low */
+            const uint32_t w = ((half & 0xFFu) << 8) | (half >> 8);
+            run += (uint32_t)(int32_t)(int16_t)(sq[j >> 1] >> (16u * (j & 1u)));
+            dst[k0 + j] = HVQ_BASIS(w, (run + ((w >> 13) & 3u)) & 0x3FFFFu);
+        }
+    }
+}
+
+/* a wave-uniform 64-bit value (a pointer read from the picture state in LDS) into scalar registers: the kernel has 64 vector registers */
+__device__ static inline uint64_t gfd_uni64(uint64_t v) { return ((uint64_t)GP_UNI(v >> 32) << 32) | GP_UNI((uint32_t)v); }
+#define GFD_UNIP(type, p) ((type)gfd_uni64((uint64_t)(p)))
+
 __device__ static void gfd_emit_merge(GPic *g, int tid)
 {
     if (g->status || g->retry) return;
     if (gf_emit_short(g)) { g->retry = 1; return; }
-    const int lane = tid & 63, wave = tid >> 6;
-    GP_G uint32_t *pool = (GP_G uint32_t *)(g->blob + g->fixed_bytes);
-    const int sh_dc = g->dc_shift & 31, sh_unk = g->unk_shift & 31;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    GP_G uint32_t *pool = GFD_UNIP(GP_G uint32_t *, g->blob + g->fixed_bytes);
+    const int sh_dc = (int)GP_UNI(g->dc_shift & 31), sh_unk = (int)GP_UNI(g->unk_shift & 31);
+    uint32_t *q_ent = gp_stage + 4u * GFD_MQ * (uint32_t)wave, *q_si = q_ent + GFD_MQ, *q_fx = q_si + GFD_MQ, *q_pi = q_fx + GFD_MQ;
     for (int i = 0; i < 3; ++i) {
-        const GP_G uint32_t *ents = g->pinfo + g->pl[i].blk_first;
-        const GP_G int16_t *S = g->sym + g->lane[GF_BT0 + i].off;
-        const GP_G uint32_t *V = g->val + g->val_off[i] + g->ntype0 * (uint32_t)g->pl[i].nblk;
-        const uint32_t n = g->pl[i].nblocks, per = (n + GPW - 1) / GPW;
+        const GP_G uint32_t *ents = GFD_UNIP(const GP_G uint32_t *, g->pinfo + g->pl[i].blk_first);
+        const GP_G int16_t *S = GFD_UNIP(const GP_G int16_t *, g->sym + g->lane[GF_BT0 + i].off);
+        const GP_G uint32_t *V = GFD_UNIP(const GP_G uint32_t *, g->val + g->val_off[i] + g->ntype0 * (uint32_t)g->pl[i].nblk);
+        const uint32_t n = GP_UNI(g->pl[i].nblocks), per = (n + GPW - 1) / GPW;
         const uint32_t e0 = per * 64u * (uint32_t)wave < n ? per * 64u * (uint32_t)wave : n;
         const uint32_t e1 = per * 64u * (uint32_t)(wave + 1) < n ? per * 64u * (uint32_t)(wave + 1) : n;
-        uint64_t fx = g->fx_off[i] + g->part[GF_P(GF_I_FX(i), 64 * wave)];
-        uint32_t si = g->part[GF_P(GF_I_NB(i), 64 * wave)], pi = g->part[GF_P(GF_I_PREDI(i), 64 * wave)];
-        for (uint32_t eb = e0; eb < e1; eb += 64) {
-            const uint32_t e = eb + (uint32_t)lane;
-            const uint32_t ent = e < e1 ? ents[e] : 0u, mode = ent >> 30;
-            const uint32_t nb = mode >= GP_MODE_BASES ? (ent >> 22) & 0xFFu : 0u, fb = gp_ent_fx_bytes(ent), ip = mode == GP_MODE_PREDI;
-            const uint32_t s_nb = gfd_dpp_incl(nb), s_fb = gfd_dpp_incl(fb), s_ip = gfd_dpp_incl(ip);
-            const uint32_t my_si = si + s_nb - nb, my_pi = pi + s_ip - ip;
-            const uint64_t my_fx = fx + (s_fb - fb);
-            si += (uint32_t)__builtin_amdgcn_readlane((int)s_nb, 63);
-            fx += (uint32_t)__builtin_amdgcn_readlane((int)s_fb, 63);
-            pi += (uint32_t)__builtin_amdgcn_readlane((int)s_ip, 63);
-            if (mode == GP_MODE_NONE) continue;
-            GP_G uint32_t *dst = pool + (ent & 0x3FFFFFu);
-            if (mode == GP_MODE_LITERAL) {
-                uint32_t v[4];
-                for (int k = 0; k < 4; ++k) v[k] = __builtin_bswap32(gp_be32(g, my_fx + 4u * (uint32_t)k));
-                for (int k = 0; k < 4; ++k) dst[k] = v[k];
-                continue;
-            }
-            if (mode == GP_MODE_PREDI) {
-                const int32_t s1 = (int32_t)V[2u * my_pi], s2 = (int32_t)V[2u * my_pi + 1u];
-                dst[0] = (uint32_t)(s1 >> sh_dc) << sh_unk;
-                dst[1] = (uint32_t)(s2 >> sh_dc);
-                dst += 2;
-            }
-            uint32_t run = 0;
-            /* eight bases a time from two 16-byte loads (words and symbols lie consecutive; both arrays and the picture are
-             * padded far enough to read a full block): this loop is the largest single consumer of vector instructions in
-             * the kernel, the byte-wise form took three times as many */
-            for (uint32_t k0 = 0; k0 < nb; k0 += 8) {
-                const uint64_t wo = my_fx + 2u * k0;
-                uint32_t wq[4];
-                if (__builtin_expect(wo + 16u <= (uint64_t)g->nd * 4u, 1)) __builtin_memcpy(wq, (const GP_G uint8_t *)g->d + wo, 16);
-                else for (uint32_t j = 0; j < 4; ++j) wq[j] = __builtin_bswap32((gp_be16(g, wo + 4u * j) << 16) | gp_be16(g, wo + 4u * j + 2u));
-                uint32_t sq[4];
-                __builtin_memcpy(sq, S + my_si + k0, 16);
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) {
-                    if (k0 + j >= nb) break;
-                    const uint32_t half = (wq[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu;           /* bytes b0 b1 of the word, b0 low */
-                    const uint32_t w = ((half & 0xFFu) << 8) | (half >> 8);
-                    run += (uint32_t)(int32_t)(int16_t)(sq[j >> 1] >> (16u * (j & 1u)));
-                    dst[k0 + j] = HVQ_BASIS(w, (run + ((w >> 13) & 3u)) & 0x3FFFFu);
+        uint64_t fx = gfd_uni64(g->fx_off[i] + g->part[GF_P(GF_I_FX(i), 64 * wave)]);
+        uint32_t si = GP_UNI(g->part[GF_P(GF_I_NB(i), 64 * wave)]), pi = GP_UNI(g->part[GF_P(GF_I_PREDI(i), 64 * wave)]);
+        uint32_t head = 0, tail = 0;                                  /* records taken / put so far (wave-uniform) */
+        for (uint32_t eb = e0; eb < e1 || tail != head; eb += 64) {
+            if (eb < e1) {
+                const uint32_t e = eb + (uint32_t)lane;
+                const uint32_t ent = e < e1 ? ents[e] : 0u, mode = ent >> 30;
+                const uint32_t nb = mode >= GP_MODE_BASES ? (ent >> 22) & 0xFFu : 0u, fb = gp_ent_fx_bytes(ent), ip = mode == GP_MODE_PREDI;
+                const uint32_t s_nb = gfd_dpp_incl(nb), s_fb = gfd_dpp_incl(fb), s_ip = gfd_dpp_incl(ip);
+                const uint64_t my_fx = fx + (s_fb - fb);
+                const bool work = mode != GP_MODE_NONE;
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(work);
+                if (work) {
+                    const uint32_t slot = (tail + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))) & (GFD_MQ - 1u);
+                    q_ent[slot] = ent; q_si[slot] = si + s_nb - nb; q_pi[slot] = pi + s_ip - ip;
+                    q_fx[slot] = my_fx > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)my_fx;   /* past 4 GiB there are only zeros to read either way */
                 }
+                tail += (uint32_t)__builtin_popcountll(mask);
+                si += (uint32_t)__builtin_amdgcn_readlane((int)s_nb, 63);
+                fx += (uint32_t)__builtin_amdgcn_readlane((int)s_fb, 63);
+                pi += (uint32_t)__builtin_amdgcn_readlane((int)s_ip, 63);
             }
+            /* a full wave of records -- or, behind the plane's last entries, what is left */
+            const uint32_t have = tail - head, take = have >= 64u ? 64u : (eb + 64u >= e1 ? have : 0u);
+            if ((uint32_t)lane < take) {
+                const uint32_t slot = (head + (uint32_t)lane) & (GFD_MQ - 1u);
+                gfd_merge_one(g, pool, S, V, sh_dc, sh_unk, q_ent[slot], q_si[slot], q_fx[slot], q_pi[slot]);
+            }
+            head += take;
         }
     }
 }
@@ -409,14 +440,31 @@ __device__ static void gf_idc_predict_wave(GPic *g, int i, uint8_t *rowbuf, uint
  * (HvqParseResult.pad[0] = 2); !FLAT = the chains, for those pictures (`redo` lists them) or, with HVQM4_AMD_PARSE_FLAT=0,
  * for all.  One kernel with both paths costs the flat path 5 % (93 instead of 12 spilled SGPRs in the chains it shares,
  * profiles/r02ak_*). */
+#ifdef GP_PROBE
+#define GP_PROBE_ARG , uint32_t exit_word
+#else
+#define GP_PROBE_ARG
+#endif
 template <bool FLAT>
 __global__ __launch_bounds__(GPW) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
 void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__restrict__ results, uint32_t rowbuf_stride,
                         const uint32_t *__restrict__ redo,           /* optional: the pictures to parse, one per workgroup */
-                        uint64_t *__restrict__ timing)               /* optional: 16 phase timestamps per picture (100 MHz clock) */
+                        uint64_t *__restrict__ timing                /* optional: 16 phase timestamps per picture (100 MHz clock) */
+                        GP_PROBE_ARG)
 {
     const uint32_t pic = redo ? redo[blockIdx.x] : blockIdx.x;
+#ifdef GP_PROBE
+    /* probe builds (tools/r04_parse_phases.sh): the whole workgroup leaves at stamp `exit_at` -- what the kernel has cost up to there */
+    /* skip: 1 decode waves, 2 type/proc chains, 4 vector chains; bits 16-19: K > 0 = only the first K workgroups dealt to a CU go past the trees */
+    const uint32_t probe_skip = (exit_word >> 8) & 0xFFu, probe_k = (exit_word >> 16) & 15u;
+    const uint32_t exit_at = (probe_k && ((blockIdx.x >> 8) & 7u) >= probe_k) ? 1u : (exit_word & 0xFFu);
+#define GP_STAMP(k) do { if (timing && tid == 0) timing[16 * pic + (k)] = wall_clock64(); \
+                         if (exit_at == (uint32_t)(k) || (exit_at == 12u && !g.is_pb && (k) == 14)) return; } while (0)
+#define GP_SKIP(bit) (probe_skip & (bit))
+#else
 #define GP_STAMP(k) do { if (timing && tid == 0) timing[16 * pic + (k)] = wall_clock64(); } while (0)
+#define GP_SKIP(bit) 0
+#endif
     extern __shared__ uint8_t s_rowbuf[];            /* 3 * rowbuf_stride */
     __shared__ GPic g;
     GCode *codes = (GCode *)(gp_stage + GP_STAGE_DWORDS);              /* the six trees follow the staging slots */
@@ -493,29 +541,29 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
          * rare long codes would hold the other lanes up, have their own); P/B: the type and proc runs beside them */
         if (!is_pb) {
             const uint32_t dc_lanes = 7u << GF_DC0;
-            if (role == 0) { gf_decode_wave(&g, codes, lane, ~dc_lanes); if (timing && lane == 0) timing[16 * pic + 5] = wall_clock64(); }
-            else if (role == 2) gf_decode_wave(&g, codes, lane, dc_lanes);
+            if (role == 0) { gf_decode_wave(&g, codes, lane, GP_SKIP(1u) ? 0u : ~dc_lanes); if (timing && lane == 0) timing[16 * pic + 5] = wall_clock64(); }
+            else if (role == 2) gf_decode_wave(&g, codes, lane, GP_SKIP(1u) ? 0u : dc_lanes);
             else if (role == 1) gf_stage_wave(&g, lane, 2u);
         } else {
-            if (role == 0) { gf_decode_wave(&g, codes, lane, ~0u); if (timing && lane == 0) timing[16 * pic + 5] = wall_clock64(); }
+            if (role == 0) { gf_decode_wave(&g, codes, lane, GP_SKIP(1u) ? 0u : ~0u); if (timing && lane == 0) timing[16 * pic + 5] = wall_clock64(); }
             else if (role == 1) gf_stage_wave(&g, lane, 1u);
             else {
                 /* the type runs, then the x components of the vectors (which need nothing but the type bytes); the proc runs,
                  * then -- once the types are there -- the y components */
                 const int comp = role - 2;
                 if (comp == 0) {
-                    gp_mbtypes(&g, codes);
+                    if (!GP_SKIP(2u)) gp_mbtypes(&g, codes); else g.ntrun = 0;
                     if (timing && lane == 0) timing[16 * pic + 2] = wall_clock64();
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     GF_ST(gf_types_done, 1u);
                 } else {
-                    gp_mbprocs(&g, codes);
+                    if (!GP_SKIP(2u)) gp_mbprocs(&g, codes); else { g.nprun = 0; g.pend = 0; }
                     for (uint32_t spin = 0; !GF_LD(gf_types_done) && spin < GF_SPIN_CAP; ++spin) __builtin_amdgcn_s_sleep(4);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
                 GBits *b = comp ? &g.mvv : &g.mvh;
                 b->slot = GF_SIDE_SLOT + (uint32_t)comp; b->base = ~0u;
-                const uint32_t f = gp_mvs(&g, codes, comp, GF_SIDE_SLOT + 2u + (uint32_t)comp);
+                const uint32_t f = GP_SKIP(4u) ? 0u : gp_mvs(&g, codes, comp, GF_SIDE_SLOT + 2u + (uint32_t)comp);
                 GP_ST(g.part[GP_MISC + 13 + comp], f);
                 if (timing && lane == 0) timing[16 * pic + (comp ? 15 : 11)] = wall_clock64();
             }
@@ -712,14 +760,35 @@ extern "C" hipError_t hvq_launch_parse(const HvqParseJob *jobs_dev, HvqParseResu
                                        hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
+#ifdef GP_PROBE
+    if (use_flat)
+        hipLaunchKernelGGL(hvq_parse_kernel_t<true>, dim3(n), dim3(GPW), 3 * (size_t)rowbuf_stride, stream, jobs_dev, results_dev,
+                           rowbuf_stride, redo_dev, timing_dev, 0xFFu);
+    else
+        hipLaunchKernelGGL(hvq_parse_kernel_t<false>, dim3(n), dim3(GPW), 3 * (size_t)rowbuf_stride, stream, jobs_dev, results_dev,
+                           rowbuf_stride, redo_dev, timing_dev, 0xFFu);
+#else
     if (use_flat)
         hipLaunchKernelGGL(hvq_parse_kernel_t<true>, dim3(n), dim3(GPW), 3 * (size_t)rowbuf_stride, stream, jobs_dev, results_dev,
                            rowbuf_stride, redo_dev, timing_dev);
     else
         hipLaunchKernelGGL(hvq_parse_kernel_t<false>, dim3(n), dim3(GPW), 3 * (size_t)rowbuf_stride, stream, jobs_dev, results_dev,
                            rowbuf_stride, redo_dev, timing_dev);
+#endif
     return hipGetLastError();
 }
+
+#ifdef GP_PROBE
+/* the flat kernel, leaving at stamp `exit_at`; writes no result records */
+extern "C" hipError_t hvq_launch_parse_probe(const HvqParseJob *jobs_dev, HvqParseResult *results_dev, uint32_t n, uint32_t rowbuf_stride,
+                                             uint32_t exit_at, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(hvq_parse_kernel_t<true>, dim3(n), dim3(GPW), 3 * (size_t)rowbuf_stride, stream, jobs_dev, results_dev,
+                       rowbuf_stride, (const uint32_t *)nullptr, (uint64_t *)nullptr, exit_at);
+    return hipGetLastError();
+}
+#endif
 
 extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t n, hipStream_t stream)
 {

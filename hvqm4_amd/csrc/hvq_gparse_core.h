@@ -1247,16 +1247,18 @@ GP_FN void gp_dc_scatter(GPic *g, int tid, int nthr)
 }
 
 /* chain: one motion-vector component (comp 0: x from mvh, 1: y from mvv) of every inter macroblock
- * (h4m:1846-1860, 1943-1955); returns HVQ_F_CLAMPED when a target had to be clamped to int16 */
-GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
+ * (h4m:1846-1860, 1943-1955); returns HVQ_F_CLAMPED when a target had to be clamped to int16.
+ * `comp` is a constant at every call site (the body is specialised per component), a run of macroblocks is walked row segment
+ * by row segment (no end-of-row test per vector) and the clamp flag comes from the extremes at the end: the chain is bound by the
+ * scalar instructions it issues. */
+GP_FN __attribute__((always_inline)) uint32_t gp_mvs_comp(GPic *g, const GCode *codes, const int comp, uint32_t list_slot)
 {
     if (g->status) return 0;
     GBits b = comp ? g->mvv : g->mvh;
     const GCode *c = &codes[GC_MV];
     GP_G int16_t *mvs = (GP_G int16_t *)(g->blob + g->mv_off);
     int cur_ref = -1;
-    int32_t acc = 0;
-    uint32_t fl = 0;
+    int32_t acc = 0, pos_min = 0, pos_max = 0;
     /* residual bits per reference, in registers: a table read per vector is an LDS round trip on the chain's critical path */
     const int rb0 = (int)GP_UNI(g->res[2 * comp] & 15), rb1 = (int)GP_UNI(g->res[2 * comp + 1] & 15), rb2 = (int)GP_UNI(g->res[2 * comp + 2] & 15);
     const uint32_t mw = GP_UNI(g->mw), n = mw * GP_UNI(g->mh), nr = GP_UNI(g->ntrun);
@@ -1273,31 +1275,38 @@ GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
         if (ref != cur_ref) { cur_ref = ref; acc = 0; }
         const int rbits = ref == 0 ? rb0 : (ref == 1 ? rb1 : rb2);        /* ref = 2 only from a first type value of 3 */
         const int32_t lim = (int32_t)(1u << (rbits + 5));
-        const uint32_t my0 = m0 / mw;
-        uint32_t mx = m0 - my0 * mw;
-        int32_t at = (int32_t)(comp ? my0 : mx) * 16;                     /* 16 x the macroblock's row resp. column */
+        uint32_t my = m0 / mw, mx = m0 - my * mw;
         GP_G int16_t *out = mvs + 2 * m0 + (uint32_t)comp;
-        for (uint32_t m = m0; m < m1; ++m) {
-            /* symbol and residual bits from one refill: a code from the table is at most 8 bits, the residual at most 15 */
-            int32_t v = (int32_t)((uint32_t)gsym(c, &b) << rbits);
-            if (rbits) {
-                if (b.cnt < rbits) gb_refill(&b);
-                v += (int32_t)(uint32_t)(b.acc >> (64 - rbits));
-                b.acc <<= rbits; b.cnt -= rbits;
+        for (uint32_t m = m0; m < m1;) {
+            const uint32_t seg = m + (mw - mx) < m1 ? m + (mw - mx) : m1;  /* to the end of the macroblock row or of the run */
+            int32_t at = (int32_t)(comp ? my : mx) * 16;                  /* 16 x the macroblock's row resp. column */
+            for (; m < seg; ++m) {
+                /* symbol and residual bits from one refill: a code from the table is at most 8 bits, the residual at most 15 */
+                int32_t v = (int32_t)((uint32_t)gsym(c, &b) << rbits);
+                if (rbits) {
+                    if (b.cnt < rbits) gb_refill(&b);
+                    v += (int32_t)(uint32_t)(b.acc >> (64 - rbits));
+                    b.acc <<= rbits; b.cnt -= rbits;
+                }
+                acc += v;
+                if (acc >= lim) acc -= lim << 1;
+                else if (acc < -lim) acc += lim << 1;
+                const int32_t pos = at + acc;
+                if (pos > pos_max) pos_max = pos;
+                if (pos < pos_min) pos_min = pos;
+                GP_ST(*out, (int16_t)(pos > 32767 ? 32767 : (pos < -32768 ? -32768 : pos)));
+                out += 2;
+                if (comp == 0) at += 16;
             }
-            acc += v;
-            if (acc >= lim) acc -= lim << 1;
-            else if (acc < -lim) acc += lim << 1;
-            int32_t pos = at + acc;
-            if (pos > 32767) { pos = 32767; fl |= HVQ_F_CLAMPED; }
-            if (pos < -32768) { pos = -32768; fl |= HVQ_F_CLAMPED; }
-            GP_ST(*out, (int16_t)pos);
-            out += 2;
-            if (comp == 0) at += 16;
-            if (++mx == mw) { mx = 0; at = comp ? at + 16 : 0; }
+            mx = 0; ++my;
         }
     }
-    return fl;
+    return (pos_max > 32767 || pos_min < -32768) ? HVQ_F_CLAMPED : 0u;
+}
+
+GP_FN uint32_t gp_mvs(GPic *g, const GCode *codes, int comp, uint32_t list_slot)
+{
+    return comp ? gp_mvs_comp(g, codes, 1, list_slot) : gp_mvs_comp(g, codes, 0, list_slot);
 }
 
 /* serial (thread 0): result record */

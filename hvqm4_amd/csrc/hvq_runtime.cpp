@@ -35,6 +35,10 @@
 #include "hvq_parse.h"
 #include "hvq_gparse_core.h"
 
+#ifdef GP_PROBE
+extern "C" hipError_t hvq_launch_parse_probe(const HvqParseJob *jobs_dev, HvqParseResult *results_dev, uint32_t n, uint32_t rowbuf_stride,
+                                             uint32_t exit_at, hipStream_t stream);
+#endif
 extern "C" hipError_t hvq_launch_parse(const HvqParseJob *jobs_dev, HvqParseResult *results_dev, uint32_t n,
                                        uint32_t rowbuf_stride, uint32_t use_flat, const uint32_t *redo_dev, uint64_t *timing_dev,
                                        hipStream_t stream);
@@ -939,11 +943,27 @@ static int device_parse_launch(HvqContext *c)
      * read-back copy queued behind the parse kernel would sit on a DMA engine for the whole parse -- and every second batch the
      * NEXT batch's bitstream uploads (copy stream) were dealt to that same engine and started only when the parse ended: periods
      * of 6.2 and 8.4 ms alternating (kernel and copy trace, profiles/r04g_streaming_timeline.txt). */
+#ifdef GP_PROBE
+    /* probe build: HVQM4_AMD_PARSE_EXIT=<stamp> runs the flat kernel up to that stamp first (its own events, time on stderr) */
+    if (const char *ex = getenv("HVQM4_AMD_PARSE_EXIT")) {
+        static hipEvent_t pe0 = nullptr, pe1 = nullptr;
+        static float last_ms = -1.f;
+        if (!pe0) { HIPCHK(hipEventCreate(&pe0)); HIPCHK(hipEventCreate(&pe1)); }
+        else if (hipEventQuery(pe1) == hipSuccess) { float pm = 0; if (hipEventElapsedTime(&pm, pe0, pe1) == hipSuccess) last_ms = pm; }
+        if (last_ms >= 0) fprintf(stderr, "hvqm4_amd parse probe: exit at stamp %d: %.3f ms (previous batch)\n", atoi(ex), last_ms);
+        HIPCHK(hipEventRecord(pe0, c->stream));
+        HIPCHK(hvq_launch_parse_probe(c->pj_dev, c->pr_host, (uint32_t)jobs.size(), rowbuf, (uint32_t)atoi(ex), c->stream));
+        HIPCHK(hipEventRecord(pe1, c->stream));
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+    }
+#endif
     HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_host, (uint32_t)jobs.size(), rowbuf, use_flat ? 1u : 0u, nullptr, c->timing_dev, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventRecord(c->ev_parse, c->stream));
     return HVQ_OK;
 }
+
+static size_t jobs_len_of(const HvqContext *c, size_t k) { return k < c->pjobs_host.size() ? (size_t)c->pjobs_host[k].len : 0; }
 
 /* wait for the parse results of the batch in flight and take them over */
 static int device_parse_finish(HvqContext *c)
@@ -1012,6 +1032,18 @@ static int device_parse_finish(HvqContext *c)
         fprintf(stderr, "hvqm4_amd parse timing: %zu pictures, kernel %.3f ms, first start -> last end %.3f ms, last start +%.3f ms, "
                 "per picture %.3f .. %.3f ms\n",
                 idx.size(), ms, (double)(t_max - t_min) * 1e-5, (double)(s_max - t_min) * 1e-5, (double)d_min * 1e-5, (double)d_max * 1e-5);
+        if (const char *dump = getenv("HVQM4_AMD_PARSE_TIMING_DUMP")) {       /* raw rows of the latest batch: kind, bytes, 16 stamps (10 ns) */
+            static int seq = 0;
+            const std::string path = std::string(dump) + "." + std::to_string(seq++);
+            if (FILE *f = seq <= 12 ? fopen(path.c_str(), "w") : nullptr) {
+                for (size_t k = 0; k < idx.size(); ++k) {
+                    fprintf(f, "%d %zu", (int)c->fl_pending[idx[k]].kind, (size_t)jobs_len_of(c, k));
+                    for (int ph = 0; ph < 16; ++ph) fprintf(f, " %llu", (unsigned long long)(tm[16 * k + ph] ? tm[16 * k + ph] - t_min : 0ull));
+                    fprintf(f, "\n");
+                }
+                fclose(f);
+            }
+        }
         for (int kind = 0; kind < 3; ++kind) {
             if (!pics[kind]) continue;
             std::vector<std::pair<double, int>> ord;
