@@ -77,12 +77,12 @@ __device__ static inline uint64_t gf_ring_window64(const uint32_t *ring, uint32_
     return ((((uint64_t)w0 << 32) | w1) << sh & 0xFFFFFFFF00000000ull) | (((((uint64_t)w1 << 32) | w2) << sh) >> 32);
 }
 
-/* four symbols from a 64-bit window at `pos` (4 x 9 table bits fit it).  A code longer than the lane's table is rare per
- * lane but not per wave -- some lane of the thirteen meets one in every third group -- so it is finished on the spot:
- * the tree is walked bit by bit from the node the table gave, the window is taken anew behind it, the other lanes wait
- * for that one symbol only.  `a` = how far the lane's ring is known to reach. */
-__device__ static inline uint2 gf_four(const GCode *c, const uint32_t *tab, int bits, const uint32_t *ring, int l,
-                                       uint32_t *ppos, uint32_t *pa, uint32_t nbits, uint32_t *guard)
+/* four symbols (leaf bytes) from a 64-bit window at `pos` (4 x 10 table bits fit it).  A code longer than the lane's table
+ * is rare per lane but not per wave, so it is finished on the spot: the tree is walked bit by bit from the node the table
+ * gave, the window is taken anew behind it, the other lanes wait for that one symbol only.  `a` = how far the lane's ring is
+ * known to reach. */
+__device__ static inline uint32_t gf_four(const GCode *c, const uint16_t *tab, int bits, const uint32_t *ring, int l,
+                                          uint32_t *ppos, uint32_t *pa, uint32_t nbits, uint32_t *guard)
 {
     uint32_t pos = *ppos;
     uint64_t w = gf_ring_window64(ring, pos);
@@ -99,7 +99,7 @@ __device__ static inline uint2 gf_four(const GCode *c, const uint32_t *tab, int 
             GF_ST(gf_pos_pub[l], pos);
             while ((*pa = GF_LD(gf_avail_pub[l])) < pos + GF_AHEAD_SLOW && ++*guard <= GF_SPIN_CAP) __builtin_amdgcn_s_sleep(1);
         }
-        int id = (int)(e >> 16);
+        int id = (int)(e >> 8) + 256;
         w = gf_ring_window64(ring, pos);                   /* the bits behind the table's part of the code */
         for (uint32_t left = 64; id >= 256; --left) {
             if (left == 0) { w = gf_ring_window64(ring, pos); left = 64; }
@@ -107,13 +107,14 @@ __device__ static inline uint2 gf_four(const GCode *c, const uint32_t *tab, int 
             id = c->kid[bit][id - 256];
             w <<= 1; ++pos;
         }
-        sy[k] = (uint32_t)gc_leaf(c, id) << 16;
+        sy[k] = (uint32_t)id << 8;
 #ifdef GF_PROFILE
         gf_slow_count++;
 #endif
     }
     *ppos = pos;
-    return make_uint2(__builtin_amdgcn_perm(sy[1], sy[0], 0x07060302u), __builtin_amdgcn_perm(sy[3], sy[2], 0x07060302u));
+    /* byte 1 of the four entries */
+    return __builtin_amdgcn_perm(__builtin_amdgcn_perm(sy[3], sy[2], 0x0C0C0501u), __builtin_amdgcn_perm(sy[1], sy[0], 0x0C0C0501u), 0x05040100u);
 }
 
 /* the lanes of this wave decode one section each, in lockstep (gf_decode_lane is the same loop for one lane): eight
@@ -127,9 +128,9 @@ __device__ static void gf_decode_wave(GPic *g, const GCode *codes, int lane, uin
     const bool mine = lane < nl && ((lanes >> lane) & 1u) && c->root >= 256 && !g->status;
     const uint32_t end = mine ? q->end : 0u, cap = q->cap, nbits = g->nd * 32u;
     uint32_t pos = q->pos, n = 0, guard = 0;
-    GP_G int16_t *out = g->sym + q->off;
+    GP_G uint8_t *out = (GP_G uint8_t *)(g->sym + q->off);
     const uint32_t *ring = gf_ring(l);
-    const uint32_t *tab = gf_lane_table(c, (int)q->tree);
+    const uint16_t *tab = gf_lane_table(c, (int)q->tree);
     const int bits = gf_lane_bits((int)q->tree);
 #ifdef GF_PROFILE
     uint64_t ta = 0, tb = 0, rounds = 0;
@@ -154,9 +155,9 @@ __device__ static void gf_decode_wave(GPic *g, const GCode *codes, int lane, uin
         if (guard > GF_SPIN_CAP) { g->retry = 1; break; }
         GF_T(t1);
         if (act) {
-            const uint2 lo = gf_four(c, tab, bits, ring, l, &pos, &a, nbits, &guard);
-            const uint2 hi = gf_four(c, tab, bits, ring, l, &pos, &a, nbits, &guard);
-            *(GP_G uint4 *)(out + n) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            const uint32_t lo = gf_four(c, tab, bits, ring, l, &pos, &a, nbits, &guard);
+            const uint32_t hi = gf_four(c, tab, bits, ring, l, &pos, &a, nbits, &guard);
+            *(GP_G uint2 *)(out + n) = make_uint2(lo, hi);
             n += 8;
         }
 #ifdef GF_PROFILE
@@ -274,7 +275,7 @@ __device__ static inline uint32_t gfd_dpp_incl(uint32_t v)
  * entry-per-lane form (which was the largest single consumer of vector instructions in the kernel). */
 #define GFD_MQ 128u                                                /* records per wave: 4 arrays of 128 dwords */
 
-__device__ static inline void gfd_merge_one(const GPic *g, GP_G uint32_t *pool, const GP_G int16_t *S, const GP_G uint32_t *V,
+__device__ static inline void gfd_merge_one(const GPic *g, GP_G uint32_t *pool, const GP_G uint8_t *S, const GP_G uint32_t *V,
                                             int sh_dc, int sh_unk, uint32_t ent, uint32_t my_si, uint64_t my_fx, uint32_t my_pi)
 {
     const uint32_t mode = ent >> 30;
@@ -293,21 +294,21 @@ __device__ static inline void gfd_merge_one(const GPic *g, GP_G uint32_t *pool, 
         dst += 2;
     }
     uint32_t run = 0;
-    /* eight bases a time from two 16-byte loads (words and symbols lie consecutive; both arrays and the picture are
-     * padded far enough to read a full block) */
+    /* eight bases a time from a 16-byte and an 8-byte load (words and symbols -- leaf bytes of the coefficient tree, value =
+     * byte << 2 -- lie consecutive; both arrays and the picture are padded far enough to read a full block) */
     for (uint32_t k0 = 0; k0 < nb; k0 += 8) {
         const uint64_t wo = my_fx + 2u * k0;
         uint32_t wq[4];
         if (__builtin_expect(wo + 16u <= (uint64_t)g->nd * 4u, 1)) __builtin_memcpy(wq, (const GP_G uint8_t *)g->d + wo, 16);
         else for (uint32_t j = 0; j < 4; ++j) wq[j] = __builtin_bswap32((gp_be16(g, wo + 4u * j) << 16) | gp_be16(g, wo + 4u * j + 2u));
-        uint32_t sq[4];
-        __builtin_memcpy(sq, S + my_si + k0, 16);
+        uint32_t sq[2];
+        __builtin_memcpy(sq, S + my_si + k0, 8);
 #pragma unroll
         for (uint32_t j = 0; j < 8; ++j) {
             if (k0 + j >= nb) break;
             const uint32_t half = (wq[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu;           /* bytes b0 b1 of the word, b0 low */
             const uint32_t w = ((half & 0xFFu) << 8) | (half >> 8);
-            run += (uint32_t)(int32_t)(int16_t)(sq[j >> 1] >> (16u * (j & 1u)));
+            run += ((sq[j >> 2] >> (8u * (j & 3u))) & 0xFFu) << 2;
             dst[k0 + j] = HVQ_BASIS(w, (run + ((w >> 13) & 3u)) & 0x3FFFFu);
         }
     }
@@ -327,7 +328,7 @@ __device__ static void gfd_emit_merge(GPic *g, int tid)
     uint32_t *q_ent = gp_stage + 4u * GFD_MQ * (uint32_t)wave, *q_si = q_ent + GFD_MQ, *q_fx = q_si + GFD_MQ, *q_pi = q_fx + GFD_MQ;
     for (int i = 0; i < 3; ++i) {
         const GP_G uint32_t *ents = GFD_UNIP(const GP_G uint32_t *, g->pinfo + g->pl[i].blk_first);
-        const GP_G int16_t *S = GFD_UNIP(const GP_G int16_t *, g->sym + g->lane[GF_BT0 + i].off);
+        const GP_G uint8_t *S = GFD_UNIP(const GP_G uint8_t *, g->sym + g->lane[GF_BT0 + i].off);
         const GP_G uint32_t *V = GFD_UNIP(const GP_G uint32_t *, g->val + g->val_off[i] + g->ntype0 * (uint32_t)g->pl[i].nblk);
         const uint32_t n = GP_UNI(g->pl[i].nblocks), per = (n + GPW - 1) / GPW;
         const uint32_t e0 = per * 64u * (uint32_t)wave < n ? per * 64u * (uint32_t)wave : n;
@@ -499,8 +500,9 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
     if (is_pb && wave < 2) gp_read_tree(&g, codes, GC_MV + wave);  /* MV, MCB */
     __syncthreads();
     if (wave == 0) gp_collect_tree_status(&g, ntrees);
-    for (int c = 0; c < ntrees; ++c) gc_fill_lut(&codes[c], tid, GPW);
-    if (flat) gf_fill_xlut(&g, codes, tid, GPW);
+    /* the chains read 8-bit tables with the leaf's value in the entry; the flat path's lanes have their own (gf_fill_lane_tables) */
+    for (int c = flat ? GC_MV : 0; c < ntrees; ++c) gc_fill_lut(&codes[c], tid, GPW);
+    if (flat) gf_fill_lane_tables(&g, codes, tid, GPW);
     __syncthreads();
     GP_STAMP(1);
 

@@ -4,6 +4,11 @@
  * hvq_gparse_core.h did symbol by symbol -- zero runs, overflow grouping, DC prediction, running coefficient sums --
  * becomes scans over those arrays by all threads.
  *
+ * The symbol arrays hold LEAF BYTES (round 4): a lane's table entry is 16 bits -- bits consumed, leaf flag, leaf byte or inner
+ * node -- which lets the block-kind tree have a 10-bit table and the others 9-bit ones in the LDS the 8-bit tables with 32-bit
+ * entries took, and the value of a leaf (h4m:613-617) is computed by whoever reads the array: 64 lanes at a time there, a
+ * dozen in the decode wave.
+ *
  * Why this is exact: a section's symbol boundaries depend on nothing but its own bits and its tree (h4m:644-651); what
  * the reference's loops decide from OTHER sections is only how many symbols of a section are consumed and what they
  * mean.  (The exceptions keep their chains: a motion vector is a symbol plus `res` raw bits where `res` depends on the
@@ -52,11 +57,25 @@ GP_FN void gp_chunk_min(uint32_t n, int tid, int nthr, uint32_t minper, uint32_t
 /* eight consecutive symbols / four consecutive values with one 16-byte load (p 16-byte aligned): the passes below walk
  * their chunk in such blocks -- a load instruction of a wave touches 64 cache lines whatever its width */
 typedef struct { uint32_t x, y, z, w; } GfQuad;
-GP_FN void gf_ld8(const GP_G int16_t *p, int32_t *o)
+typedef struct { uint32_t x, y; } GfPair;
+
+/* value of leaf byte `b` of tree `tree` (gc_leaf with the tree's parameters of gp_read_tree: block kinds and run lengths are the
+ * byte, DC symbols the signed byte << dc_shift, coefficient symbols the byte << 2; an empty section's tree has the one leaf 0) */
+GP_FN int32_t gf_leaf_value(const GPic *g, int tree, uint32_t b)
 {
-    const GfQuad q = *(const GP_G GfQuad *)p;
-    o[0] = (int16_t)q.x; o[1] = (int32_t)q.x >> 16; o[2] = (int16_t)q.y; o[3] = (int32_t)q.y >> 16;
-    o[4] = (int16_t)q.z; o[5] = (int32_t)q.z >> 16; o[6] = (int16_t)q.w; o[7] = (int32_t)q.w >> 16;
+    if (tree == GC_DC) return (int16_t)((uint32_t)(int32_t)(int8_t)(uint8_t)b << (g->dc_shift & 31));
+    if (tree == GC_BT) return (int32_t)((b & 0xFFu) << 2);
+    return (int32_t)(b & 0xFFu);
+}
+
+/* the symbols of lane `l`: leaf bytes, the lane's region of GPic.sym taken as bytes */
+GP_FN const GP_G uint8_t *gf_lane_syms(const GPic *g, int l) { return (const GP_G uint8_t *)(g->sym + g->lane[l].off); }
+
+/* eight consecutive symbols (p 8-byte aligned) as values of tree `tree` */
+GP_FN void gf_ld8(const GPic *g, int tree, const GP_G uint8_t *p, int32_t *o)
+{
+    const GfPair q = *(const GP_G GfPair *)p;
+    for (int k = 0; k < 4; ++k) { o[k] = gf_leaf_value(g, tree, q.x >> (8 * k)); o[4 + k] = gf_leaf_value(g, tree, q.y >> (8 * k)); }
 }
 GP_FN void gf_ld4(const GP_G uint32_t *p, uint32_t *o)
 {
@@ -111,14 +130,26 @@ GP_FN void gf_setup_lanes(GPic *g)
     }
 }
 
-/* the table a lane decodes with: the tree's own 8-bit one, or -- coefficient symbols, most of a picture's symbols and in
- * dense streams spread over 7 to 9 bits -- the 9-bit one behind the trees (gf_fill_xlut) */
-GP_FN const uint32_t *gf_lane_table(const GCode *c, int tree) { return tree == GC_BT ? gp_stage + GP_XLUT_DWORD : c->lut; }
-GP_FN int gf_lane_bits(int tree) { return tree == GC_BT ? GP_XLUT_BITS : GP_LUT_BITS; }
-GP_FN void gf_fill_xlut(const GPic *g, const GCode *codes, int tid, int nthr)
+/* The table a lane decodes with: 16-bit entries -- [5:0] bits consumed, [7] leaf reached, [15:8] the leaf byte or the inner node
+ * (id - 256) -- in the LDS of the 8-bit tables with 32-bit entries the lanes' trees do not need on this path (their `lut`
+ * arrays, 1 KB each) and of the 2 KB behind the trees: 10 bits for the block kinds (a chroma pair's code is 9 or 10 bits in a
+ * dense stream: 45 % of them missed an 8-bit table, and every miss holds all lanes up for a walk through the tree), 9 bits for
+ * run lengths, DC symbols (a third of whose rare long codes are 9 bits) and coefficient symbols (7 to 9 bits). */
+GP_FN int gf_lane_bits(int tree) { return tree == GC_BN ? 10 : 9; }
+GP_FN uint16_t *gf_lane_table(const GCode *c, int tree) { return (uint16_t *)(tree == GC_BN ? gp_stage + GP_XLUT_DWORD : (uint32_t *)c->lut); }
+GP_FN void gf_fill_lane_tables(const GPic *g, GCode *codes, int tid, int nthr)
 {
     if (g->status) return;
-    gc_fill_table(&codes[GC_BT], gp_stage + GP_XLUT_DWORD, GP_XLUT_BITS, tid, nthr);
+    for (int tree = GC_BN; tree <= GC_BT; ++tree) {
+        const GCode *c = &codes[tree];
+        uint16_t *tab = gf_lane_table(c, tree);
+        const int bits = gf_lane_bits(tree), root = c->root;
+        for (int e = tid; e < (1 << bits); e += nthr) {
+            int node = root, d = 0;
+            while (node >= 256 && d < bits) { node = c->kid[(e >> (bits - 1 - d)) & 1][node - 256]; ++d; }
+            tab[e] = (uint16_t)((uint32_t)d | (node < 256 ? 0x80u | ((uint32_t)node << 8) : (uint32_t)(node - 256) << 8));
+        }
+    }
 }
 
 #if !(defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__))
@@ -139,23 +170,21 @@ GP_FN void gf_decode_lane(GPic *g, const GCode *codes, int l)
     if (g->status) return;
     GLane *q = &g->lane[l];
     const GCode *c = &codes[q->tree];
-    const uint32_t *tab = gf_lane_table(c, (int)q->tree);
+    const uint16_t *tab = gf_lane_table(c, (int)q->tree);
     const int bits = gf_lane_bits((int)q->tree);
-    GP_G int16_t *out = g->sym + q->off;
+    GP_G uint8_t *out = (GP_G uint8_t *)(g->sym + q->off);
     uint32_t pos = q->pos, n = 0;
     if (c->root < 256) { q->n = 0; return; }                  /* one-leaf tree: gf_fill_const */
     while (pos < q->end && n + 8 <= q->cap) {
         for (int k = 0; k < 8; ++k) {
             const uint32_t e = tab[gf_peek64(g, pos) >> (64 - bits)];
             pos += e & 63u;
-            int32_t v;
-            if (e & 0x80u) v = (int16_t)(e >> 16);
-            else {
-                int id = (int)(e >> 16);
+            int id = (int)(e >> 8);
+            if (!(e & 0x80u)) {
+                id += 256;
                 while (id >= 256) { id = c->kid[gf_peek64(g, pos) >> 63][id - 256]; ++pos; }
-                v = gc_leaf(c, id);
             }
-            out[n++] = (int16_t)v;
+            out[n++] = (uint8_t)id;
         }
     }
     q->n = n;
@@ -171,8 +200,8 @@ GP_FN void gf_fill_const(GPic *g, const GCode *codes, int tid, int nthr)
         const GLane *q = &g->lane[l];
         const GCode *c = &codes[q->tree];
         if (c->root >= 256) continue;
-        const int16_t v = (int16_t)gc_leaf(c, c->root);
-        GP_G int16_t *out = g->sym + q->off;
+        const uint8_t v = (uint8_t)c->root;
+        GP_G uint8_t *out = (GP_G uint8_t *)(g->sym + q->off);
         for (uint32_t j = (uint32_t)tid; j < q->cap; j += (uint32_t)nthr) out[j] = v;
     }
 }
@@ -216,12 +245,12 @@ GP_FN void gf_dc_count(GPic *g, int tid, int nthr)
     const int32_t wlo = g->dc_lo, whi = g->dc_hi;
     for (int i = 0; i < 3; ++i) {
         const GLane *q = &g->lane[GF_DC0 + i];
-        const GP_G int16_t *S = g->sym + q->off;
+        const GP_G uint8_t *S = gf_lane_syms(g, GF_DC0 + i);
         uint32_t lo, hi, T = 0, sum = 0, has = 0, run = 0, mx = 0;
         gp_chunk8(q->n, tid, nthr, 16, &lo, &hi);
         for (uint32_t j0 = lo; j0 < hi; j0 += 8) {
             int32_t b[8];
-            gf_ld8(S + j0, b);
+            gf_ld8(g, GC_DC, S + j0, b);
             const uint32_t m = hi - j0 < 8u ? hi - j0 : 8u;
             for (uint32_t k = 0; k < m; ++k) {
                 const int32_t s = b[k];
@@ -243,13 +272,13 @@ GP_FN void gf_dc_values(GPic *g, int tid, int nthr)
     const int32_t wlo = g->dc_lo, whi = g->dc_hi;
     for (int i = 0; i < 3; ++i) {
         const GLane *q = &g->lane[GF_DC0 + i];
-        const GP_G int16_t *S = g->sym + q->off;
+        const GP_G uint8_t *S = gf_lane_syms(g, GF_DC0 + i);
         GP_G uint32_t *V = g->val + g->val_off[i];
         uint32_t lo, hi, vi = g->part[GF_P(GF_I_TERM(i), tid)], sum = g->part[GF_P(GF_I_DCV(i), tid)];
         gp_chunk8(q->n, tid, nthr, 16, &lo, &hi);
         for (uint32_t j0 = lo; j0 < hi; j0 += 8) {
             int32_t b[8];
-            gf_ld8(S + j0, b);
+            gf_ld8(g, GC_DC, S + j0, b);
             const uint32_t m = hi - j0 < 8u ? hi - j0 : 8u;
             for (uint32_t k = 0; k < m; ++k) {
                 const int32_t s = b[k];
@@ -265,9 +294,9 @@ GP_FN void gf_dc_values(GPic *g, int tid, int nthr)
  * run length from a second section and leaves 1 + run blocks at zero.  Expansions: 0 = kinds Y, 1 = kinds U+V (slots of
  * the coded macroblocks in a P/B picture), 2-4 = DC deltas of an I picture's planes. */
 typedef struct {
-    const GP_G int16_t *t16;
-    const GP_G uint32_t *t32;
-    const GP_G int16_t *run;
+    const GP_G uint8_t *t8;              /* tokens: leaf bytes of the block-kind tree (their own values) ... */
+    const GP_G uint32_t *t32;            /* ... or DC values */
+    const GP_G uint8_t *run;             /* run lengths: leaf bytes of the run tree (their own values) */
     uint32_t ntok, nrun, N;
 } GExp;
 
@@ -275,15 +304,15 @@ GP_FN int gf_exp(const GPic *g, int x, GExp *e)
 {
     if (x < 2) {
         const GLane *t = &g->lane[GF_BN0 + x], *r = &g->lane[GF_BNR0 + x];
-        e->t16 = g->sym + t->off; e->t32 = 0; e->ntok = t->n;
-        e->run = g->sym + r->off; e->nrun = r->n;
+        e->t8 = gf_lane_syms(g, GF_BN0 + x); e->t32 = 0; e->ntok = t->n;
+        e->run = gf_lane_syms(g, GF_BNR0 + x); e->nrun = r->n;
         e->N = g->is_pb ? g->ncoded * (uint32_t)g->pl[x].nblk : g->pl[x].nblocks;
     } else {
         if (g->is_pb) return 0;
         const int i = x - 2;
         const GLane *r = &g->lane[GF_RLE0 + i];
-        e->t16 = 0; e->t32 = g->val + g->val_off[i]; e->ntok = g->nv[i];
-        e->run = g->sym + r->off; e->nrun = r->n;
+        e->t8 = 0; e->t32 = g->val + g->val_off[i]; e->ntok = g->nv[i];
+        e->run = gf_lane_syms(g, GF_RLE0 + i); e->nrun = r->n;
         e->N = g->pl[i].nblocks;
     }
     if (e->ntok > e->N) e->ntok = e->N;                       /* a token covers at least one block */
@@ -293,7 +322,7 @@ GP_FN int gf_exp(const GPic *g, int x, GExp *e)
 /* tokens j0 .. j0 + 7 (j0 a multiple of 8; the arrays are padded to whole blocks) */
 GP_FN void gf_tok8(const GExp *e, uint32_t j0, uint32_t *t)
 {
-    if (e->t16) { int32_t b[8]; gf_ld8(e->t16 + j0, b); for (int k = 0; k < 8; ++k) t[k] = (uint32_t)(uint16_t)b[k]; }
+    if (e->t8) { const GfPair q = *(const GP_G GfPair *)(e->t8 + j0); for (int k = 0; k < 4; ++k) { t[k] = (q.x >> (8 * k)) & 0xFFu; t[4 + k] = (q.y >> (8 * k)) & 0xFFu; } }
     else { gf_ld4(e->t32 + j0, t); gf_ld4(e->t32 + j0 + 4, t + 4); }
 }
 
@@ -589,7 +618,7 @@ GP_FN void gf_emit_merge(GPic *g, int tid, int nthr)
     const int sh_dc = g->dc_shift & 31, sh_unk = g->unk_shift & 31;
     for (int i = 0; i < 3; ++i) {
         const GP_G uint32_t *ents = g->pinfo + g->pl[i].blk_first;
-        const GP_G int16_t *S = g->sym + g->lane[GF_BT0 + i].off;
+        const GP_G uint8_t *S = gf_lane_syms(g, GF_BT0 + i);
         const GP_G uint32_t *V = g->val + g->val_off[i] + g->ntype0 * (uint32_t)g->pl[i].nblk;
         uint32_t lo, hi;
         gp_chunk(g->pl[i].nblocks, tid, nthr, &lo, &hi);
@@ -621,7 +650,7 @@ GP_FN void gf_emit_merge(GPic *g, int tid, int nthr)
                 for (uint32_t j = 0; j < 4; ++j) {
                     const int live = k0 + j < nb;
                     w[j] = live ? gp_be16(g, fx + 2u * (k0 + j)) : 0u;
-                    sv[j] = live ? S[si + k0 + j] : 0;
+                    sv[j] = live ? (int32_t)S[si + k0 + j] << 2 : 0;          /* gf_leaf_value of the coefficient tree */
                 }
                 for (uint32_t j = 0; j < 4; ++j) {
                     run += (uint32_t)sv[j];
