@@ -88,6 +88,20 @@ __device__ static inline uint32_t gf_four(const GCode *c, const uint16_t *tab, i
     uint64_t w = gf_ring_window64(ring, pos);
     const int down = 64 - bits;
     uint32_t sy[4];
+    {   /* all four straight from the table, no lane looking left or right: with the tables of round 4 four groups in five end
+         * here.  (An entry that is no leaf consumes its table bits; what is looked up behind it is not used.) */
+        const uint32_t e0 = tab[w >> down];
+        const uint64_t w1 = w << (e0 & 63u);
+        const uint32_t e1 = tab[w1 >> down];
+        const uint64_t w2 = w1 << (e1 & 63u);
+        const uint32_t e2 = tab[w2 >> down];
+        const uint64_t w3 = w2 << (e2 & 63u);
+        const uint32_t e3 = tab[w3 >> down];
+        if (!__builtin_amdgcn_ballot_w64(((e0 & e1 & e2 & e3) & 0x80u) == 0)) {
+            *ppos = pos + (e0 & 63u) + (e1 & 63u) + (e2 & 63u) + (e3 & 63u);
+            return __builtin_amdgcn_perm(__builtin_amdgcn_perm(e3, e2, 0x0C0C0501u), __builtin_amdgcn_perm(e1, e0, 0x0C0C0501u), 0x05040100u);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t e = tab[w >> down];
