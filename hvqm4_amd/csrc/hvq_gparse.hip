@@ -591,11 +591,14 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
             __syncthreads();
             gp_tags_count(&g, tid, GPW);
             __syncthreads();
-            if (wave == 0) gp_tags_scan(&g, GPW);
+            /* gp_tags_scan / gp_lists_scan as wave scans: one thread walking 256 words of HBM, each store in the way of the next
+             * load, took longer than the passes on either side of it */
+            if (wave == 0 && !g.status) gfd_scan_add(&g, 0, lane, 0);
             __syncthreads();
             gp_tags_assign(&g, tid, GPW);
             __syncthreads();
-            if (wave == 0) gp_lists_scan(&g, GPW);
+            if (wave == 0 && !g.status) gfd_scan_add(&g, GP_EP(0, 0, 0) / 256, lane, &g.ncoded);
+            else if (wave == 1 && !g.status) gfd_scan_add(&g, GP_EP(0, 1, 0) / 256, lane, &g.ntype0);
             __syncthreads();
             gp_lists_write(&g, tid, GPW);
             __syncthreads();
