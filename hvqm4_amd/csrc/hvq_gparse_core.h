@@ -222,32 +222,35 @@ GP_FN int32_t gc_leaf(const GCode *c, int b)
     return (int16_t)((uint32_t)v << c->scale);
 }
 
-/* serial: read the tree that heads `carrier` (h4m:604-642); iterative form of hvq_parse.c code_node */
+/* serial: read the tree that heads `carrier` (h4m:604-642); iterative form of hvq_parse.c code_node.  The cursor is worked on in
+ * registers and put back at the end: through the pointer every step of it was an LDS write */
 GP_FN void gc_read(GCode *c, GBits *carrier, int is_signed, int scale, uint32_t *status, uint32_t *flags)
 {
     c->root = 0; c->sgn = 0; c->scale = 0;        /* a tree from an empty section: leaf byte 0, value 0 */
     if (!carrier->live) { (void)flags; return; }
     c->sgn = (uint8_t)is_signed; c->scale = (uint8_t)scale;
+    GBits b = *carrier;
     uint16_t *stk = (uint16_t *)c->lut;
-    int sp = 0, next = 0x100;
+    int sp = 0, next = 0x100, root = 0;
     for (;;) {
         int val;
-        gb_refill(carrier);                                 /* at least 33 bits: a leaf is '0' + its byte, looked at in one go */
-        const uint32_t nine = (uint32_t)(carrier->acc >> 55);
+        gb_refill(&b);                                      /* at least 33 bits: a leaf is '0' + its byte, looked at in one go */
+        const uint32_t nine = (uint32_t)(b.acc >> 55);
         if (!(nine & 0x100u)) {
             val = (int)(nine & 0xFFu);
-            carrier->acc <<= 9; carrier->cnt -= 9;
+            b.acc <<= 9; b.cnt -= 9;
         } else {
-            carrier->acc <<= 1; carrier->cnt -= 1;
+            b.acc <<= 1; b.cnt -= 1;
             /* a tree over 256 leaf bytes has at most 255 inner nodes (ids 256..510) and so nests at most 255 deep;
              * anything more is malformed, and would let node 511 become its own child (an endless walk in gsym) */
-            if (next >= 511 || sp >= 256) { *status |= GP_ST_BADTREE; c->root = 0; c->sgn = 0; c->scale = 0; return; }
+            if (next >= 511 || sp >= 256) { *status |= GP_ST_BADTREE; c->sgn = 0; c->scale = 0; root = 0; break; }
             const int id = next++;
             stk[sp++] = (uint16_t)id;
             continue;
         }
+        int done = 0;
         for (;;) {                                  /* hand the finished subtree to its parent */
-            if (sp == 0) { c->root = val; return; }
+            if (sp == 0) { root = val; done = 1; break; }
             const uint16_t top = stk[sp - 1];
             const int id = top & 0x3FF;
             if (!(top & 0x8000u)) { c->kid[0][id - 256] = (uint16_t)val; stk[sp - 1] = (uint16_t)(top | 0x8000u); break; }
@@ -255,7 +258,10 @@ GP_FN void gc_read(GCode *c, GBits *carrier, int is_signed, int scale, uint32_t 
             --sp;
             val = id;
         }
+        if (done) break;
     }
+    c->root = root;
+    *carrier = b;
 }
 
 /* parallel: thread `tid` of `nthr` fills its share of a first-level table of `bits` index bits */
