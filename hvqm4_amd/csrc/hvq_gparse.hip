@@ -350,10 +350,12 @@ __device__ static void gfd_emit_merge(GPic *g, int tid)
         uint64_t fx = gfd_uni64(g->fx_off[i] + g->part[GF_P(GF_I_FX(i), 64 * wave)]);
         uint32_t si = GP_UNI(g->part[GF_P(GF_I_NB(i), 64 * wave)]), pi = GP_UNI(g->part[GF_P(GF_I_PREDI(i), 64 * wave)]);
         uint32_t head = 0, tail = 0;                                  /* records taken / put so far (wave-uniform) */
+        uint32_t ent_next = e0 + (uint32_t)lane < e1 ? ents[e0 + (uint32_t)lane] : 0u;
         for (uint32_t eb = e0; eb < e1 || tail != head; eb += 64) {
             if (eb < e1) {
-                const uint32_t e = eb + (uint32_t)lane;
-                const uint32_t ent = e < e1 ? ents[e] : 0u, mode = ent >> 30;
+                /* the entries of the next step are requested before this step's records are worked on */
+                const uint32_t ent = ent_next, mode = ent >> 30;
+                ent_next = eb + 64u + (uint32_t)lane < e1 ? ents[eb + 64u + (uint32_t)lane] : 0u;
                 const uint32_t nb = mode >= GP_MODE_BASES ? (ent >> 22) & 0xFFu : 0u, fb = gp_ent_fx_bytes(ent), ip = mode == GP_MODE_PREDI;
                 const uint32_t s_nb = gfd_dpp_incl(nb), s_fb = gfd_dpp_incl(fb), s_ip = gfd_dpp_incl(ip);
                 const uint64_t my_fx = fx + (s_fb - fb);

@@ -58,6 +58,11 @@
 #define GP_UNI(x) ((uint32_t)(x))
 #endif
 
+#if defined(__HIPCC__)
+#define GP_UNROLL _Pragma("unroll")
+#else
+#define GP_UNROLL
+#endif
 #define GP_LUT_BITS 8
 /* caps of the overflow-symbol loops (the reference has none: h4m:654-677 loop for as long as the stream says).  A
  * signed-overflow value (DC delta, MC-residual scalar) is a handful of symbols in any real stream; a run count is at

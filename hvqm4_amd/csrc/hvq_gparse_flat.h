@@ -503,12 +503,23 @@ GP_FN void gf_layout_sum(GPic *g, int tid, int nthr)
             uint32_t sum = 0;
             uint32_t by = b0 / (uint32_t)q->hb, bx = b0 - by * (uint32_t)q->hb;
             const GP_G uint8_t *tp8 = gp_map_ent(g, i, (int)by, (int)bx) + 1;      /* type bytes: 2 apart, 4 more over the border */
-            for (uint32_t b = b0; b < b0 + 64u && b < q->nblocks; ++b) {
-                uint32_t n, it, pr, f;
-                gp_type_info(ctx, *tp8, &n, &it, &pr, &f);
-                sum += n; ti += it; tp += pr; fl |= f;
-                tp8 += 2;
-                if (++bx == (uint32_t)q->hb) { bx = 0; tp8 += 4; }
+            const uint32_t bend = b0 + 64u < q->nblocks ? b0 + 64u : q->nblocks;
+            /* eight type bytes requested before the first is looked at: one at a time, a run is 64 round trips to the L2 in a row */
+            for (uint32_t b = b0; b < bend; b += 8) {
+                uint32_t tv[8];
+                const uint32_t m = bend - b < 8u ? bend - b : 8u;
+                GP_UNROLL
+                for (uint32_t j = 0; j < 8; ++j) {
+                    tv[j] = j < m ? *tp8 : 0u;
+                    if (j < m) { tp8 += 2; if (++bx == (uint32_t)q->hb) { bx = 0; tp8 += 4; } }
+                }
+                GP_UNROLL
+                for (uint32_t j = 0; j < 8; ++j) {
+                    uint32_t n, it, pr, f;
+                    if (j >= m) break;
+                    gp_type_info(ctx, tv[j], &n, &it, &pr, &f);
+                    sum += n; ti += it; tp += pr; fl |= f;
+                }
             }
             wave_base[r] = run;
             run += sum;
@@ -554,26 +565,42 @@ GP_FN void gf_layout_blocks(GPic *g, int tid, int nthr)
         wave_base[r] = off;
         uint32_t by = b0 / (uint32_t)q->hb, bx = b0 - by * (uint32_t)q->hb;
         const GP_G uint8_t *tp8 = gp_map_ent(g, i, (int)by, (int)bx) + 1;
-        for (uint32_t b = b0; b < b0 + 64u && b < q->nblocks; ++b) {
-            const uint32_t t = *tp8;
-            uint32_t n, it, pr, f;
-            gp_type_info(ctx, t, &n, &it, &pr, &f);
-            const uint32_t kind = ctx == 0 ? t : (t & 0xFu);
-            const int inter = ctx == 2 && (t & 0x60u);
-            uint32_t ent = GP_ENT(off, 0, GP_MODE_NONE);
-            if (n) ent = kind == 6 ? GP_ENT(off, 0, GP_MODE_LITERAL)
-                       : (inter ? GP_ENT(off, kind - 1, GP_MODE_PREDI) : GP_ENT(off, kind, GP_MODE_BASES));
-            uint32_t at = b;
-            if (g->is_pb) {                                   /* by_per, bx_per are 1 or 2: no divisions in this loop */
-                const uint32_t dy = by & (uint32_t)(q->by_per - 1), dx = bx & (uint32_t)(q->bx_per - 1);
-                const uint32_t mb = (by >> (q->by_per >> 1)) * (uint32_t)g->mw + (bx >> (q->bx_per >> 1));
-                at = mb * (uint32_t)q->nblk + (dx ? (dy ? 2u : 3u) : (dy ? 1u : 0u));
-                if (q->nblk == 1) at = mb;
+        const uint32_t bend = b0 + 64u < q->nblocks ? b0 + 64u : q->nblocks;
+        for (uint32_t b8 = b0; b8 < bend; b8 += 8) {
+            uint32_t tv[8];
+            const uint32_t m = bend - b8 < 8u ? bend - b8 : 8u;
+            {                                                 /* the next eight type bytes, requested together (gf_layout_sum) */
+                const GP_G uint8_t *p = tp8;
+                uint32_t x = bx;
+                GP_UNROLL
+                for (uint32_t j = 0; j < 8; ++j) {
+                    tv[j] = j < m ? *p : 0u;
+                    if (j < m) { p += 2; if (++x == (uint32_t)q->hb) { x = 0; p += 4; } }
+                }
             }
-            g->pinfo[q->blk_first + at] = ent;
-            off += n;
-            tp8 += 2;
-            if (++bx == (uint32_t)q->hb) { bx = 0; ++by; tp8 += 4; }
+            GP_UNROLL
+            for (uint32_t j = 0; j < 8; ++j) {
+                if (j >= m) break;
+                const uint32_t b = b8 + j, t = tv[j];
+                uint32_t n, it, pr, f;
+                gp_type_info(ctx, t, &n, &it, &pr, &f);
+                const uint32_t kind = ctx == 0 ? t : (t & 0xFu);
+                const int inter = ctx == 2 && (t & 0x60u);
+                uint32_t ent = GP_ENT(off, 0, GP_MODE_NONE);
+                if (n) ent = kind == 6 ? GP_ENT(off, 0, GP_MODE_LITERAL)
+                           : (inter ? GP_ENT(off, kind - 1, GP_MODE_PREDI) : GP_ENT(off, kind, GP_MODE_BASES));
+                uint32_t at = b;
+                if (g->is_pb) {                               /* by_per, bx_per are 1 or 2: no divisions in this loop */
+                    const uint32_t dy = by & (uint32_t)(q->by_per - 1), dx = bx & (uint32_t)(q->bx_per - 1);
+                    const uint32_t mb = (by >> (q->by_per >> 1)) * (uint32_t)g->mw + (bx >> (q->bx_per >> 1));
+                    at = mb * (uint32_t)q->nblk + (dx ? (dy ? 2u : 3u) : (dy ? 1u : 0u));
+                    if (q->nblk == 1) at = mb;
+                }
+                g->pinfo[q->blk_first + at] = ent;
+                off += n;
+                tp8 += 2;
+                if (++bx == (uint32_t)q->hb) { bx = 0; ++by; tp8 += 4; }
+            }
         }
     }
 }
