@@ -301,8 +301,17 @@ __device__ static inline void gfd_merge_one(const GPic *g, GP_G uint32_t *pool, 
         return;
     }
     const uint32_t nb = (ent >> 22) & 0xFFu;
+    /* everything the entry needs is requested before its first store: the two scalars of an MC-residual block, the first eight
+     * basis words and symbols (a load behind a store waits for the store's acknowledgement as well) */
+    int32_t s1 = 0, s2 = 0;
+    if (mode == GP_MODE_PREDI) { s1 = (int32_t)V[2u * my_pi]; s2 = (int32_t)V[2u * my_pi + 1u]; }
+    uint32_t wq[4] = { 0, 0, 0, 0 }, sq[2] = { 0, 0 };
+    if (nb) {
+        if (__builtin_expect(my_fx + 16u <= (uint64_t)g->nd * 4u, 1)) __builtin_memcpy(wq, (const GP_G uint8_t *)g->d + my_fx, 16);
+        else for (uint32_t j = 0; j < 4; ++j) wq[j] = __builtin_bswap32((gp_be16(g, my_fx + 4u * j) << 16) | gp_be16(g, my_fx + 4u * j + 2u));
+        __builtin_memcpy(sq, S + my_si, 8);
+    }
     if (mode == GP_MODE_PREDI) {
-        const int32_t s1 = (int32_t)V[2u * my_pi], s2 = (int32_t)V[2u * my_pi + 1u];
         dst[0] = (uint32_t)(s1 >> sh_dc) << sh_unk;
         dst[1] = (uint32_t)(s2 >> sh_dc);
         dst += 2;
@@ -311,12 +320,12 @@ __device__ static inline void gfd_merge_one(const GPic *g, GP_G uint32_t *pool, 
     /* eight bases a time from a 16-byte and an 8-byte load (words and symbols -- leaf bytes of the coefficient tree, value =
      * byte << 2 -- lie consecutive; both arrays and the picture are padded far enough to read a full block) */
     for (uint32_t k0 = 0; k0 < nb; k0 += 8) {
-        const uint64_t wo = my_fx + 2u * k0;
-        uint32_t wq[4];
-        if (__builtin_expect(wo + 16u <= (uint64_t)g->nd * 4u, 1)) __builtin_memcpy(wq, (const GP_G uint8_t *)g->d + wo, 16);
-        else for (uint32_t j = 0; j < 4; ++j) wq[j] = __builtin_bswap32((gp_be16(g, wo + 4u * j) << 16) | gp_be16(g, wo + 4u * j + 2u));
-        uint32_t sq[2];
-        __builtin_memcpy(sq, S + my_si + k0, 8);
+        if (k0) {
+            const uint64_t wo = my_fx + 2u * k0;
+            if (__builtin_expect(wo + 16u <= (uint64_t)g->nd * 4u, 1)) __builtin_memcpy(wq, (const GP_G uint8_t *)g->d + wo, 16);
+            else for (uint32_t j = 0; j < 4; ++j) wq[j] = __builtin_bswap32((gp_be16(g, wo + 4u * j) << 16) | gp_be16(g, wo + 4u * j + 2u));
+            __builtin_memcpy(sq, S + my_si + k0, 8);
+        }
 #pragma unroll
         for (uint32_t j = 0; j < 8; ++j) {
             if (k0 + j >= nb) break;
@@ -583,7 +592,9 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
                 b->slot = GF_SIDE_SLOT + (uint32_t)comp; b->base = ~0u;
                 const uint32_t f = GP_SKIP(4u) ? 0u : gp_mvs(&g, codes, comp, GF_SIDE_SLOT + 2u + (uint32_t)comp);
                 GP_ST(g.part[GP_MISC + 13 + comp], f);
+#ifndef GP_SUBSTAMPS
                 if (timing && lane == 0) timing[16 * pic + (comp ? 15 : 11)] = wall_clock64();
+#endif
             }
         }
         __syncthreads();
@@ -622,12 +633,18 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
             }
         }
         __syncthreads();
+#ifdef GP_SUBSTAMPS
+        if (is_pb) GP_STAMP(11);
+#endif
         /* round 2: values | kinds: blocks covered */
         gf_dc_values(&g, tid, GPW);
         gf_exp_lens(&g, 0, 2, tid, GPW);
         __syncthreads();
         if (!g.retry && !g.status && wave < 2) gfd_scan_add(&g, GF_I_LEN(wave), lane, 0);
         __syncthreads();
+#ifdef GP_SUBSTAMPS
+        if (is_pb) GP_STAMP(15);
+#endif
         if (!is_pb) {
             gf_exp_write(&g, 0, 2, tid, GPW);
             gf_exp_zeros(&g, 2, 5, tid, GPW);
