@@ -1273,6 +1273,10 @@ GP_FN __attribute__((always_inline)) uint32_t gp_mvs_comp(GPic *g, const GCode *
     /* residual bits per reference, in registers: a table read per vector is an LDS round trip on the chain's critical path */
     const int rb0 = (int)GP_UNI(g->res[2 * comp] & 15), rb1 = (int)GP_UNI(g->res[2 * comp + 1] & 15), rb2 = (int)GP_UNI(g->res[2 * comp + 2] & 15);
     const uint32_t mw = GP_UNI(g->mw), n = mw * GP_UNI(g->mh), nr = GP_UNI(g->ntrun);
+    /* row of a macroblock by one multiplication: exact for m < 65536 (m * (recip * mw - 2^32) < 2^32 as mw < 65536); the division the
+     * compiler builds is 14 scalar instructions per run of macroblocks, and a dense stream's runs are one or two macroblocks long */
+    const uint32_t recip = GP_UNI((uint32_t)((0x100000000ull + mw - 1u) / (mw ? mw : 1u)));
+    const int small = n <= 65536u && mw > 1u;                            /* mw = 1: the reciprocal does not fit 32 bits */
     GList runs;                                                          /* the type runs (gp_mbtypes) */
     gl_init(&runs, g->trun, nr, list_slot);
     uint32_t e = nr ? GP_UNI(gl_next(&runs)) : 0u;
@@ -1286,7 +1290,7 @@ GP_FN __attribute__((always_inline)) uint32_t gp_mvs_comp(GPic *g, const GCode *
         if (ref != cur_ref) { cur_ref = ref; acc = 0; }
         const int rbits = ref == 0 ? rb0 : (ref == 1 ? rb1 : rb2);        /* ref = 2 only from a first type value of 3 */
         const int32_t lim = (int32_t)(1u << (rbits + 5));
-        uint32_t my = m0 / mw, mx = m0 - my * mw;
+        uint32_t my = small ? (uint32_t)(((uint64_t)m0 * recip) >> 32) : m0 / mw, mx = m0 - my * mw;
         GP_G int16_t *out = mvs + 2 * m0 + (uint32_t)comp;
         for (uint32_t m = m0; m < m1;) {
             const uint32_t seg = m + (mw - mx) < m1 ? m + (mw - mx) : m1;  /* to the end of the macroblock row or of the run */
