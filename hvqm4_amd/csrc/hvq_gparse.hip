@@ -8,7 +8,7 @@
  * array, all sections at once -- the lanes of ONE wave are the sections -- and zero runs, overflow grouping, DC
  * prediction and coefficient sums become scans by all threads.
  *   all pictures : setup + section cursors (wave 0) | maps/MVs/tree tables cleared (all) | prefix trees read, one per wave |
- *                  first-level tables + the coefficient tree's 9-bit table filled (all)
+ *                  the chains' 8-bit tables and the lanes' 16-bit-entry tables (10 bits block kinds, 9 bits the others) filled (all)
  *   I picture    : { decode wave: kinds, coefficients, DC runs | decode wave: the three DC sections | staging wave } |
  *                  5 scan rounds (values, zero runs -> blocks) | DC prediction as a wavefront, one wave per plane | nest, pool
  *                  layout (tile sums, one wave scan, entries) | payload positions (scans) | merge (entries on consecutive lanes)
@@ -30,7 +30,7 @@
  *
  * LDS per workgroup: the picture state (cursors, lanes, geometry), 24 staging slots of 128 B (the chains' bitstream blocks and
  * work lists; the flat path's rings of 256 B per lane lie over them), six prefix trees (8-bit table whose entries hold the leaf
- * value + child table: 2 KB each), the 9-bit coefficient table (2 KB), the DC row buffers: 19.3 KB + 3 x (hb + 2), 8 workgroups
+ * value + child table: 2 KB each; the flat path's lane tables lie over four of the 8-bit tables), 2 KB behind them (10-bit block-kind table), the DC row buffers: 19.3 KB + 3 x (hb + 2), 8 workgroups
  * per CU.  At most 80 SGPRs (more costs a wave slot per SIMD on gfx950) and 64 VGPRs.
  */
 #include <hip/hip_runtime.h>
