@@ -572,7 +572,12 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
             else if (role == 2) gf_decode_wave(&g, codes, lane, GP_SKIP(1u) ? 0u : dc_lanes);
             else if (role == 1) gf_stage_wave(&g, lane, 2u);
         } else {
-            if (role == 0) { gf_decode_wave(&g, codes, lane, GP_SKIP(1u) ? 0u : ~0u); if (timing && lane == 0) timing[16 * pic + 5] = wall_clock64(); }
+            if (role == 0) {
+                gf_decode_wave(&g, codes, lane, GP_SKIP(1u) ? 0u : ~0u);
+#ifndef GP_SUBSTAMPS
+                if (timing && lane == 0) timing[16 * pic + 5] = wall_clock64();
+#endif
+            }
             else if (role == 1) gf_stage_wave(&g, lane, 1u);
             else {
                 /* the type runs, then the x components of the vectors (which need nothing but the type bytes); the proc runs,
@@ -580,7 +585,9 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
                 const int comp = role - 2;
                 if (comp == 0) {
                     if (!GP_SKIP(2u)) gp_mbtypes(&g, codes); else g.ntrun = 0;
+#ifndef GP_SUBSTAMPS
                     if (timing && lane == 0) timing[16 * pic + 2] = wall_clock64();
+#endif
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     GF_ST(gf_types_done, 1u);
                 } else {
@@ -664,10 +671,17 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
             if (!g.retry) gp_nest(&g, tid, GPW);
         } else {
             gf_exp_write(&g, 0, 2, tid, GPW);
+#ifdef GP_SUBSTAMPS
+            __syncthreads();
+            GP_STAMP(2);
+#endif
             gf_pbdc_sums(&g, tid, GPW);
             __syncthreads();
             if (!g.retry && !g.status && wave < 3) gfd_scan_seg(&g, GF_I_PBF(wave), GF_I_PBV(wave), lane);
             __syncthreads();
+#ifdef GP_SUBSTAMPS
+            GP_STAMP(5);
+#endif
             gf_pbdc_write(&g, tid, GPW);
             __syncthreads();
             GP_STAMP(3);
