@@ -322,7 +322,7 @@ GP_FN int32_t gsym_uovf(const GCode *c, GBits *b, int cap, uint32_t *fl)        
 
 /* ------------------------------------------------------------------ per-picture state (LDS on the device) */
 /* one lane of the flat symbol decode (hvq_gparse_flat.h): a prefix-coded section decoded front to back into an
- * int16 array, independently of every other section */
+ * array of leaf bytes (round 4; int16 values before), independently of every other section */
 #define GF_LANES 13
 #define GP_TOTS 32                 /* totals of the scan instances 16..47 (hvq_gparse_flat.h) */
 typedef struct {
@@ -384,7 +384,7 @@ typedef struct {
     /* flat path (hvq_gparse_flat.h) */
     uint32_t sec_pay[17];        /* payload start (byte) of every section, for the lanes' end heuristics */
     GLane lane[GF_LANES];
-    GP_G int16_t *sym;           /* the lanes' symbol arrays */
+    GP_G int16_t *sym;           /* the lanes' symbol arrays: leaf bytes, in regions laid out (offsets, capacities) in 2-byte units */
     GP_G uint32_t *val;          /* grouped DC-buffer values, per plane at val_off[] */
     uint32_t val_off[3], nv[3];
     uint32_t tot[GP_TOTS];       /* totals of the scans */
