@@ -1867,6 +1867,22 @@ void hvq_gather_kernel(const uint64_t *__restrict__ src, uint8_t *__restrict__ d
     for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) __builtin_nontemporal_store(s[i], d + i);
 }
 
+/* a table from pinned host memory into HBM, read over PCIe by the compute queue itself: stream-ordered without a DMA engine */
+extern "C" __global__ __launch_bounds__(256)
+void hvq_upload_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, u32 n16)
+{
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
+extern "C" hipError_t hvq_launch_upload(const void *src_pinned, void *dst_dev, size_t bytes, hipStream_t stream)
+{
+    const u32 n16 = (u32)((bytes + 15u) / 16u);
+    if (!n16) return hipSuccess;
+    const u32 wgs = (n16 + 255u) / 256u;
+    hipLaunchKernelGGL(hvq_upload_kernel, dim3(wgs < 256u ? wgs : 256u), dim3(256), 0, stream, (const uint4 *)src_pinned, (uint4 *)dst_dev, n16);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t hvq_launch_gather(const uint64_t *src_dev, uint8_t *dst_dev, uint32_t n, uint32_t pic_bytes, hipStream_t stream)
 {
     if (!n) return hipSuccess;

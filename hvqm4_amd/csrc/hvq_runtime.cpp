@@ -15,6 +15,7 @@
  * would produce pixels fails with HVQ_E_NOGPU.
  */
 #include <hip/hip_runtime.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <chrono>
@@ -54,6 +55,7 @@ extern "C" hipError_t hvq_launch_recon_inline(const HvqJob *jobs_dev, uint32_t n
                                               uint32_t items_cap, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream);
 extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t items_cap);
 extern "C" hipError_t hvq_launch_gather(const uint64_t *src_dev, uint8_t *dst_dev, uint32_t n, uint32_t pic_bytes, hipStream_t stream);
+extern "C" hipError_t hvq_launch_upload(const void *src_pinned, void *dst_dev, size_t bytes, hipStream_t stream);
 extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *side, uint8_t *dst, hipStream_t stream);
 extern "C" hipError_t hvq_upload_tables(void);
 
@@ -346,6 +348,24 @@ static double now_ms()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+/* A bitstream into the pinned arena with non-temporal stores: the arena is written once and read by the DMA engine, so fetching
+ * its lines into the cache first (what a plain store does) doubles the memory traffic of a copy whose 160 MB per batch have to
+ * fit into the 4.7 ms the GPU takes for the batch before (HVQM4_AMD_NT_COPY=0: memcpy). */
+static inline void copy_to_arena(uint8_t *dst, const uint8_t *src, size_t len)
+{
+    static const bool nt = !(getenv("HVQM4_AMD_NT_COPY") && atoi(getenv("HVQM4_AMD_NT_COPY")) == 0);
+    size_t i = 0;
+    if (nt && ((uintptr_t)dst & 15u) == 0 && len >= 4096) {
+        for (; i + 64 <= len; i += 64) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 16)),
+                          c = _mm_loadu_si128((const __m128i *)(src + i + 32)), d = _mm_loadu_si128((const __m128i *)(src + i + 48));
+            _mm_stream_si128((__m128i *)(dst + i), a); _mm_stream_si128((__m128i *)(dst + i + 16), b);
+            _mm_stream_si128((__m128i *)(dst + i + 32), c); _mm_stream_si128((__m128i *)(dst + i + 48), d);
+        }
+    }
+    memcpy(dst + i, src + i, len - i);
+}
+
 /* copy `bytes` into pinned staging buffer [id][which] and queue its upload to `dst` on the compute stream */
 static int staged_upload(HvqContext *c, int id, int which, void *dst, const void *src, size_t bytes)
 {
@@ -357,7 +377,17 @@ static int staged_upload(HvqContext *c, int id, int which, void *dst, const void
         b.cap = ncap;
     }
     memcpy(b.p, src, bytes);
-    HIPCHK(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyHostToDevice, c->stream));
+    /* Tables of a few hundred KB go up by a kernel of the compute queue that reads the pinned buffer over PCIe.  A copy command goes
+     * to a DMA engine, and the runtime deals engines to streams as it likes: the job table of batch k, queued at flush_end, ended up
+     * behind the 160 MB of batch k + 1's bitstreams on the copy stream's engine once in four or five batches and held the
+     * reconstruction -- and the parse queued behind it -- back by 1-2 ms (HVQM4_AMD_KERNEL_UPLOAD=0: copy commands).  Buffers are
+     * 16-byte multiples (pinned capacity is rounded to 4 KB, device tables are allocated with slack). */
+    static const bool by_kernel = !(getenv("HVQM4_AMD_KERNEL_UPLOAD") && atoi(getenv("HVQM4_AMD_KERNEL_UPLOAD")) == 0);
+    if (by_kernel && bytes <= ((size_t)8 << 20) && ((uintptr_t)dst & 15u) == 0) {
+        const size_t pad = align_up(bytes, 16);
+        if (pad > bytes) memset(b.p + bytes, 0, pad - bytes);
+        HIPCHK(hvq_launch_upload(b.p, dst, bytes, c->stream));
+    } else HIPCHK(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyHostToDevice, c->stream));
     return HVQ_OK;
 }
 
@@ -830,8 +860,9 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
                 if (i >= n) return any;
                 uint8_t *dst = j.host + j.offs[(size_t)i];
                 const size_t span = align_up(j.lens[(size_t)i] + 32, 256);
-                memcpy(dst, j.pics[(size_t)i], j.lens[(size_t)i]);
+                copy_to_arena(dst, j.pics[(size_t)i], j.lens[(size_t)i]);
                 memset(dst + j.lens[(size_t)i], 0, span - j.lens[(size_t)i]);
+                _mm_sfence();                            /* the streamed lines are in memory before the chunk's upload is queued */
                 left[(size_t)chunk_of[(size_t)i]].fetch_sub(1, std::memory_order_release);
                 any = true;
             }
@@ -970,7 +1001,16 @@ static int device_parse_finish(HvqContext *c)
 {
     const std::vector<size_t> &idx = c->fl_idx;
     if (idx.empty()) return HVQ_OK;
-    HIPCHK(hipEventSynchronize(c->ev_parse));
+    {   /* The reconstruction launches wait for this thread to have seen the parse results: the GPU idles for as long as the wake-up
+         * takes.  Polling the event costs this thread a core for the length of the parse kernel and takes the results some tens of
+         * microseconds earlier than the driver's wait (HVQM4_AMD_SPIN_WAIT=0: the driver's wait). */
+        static const bool spin = !(getenv("HVQM4_AMD_SPIN_WAIT") && atoi(getenv("HVQM4_AMD_SPIN_WAIT")) == 0);
+        if (spin) {
+            hipError_t q;
+            while ((q = hipEventQuery(c->ev_parse)) == hipErrorNotReady) { for (int k = 0; k < 32; ++k) __builtin_ia32_pause(); }
+            HIPCHK(q);
+        } else HIPCHK(hipEventSynchronize(c->ev_parse));
+    }
     const HvqParseResult *res = c->pr_host;
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
