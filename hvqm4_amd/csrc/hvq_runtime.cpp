@@ -1371,8 +1371,7 @@ static int flush_end(HvqContext *c)
     c->selfrefs.clear();
     HvqStats st{};
     for (size_t k = 0; k < slots.size(); ++k) {
-        HvqJob &j = jobs[k];
-        memset(&j, 0, sizeof j);
+        HvqJob &j = jobs[k];                                        /* zeroed by the assign above */
         if (slots[k].job == 0xFFFFFFFFu) continue;                  /* padding slot: total_tiles = 0, its workgroups exit at once */
         const size_t i = slots[k].job;
         slot_of[i] = (uint32_t)k;
@@ -1463,21 +1462,26 @@ static int flush_end(HvqContext *c)
     }
     /* LDS sizes of the launches (their tile ranges were dealt at begin): accumulators are 16 dwords per queued block,
      * rows padded to 32 entries (LDS banks); pairs above the cap take the kernel's serial fallback */
-    for (auto &L : c->fl_launches) {
-        uint32_t mi = 0, mp = 0;
-        uint64_t payload = 0, ntl = 0;
-        for (size_t i = 0; i < c->fl_pending.size(); ++i) {
-            const Pending &p = c->fl_pending[i];
-            if (p.dropped || p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
-            mi = std::max(mi, p.max_items); mp = std::max(mp, p.max_pairs);
-            payload += jobs[slot_of[i]].pool_dwords; ntl += p.ntiles;
+    /* fullest tile per launch: one pass over the pictures (this runs between the parse results and the first launch: the GPU waits) */
+    std::vector<uint32_t> lmi(c->fl_launches.size(), 0), lmp(c->fl_launches.size(), 0);
+    for (size_t i = 0; i < c->fl_pending.size(); ++i) {
+        const Pending &p = c->fl_pending[i];
+        if (p.dropped) continue;
+        for (size_t l = 0; l < c->fl_launches.size(); ++l) {
+            const Launch &L = c->fl_launches[l];
+            if (p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
+            lmi[l] = std::max(lmi[l], p.max_items); lmp[l] = std::max(lmp[l], p.max_pairs);
+            break;
         }
+    }
+    for (size_t li = 0; li < c->fl_launches.size(); ++li) {
+        Launch &L = c->fl_launches[li];
+        const uint32_t mi = lmi[li], mp = lmp[li];
         /* Two tiles per workgroup: twice the loads in flight per wave for the same chain of round trips -- what a latency-bound
          * kernel is short of (profiles/r03_ablation.txt).  Since the tile queues left the kernel's LDS (11.6 KB per tile) the pooled
          * accumulators of two tiles cost the AOT-dense stream no occupancy either (dense +3.7 %, flat +5 %); one tile only when the
          * two tiles' items would need more than 192 accumulator rows (LDS: fewer than 7 workgroups per CU). */
         static const int force_tpw = getenv("HVQM4_AMD_TILES_PER_WG") ? atoi(getenv("HVQM4_AMD_TILES_PER_WG")) : 0;
-        (void)payload; (void)ntl;
         L.inline_queues = !c->tile_queues;
         if (!L.inline_queues) {
             L.tpw = force_tpw ? (force_tpw >= 2 ? 2u : 1u) : (2u * mi <= 192u ? 2u : 1u);
