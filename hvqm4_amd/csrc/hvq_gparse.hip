@@ -498,14 +498,30 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         /* uniform: chains are selected per wave */
-    /* which wave decodes: rotated over the pictures so that the decoders of a CU's 8 workgroups spread over its 4 SIMDs.
-     * Workgroup b runs on XCD b % 8; whether an XCD deals its workgroups b / 8 to its 32 CUs one each in turn or eight at a
-     * time, the sum below takes all four values among the workgroups that share a CU. */
-    const int role = (wave + (int)(((blockIdx.x >> 3) + (blockIdx.x >> 8)) & 3u)) & 3;
+    /* Which wave decodes, stages, runs which chain: by the SIMD the wave sits on (HW_ID bits 5:4) and the order in which the CU's
+     * workgroups were dealt (blockIdx / 256: one workgroup per CU in turn).  Rounds 1-3 rotated the roles by the wave's index and took
+     * that for a spread over the SIMDs; the hardware starts every workgroup's waves on another SIMD, which cancelled the rotation: all
+     * eight decode waves of a CU sat on one SIMD, the eight (sleeping) staging waves on a second, the type/x chains on the third, the
+     * proc/y chains on the fourth (-DGP_HWID dump, round 4).  Spread evenly (GP_ROLEMAP 1: two decode, two staging, four chain waves
+     * per SIMD) the chain phase ends at 2.17 instead of 2.76 ms -- and the kernel is no faster, 3.6-3.75 ms: the pictures then reach
+     * their all-thread passes together, and those passes, thread-per-chunk walks whose 64 lanes touch 64 cache lines per instruction,
+     * are bound by the CU's one vector-memory pipeline whatever the issue priorities.  Map 3 (default): SIMD 0 four
+     * decode + four staging waves, 1 staging + x chains, 2 x + y chains, 3 y chains + decode: 3.41-3.42 ms against 3.44-3.47 of the
+     * old arrangement on one box.  The wave claims its role in LDS, the next free one if another wave of the workgroup has it
+     * (waves sharing a SIMD): always a bijection. */
+    __shared__ uint32_t s_roles;
+#ifndef GP_ROLEMAP
+#define GP_ROLEMAP 3
+#endif
+    const uint32_t simd_id = (uint32_t)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)), dealt = (blockIdx.x >> 8) & 7u;   /* HW_REG_HW_ID, offset 4, 2 bits */
+    const int want = GP_ROLEMAP == 0 ? (int)((wave + (int)(((blockIdx.x >> 3) + (blockIdx.x >> 8)) & 3u)) & 3)
+                   : (int)((simd_id + (GP_ROLEMAP == 1 ? dealt : (GP_ROLEMAP == 2 ? 2u * (dealt & 1u) : (GP_ROLEMAP == 3 ? (dealt & 1u) : (GP_ROLEMAP == 4 ? (dealt >> 1) : 0u))))) & 3u);
+    int role = want;
     const HvqParseJob *job = jobs + pic;
     constexpr bool flat = FLAT;
 
     GP_STAMP(0);
+    if (tid == 0) s_roles = 0;
     /* Issue priorities follow the pictures' critical path, not the waves' age: trees, then the type and proc runs -- short chains that
      * everything else of a picture waits for -- go first.  Left to the oldest-first arbiter, the youngest workgroup of a CU had its
      * 0.27 ms of type runs done after 2.3 ms (the seven older workgroups' vector chains and decode waves took the slots); with them in
@@ -524,6 +540,21 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
         for (int k = tid - 64; k < (int)(GC_COUNT * sizeof(GCode) / 4); k += GPW - 64) w[k] = 0;
     }
     __syncthreads();
+    {   /* claim the role (see above); lane 0 of every wave, the roles are first used behind two more barriers */
+        uint32_t r = (uint32_t)want;
+        if (lane == 0) {
+            for (int k = 0; k < 4; ++k, r = (r + 1u) & 3u)
+                if (!(__hip_atomic_fetch_or(&s_roles, 1u << r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & (1u << r))) break;
+        }
+        role = __builtin_amdgcn_readfirstlane((int)r);
+    }
+#ifdef GP_HWID
+    /* development: which SIMD each role runs on (HW_ID bits 5:4), 8 bits per role, into the slot of stamp 8 */
+    if (timing && lane == 0) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       /* HW_REG_HW_ID, all 32 bits */
+        atomicAdd((unsigned long long *)&timing[16 * pic + 8], (unsigned long long)(0x80u | ((hw >> 4) & 3u) | (((hw >> 8) & 15u) << 2)) << (8 * role));
+    }
+#endif
     gp_init_maps(&g, tid, GPW);
     const int is_pb = g.is_pb;
     const int ntrees = is_pb ? 6 : 4;
@@ -701,7 +732,9 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
             GP_STAMP(4);
             if (wave == 0) gfd_layout_finish(&g, lane);
             __syncthreads();
+#ifndef GP_HWID
             GP_STAMP(8);
+#endif
             gf_layout_blocks(&g, tid, GPW);
             __syncthreads();
             GP_STAMP(9);
