@@ -391,6 +391,86 @@ __device__ static void gfd_emit_merge(GPic *g, int tid)
     }
 }
 
+/* gp_tags_count .. gp_lists_write of a P/B picture with consecutive macroblocks on consecutive lanes (a wave owns a quarter of the
+ * picture's macroblocks): tag of every macroblock into the type byte of all its blocks, the lists of coded and of intra
+ * macroblocks.  Ranks come from ballots, so the three passes are loads of neighbouring bytes and stores to neighbouring
+ * entries; the thread-per-chunk form made every lane of a load touch a cache line of its own. */
+__shared__ uint32_t gfd_tl[12];
+
+__device__ static inline uint32_t gfd_below(uint64_t mask)      /* set bits of `mask` below this lane */
+{
+    return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ static void gfd_tags_lists(GPic *g, int tid)
+{
+    if (g->status) return;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    const uint32_t mw = GP_UNI(g->mw), n = mw * GP_UNI(g->mh), per = ((n + GPW - 1) / GPW) * 64u;
+    const uint32_t m0 = per * (uint32_t)wave < n ? per * (uint32_t)wave : n, m1 = m0 + per < n ? m0 + per : n;
+    const GP_G uint8_t *mbtype = GFD_UNIP(const GP_G uint8_t *, g->mbtype), *procseq = GFD_UNIP(const GP_G uint8_t *, g->procseq);
+    {   /* inter macroblocks of the waves before this one */
+        uint32_t cnt = 0;
+        for (uint32_t mb = m0; mb < m1; mb += 64) {
+            const uint32_t m = mb + (uint32_t)lane;
+            cnt += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(m < m1 && mbtype[m] != 0));
+        }
+        if (lane == 0) gfd_tl[wave] = cnt;
+    }
+    __syncthreads();
+    uint32_t rank0 = 0;
+    for (int w = 0; w < wave; ++w) rank0 += gfd_tl[w];
+    {   /* coded and intra macroblocks of the waves before this one */
+        uint32_t running = rank0, ncod = 0, nt0 = 0;
+        for (uint32_t mb = m0; mb < m1; mb += 64) {
+            const uint32_t m = mb + (uint32_t)lane;
+            const bool live = m < m1;
+            const uint32_t type = live ? mbtype[m] : 0u;
+            const uint64_t bi = __builtin_amdgcn_ballot_w64(type != 0);
+            const uint32_t proc = type ? procseq[running + gfd_below(bi)] : 0u;
+            running += (uint32_t)__builtin_popcountll(bi);
+            ncod += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && !proc));
+            nt0 += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live && !type));
+        }
+        if (lane == 0) { gfd_tl[4 + wave] = ncod; gfd_tl[8 + wave] = nt0; }
+    }
+    __syncthreads();
+    uint32_t a = 0, b = 0;
+    for (int w = 0; w < wave; ++w) { a += gfd_tl[4 + w]; b += gfd_tl[8 + w]; }
+    if (tid == 0) { g->ncoded = gfd_tl[4] + gfd_tl[5] + gfd_tl[6] + gfd_tl[7]; g->ntype0 = gfd_tl[8] + gfd_tl[9] + gfd_tl[10] + gfd_tl[11]; }
+    GP_G uint8_t *mbtag = GFD_UNIP(GP_G uint8_t *, g->mbtag);
+    GP_G uint32_t *cmb = GFD_UNIP(GP_G uint32_t *, g->cmb), *t0 = GFD_UNIP(GP_G uint32_t *, g->t0);
+    const bool is_P = g->is_P != 0;
+    uint32_t running = rank0, fl = 0;
+    for (uint32_t mb = m0; mb < m1; mb += 64) {
+        const uint32_t m = mb + (uint32_t)lane;
+        const bool live = m < m1;
+        const uint32_t type = live ? mbtype[m] : 0u;
+        const uint64_t bi = __builtin_amdgcn_ballot_w64(type != 0);
+        const uint32_t proc = type ? procseq[running + gfd_below(bi)] : 0u;
+        running += (uint32_t)__builtin_popcountll(bi);
+        const uint32_t tag = type ? (type << 5) | (proc << 4) : 0u;
+        const uint64_t bc = __builtin_amdgcn_ballot_w64(live && !proc), bt = __builtin_amdgcn_ballot_w64(live && !type);
+        if (live) {
+            mbtag[m] = (uint8_t)tag;
+            if (!proc) cmb[a + gfd_below(bc)] = m;
+            if (!type) t0[b + gfd_below(bt)] = m;
+            if (type) {
+                if (is_P && type >= 2) fl |= HVQ_F_SELF_REF;
+                const int my = (int)(m / mw), mx = (int)(m - (uint32_t)my * mw);
+                for (int i = 0; i < 3; ++i) {
+                    const GPlane *q = &g->pl[i];
+                    for (int dy = 0; dy < q->by_per; ++dy)
+                        for (int dx = 0; dx < q->bx_per; ++dx)
+                            gp_map_ent(g, i, my * q->by_per + dy, mx * q->bx_per + dx)[1] = (uint8_t)tag;
+                }
+            }
+        }
+        a += (uint32_t)__builtin_popcountll(bc); b += (uint32_t)__builtin_popcountll(bt);
+    }
+    g->part[GP_PART2 + tid] = fl;
+}
+
 /* one wave: scan of the threads' tile totals, maxima and flags of the layout, then sizes and header (gf_layout_finish) */
 __device__ static void gfd_layout_finish(GPic *g, int lane)
 {
@@ -649,18 +729,7 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
         if (is_pb) {
             gp_runs_expand(&g, tid, GPW);
             __syncthreads();
-            gp_tags_count(&g, tid, GPW);
-            __syncthreads();
-            /* gp_tags_scan / gp_lists_scan as wave scans: one thread walking 256 words of HBM, each store in the way of the next
-             * load, took longer than the passes on either side of it */
-            if (wave == 0 && !g.status) gfd_scan_add(&g, 0, lane, 0);
-            __syncthreads();
-            gp_tags_assign(&g, tid, GPW);
-            __syncthreads();
-            if (wave == 0 && !g.status) gfd_scan_add(&g, GP_EP(0, 0, 0) / 256, lane, &g.ncoded);
-            else if (wave == 1 && !g.status) gfd_scan_add(&g, GP_EP(0, 1, 0) / 256, lane, &g.ntype0);
-            __syncthreads();
-            gp_lists_write(&g, tid, GPW);
+            gfd_tags_lists(&g, tid);                            /* gp_tags_count .. gp_lists_write, lane-consecutive */
             __syncthreads();
             GP_STAMP(12);
         }
