@@ -391,6 +391,41 @@ __device__ static void gfd_emit_merge(GPic *g, int tid)
     }
 }
 
+/* gf_emit_count + its nine scans for gfd_emit_merge: what lies in front of every WAVE's entries (fixed-length bytes, coefficient
+ * symbols, MC-residual blocks per plane) and the totals gf_emit_short asks for; consecutive entries on consecutive lanes */
+__shared__ uint32_t gfd_ec[9][4];
+
+__device__ static inline uint32_t gfd_wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)gfd_dpp_incl(v), 63); }
+
+__device__ static void gfd_emit_count(GPic *g, int tid)
+{
+    if (g->status || g->retry) return;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    for (int i = 0; i < 3; ++i) {
+        const GP_G uint32_t *ents = GFD_UNIP(const GP_G uint32_t *, g->pinfo + g->pl[i].blk_first);
+        const uint32_t n = GP_UNI(g->pl[i].nblocks), per = (n + GPW - 1) / GPW;
+        const uint32_t e0 = per * 64u * (uint32_t)wave < n ? per * 64u * (uint32_t)wave : n;
+        const uint32_t e1 = per * 64u * (uint32_t)(wave + 1) < n ? per * 64u * (uint32_t)(wave + 1) : n;
+        uint32_t bytes = 0, nb = 0, np = 0;
+        for (uint32_t e = e0 + (uint32_t)lane; e < e1; e += 64) {
+            const uint32_t ent = ents[e], mode = ent >> 30;
+            bytes += gp_ent_fx_bytes(ent);
+            if (mode >= GP_MODE_BASES) nb += (ent >> 22) & 0xFFu;
+            np += mode == GP_MODE_PREDI;
+        }
+        const uint32_t sb = gfd_wave_sum(bytes), sn = gfd_wave_sum(nb), sp = gfd_wave_sum(np);
+        if (lane == 0) { gfd_ec[3 * i][wave] = sb; gfd_ec[3 * i + 1][wave] = sn; gfd_ec[3 * i + 2][wave] = sp; }
+    }
+    __syncthreads();
+    if (tid < 9) {                                      /* instance tid: exclusive prefix over the waves, total */
+        const int i = tid / 3, what = tid - 3 * i;
+        const int inst = what == 0 ? GF_I_FX(i) : (what == 1 ? GF_I_NB(i) : GF_I_PREDI(i));
+        uint32_t run = 0;
+        for (int w = 0; w < 4; ++w) { g->part[GF_P(inst, 64 * w)] = run; run += gfd_ec[tid][w]; }
+        if (inst >= 16) g->tot[inst - 16] = run;
+    }
+}
+
 /* gp_tags_count .. gp_lists_write of a P/B picture with consecutive macroblocks on consecutive lanes (a wave owns a quarter of the
  * picture's macroblocks): tag of every macroblock into the type byte of all its blocks, the lists of coded and of intra
  * macroblocks.  Ranks come from ballots, so the three passes are loads of neighbouring bytes and stores to neighbouring
@@ -470,6 +505,91 @@ __device__ static void gfd_tags_lists(GPic *g, int tid)
     }
     g->part[GP_PART2 + tid] = fl;
 }
+
+#ifdef GP_LAYOUT_COOP
+/* Not the default: measured 0.05 ms SLOWER than the thread-per-run passes with their batched loads (3.44 against 3.39 ms, r04ri / r04rj) --
+ * a run is one load either way since the loads are requested eight at a time, and this form pays two wave reductions and a division per run. */
+/* gf_layout_sum / gf_layout_blocks with the 64 blocks of a run on the 64 lanes (a wave owns a quarter of the picture's tiles): one
+ * load of neighbouring type bytes per run instead of 64 per thread, sums and offsets by DPP scans.  The sums go to the slots of the
+ * waves' first threads (zeros elsewhere), so that gfd_layout_finish scans and reduces them as before. */
+__device__ static inline void gfd_run_types(const GPic *g, uint32_t r, int lane, uint32_t *t, uint32_t *by, uint32_t *bx, int *plane, bool *live)
+{
+    const int i = gp_run_plane(g, r);
+    const GPlane *q = &g->pl[i];
+    const uint32_t b = (r - q->run_first) * 64u + (uint32_t)lane;
+    *plane = i;
+    *live = b < q->nblocks;
+    const uint32_t y = b / (uint32_t)q->hb;
+    *by = y; *bx = b - y * (uint32_t)q->hb;
+    *t = *live ? gp_map_ent(g, i, (int)y, (int)*bx)[1] : 0u;
+}
+
+__device__ static void gfd_layout_sum(GPic *g, int tid)
+{
+    if (g->status || g->retry) return;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    GP_G uint32_t *wave_base = GFD_UNIP(GP_G uint32_t *, g->blob + g->wave_base_off);
+    const uint32_t tiles = GP_UNI(g->total_tiles), t0 = tiles * (uint32_t)wave / 4u, t1 = tiles * (uint32_t)(wave + 1) / 4u;
+    uint32_t run = 0, mi = 0, mp = 0, fl = 0;
+    for (uint32_t t = t0; t < t1; ++t) {
+        uint32_t ti = 0, tp = 0;
+        for (uint32_t k = 0; k < HVQ_TILE_BLOCKS / 64; ++k) {
+            const uint32_t r = t * (HVQ_TILE_BLOCKS / 64) + k;
+            uint32_t ty, by, bx; int i; bool live;
+            gfd_run_types(g, r, lane, &ty, &by, &bx, &i, &live);
+            uint32_t n = 0, it = 0, pr = 0, f = 0;
+            if (live) gp_type_info(g->is_pb ? 2 : (i == 0 ? 0 : 1), ty, &n, &it, &pr, &f);
+            fl |= f;
+            /* 64 x (<= 255 dwords, 1 item) fit 16 + 7 bits (an I picture's luma kind is the whole byte, h4m:1093); <= 255 pairs */
+            const uint32_t s = gfd_wave_sum(n | (it << 16)), sp = gfd_wave_sum(pr);
+            if (lane == 0) wave_base[r] = run;
+            run += s & 0xFFFFu; ti += s >> 16; tp += sp;
+        }
+        mi = ti > mi ? ti : mi; mp = tp > mp ? tp : mp;
+    }
+    g->part[tid] = fl;
+    g->part[GF_P(GF_I_LS, tid)] = lane ? 0u : run;
+    g->part[GF_P(GF_I_MI, tid)] = lane ? 0u : mi;
+    g->part[GF_P(GF_I_MP, tid)] = lane ? 0u : mp;
+}
+
+__device__ static void gfd_layout_blocks(GPic *g, int tid)
+{
+    if (g->status || g->retry) return;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    GP_G uint32_t *wave_base = GFD_UNIP(GP_G uint32_t *, g->blob + g->wave_base_off);
+    GP_G uint32_t *pinfo = GFD_UNIP(GP_G uint32_t *, g->pinfo);
+    const uint32_t tiles = GP_UNI(g->total_tiles), t0 = tiles * (uint32_t)wave / 4u, t1 = tiles * (uint32_t)(wave + 1) / 4u;
+    const uint32_t base = GP_UNI(g->part[GF_P(GF_I_LS, 64 * wave)]);          /* pool dwords of the waves before this one */
+    const uint32_t mw = GP_UNI(g->mw);
+    const bool is_pb = g->is_pb != 0;
+    for (uint32_t r = t0 * (HVQ_TILE_BLOCKS / 64); r < t1 * (HVQ_TILE_BLOCKS / 64); ++r) {
+        uint32_t t, by, bx; int i; bool live;
+        gfd_run_types(g, r, lane, &t, &by, &bx, &i, &live);
+        const GPlane *q = &g->pl[i];
+        const int ctx = is_pb ? 2 : (i == 0 ? 0 : 1);
+        uint32_t n = 0, it, pr, f;
+        if (live) gp_type_info(ctx, t, &n, &it, &pr, &f);
+        const uint32_t run_off = GP_UNI(wave_base[r]) + base;
+        const uint32_t off = run_off + gfd_dpp_incl(n) - n;
+        if (lane == 0) wave_base[r] = run_off;
+        if (!live) continue;
+        const uint32_t kind = ctx == 0 ? t : (t & 0xFu);
+        const int inter = ctx == 2 && (t & 0x60u);
+        uint32_t ent = GP_ENT(off, 0, GP_MODE_NONE);
+        if (n) ent = kind == 6 ? GP_ENT(off, 0, GP_MODE_LITERAL)
+                   : (inter ? GP_ENT(off, kind - 1, GP_MODE_PREDI) : GP_ENT(off, kind, GP_MODE_BASES));
+        uint32_t at = (r - q->run_first) * 64u + (uint32_t)lane;
+        if (is_pb) {                                          /* by_per, bx_per are 1 or 2 */
+            const uint32_t dy = by & (uint32_t)(q->by_per - 1), dx = bx & (uint32_t)(q->bx_per - 1);
+            const uint32_t mb = (by >> (q->by_per >> 1)) * mw + (bx >> (q->bx_per >> 1));
+            at = mb * (uint32_t)q->nblk + (dx ? (dy ? 2u : 3u) : (dy ? 1u : 0u));
+            if (q->nblk == 1) at = mb;
+        }
+        pinfo[q->blk_first + at] = ent;
+    }
+}
+#endif
 
 /* one wave: scan of the threads' tile totals, maxima and flags of the layout, then sizes and header (gf_layout_finish) */
 __device__ static void gfd_layout_finish(GPic *g, int lane)
@@ -796,7 +916,11 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
             GP_STAMP(3);
         }
         if (!g.retry) {
+#ifdef GP_LAYOUT_COOP
+            gfd_layout_sum(&g, tid);
+#else
             gf_layout_sum(&g, tid, GPW);
+#endif
             __syncthreads();
             GP_STAMP(4);
             if (wave == 0) gfd_layout_finish(&g, lane);
@@ -804,18 +928,15 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
 #ifndef GP_HWID
             GP_STAMP(8);
 #endif
+#ifdef GP_LAYOUT_COOP
+            gfd_layout_blocks(&g, tid);
+#else
             gf_layout_blocks(&g, tid, GPW);
+#endif
             __syncthreads();
             GP_STAMP(9);
-            gf_emit_count(&g, tid, GPW);
-            __syncthreads();
+            gfd_emit_count(&g, tid);                             /* gf_emit_count and its scans, per wave */
             GP_STAMP(10);
-            if (!g.status) {
-                for (int k = wave; k < 9; k += 4) {
-                    const int i = k / 3, what = k - 3 * i;
-                    gfd_scan_add(&g, what == 0 ? GF_I_FX(i) : (what == 1 ? GF_I_NB(i) : GF_I_PREDI(i)), lane, 0);
-                }
-            }
             __syncthreads();
             GP_STAMP(6);
             gfd_emit_merge(&g, tid);
