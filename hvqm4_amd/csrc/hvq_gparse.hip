@@ -705,13 +705,13 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
      * proc/y chains on the fourth (-DGP_HWID dump, round 4).  Spread evenly (GP_ROLEMAP 1: two decode, two staging, four chain waves
      * per SIMD) the chain phase ends at 2.17 instead of 2.76 ms -- and the kernel is no faster, 3.6-3.75 ms: the pictures then reach
      * their all-thread passes together, and those passes, thread-per-chunk walks whose 64 lanes touch 64 cache lines per instruction,
-     * are bound by the CU's one vector-memory pipeline whatever the issue priorities.  Map 3 (default): SIMD 0 four
-     * decode + four staging waves, 1 staging + x chains, 2 x + y chains, 3 y chains + decode: 3.41-3.42 ms against 3.44-3.47 of the
-     * old arrangement on one box.  The wave claims its role in LDS, the next free one if another wave of the workgroup has it
-     * (waves sharing a SIMD): always a bijection. */
+     * are bound by the CU's one vector-memory pipeline whatever the issue priorities.  Once the tag / list pass had
+     * consecutive macroblocks on consecutive lanes the even spread won: 3.20-3.23 ms against 3.36-3.39 (map 3: SIMD 0 decode +
+     * staging, 1 staging + x, 2 x + y, 3 y + decode) and 3.46 (the old arrangement), r04rk.  The wave claims its role in LDS, the
+     * next free one if another wave of the workgroup has it (waves sharing a SIMD): always a bijection. */
     __shared__ uint32_t s_roles;
 #ifndef GP_ROLEMAP
-#define GP_ROLEMAP 3
+#define GP_ROLEMAP 1
 #endif
     const uint32_t simd_id = (uint32_t)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)), dealt = (blockIdx.x >> 8) & 7u;   /* HW_REG_HW_ID, offset 4, 2 bits */
     const int want = GP_ROLEMAP == 0 ? (int)((wave + (int)(((blockIdx.x >> 3) + (blockIdx.x >> 8)) & 3u)) & 3)
