@@ -280,6 +280,15 @@ __device__ static inline uint32_t gfd_dpp_incl(uint32_t v)
     return v;
 }
 
+__device__ static inline uint32_t gfd_wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)gfd_dpp_incl(v), 63); }
+
+__device__ static inline uint32_t gfd_below(uint64_t mask)      /* set bits of `mask` below this lane */
+{
+    return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__shared__ uint32_t gfd_sh[40];                 /* per-wave partials of the wave-cooperative passes (one pass at a time) */
+
 /* gf_emit_merge on the device.  A wave owns the entries of its 64 threads' chunks (whose starting offsets gf_emit_count + the
  * scans have already produced), walks them 64 at a time and gets every entry's position in the coefficient symbols, in the
  * fixed-length section and among the MC-residual blocks from three wave scans.  Most entries carry nothing (a dense 640x480
@@ -391,11 +400,100 @@ __device__ static void gfd_emit_merge(GPic *g, int tid)
     }
 }
 
+/* gf_exp_zeros / gf_exp_lens / gf_exp_write with consecutive tokens on consecutive lanes (a wave owns a quarter of an expansion's
+ * tokens): the rank of a zero token among the zeros comes from a ballot, its run length from the neighbour of the previous
+ * zero's, the block a token lands on from one DPP scan of the lengths, and what the 64 lanes then read (macroblock, tag) and
+ * write (map bytes) lies side by side.  The thread-per-chunk passes they replace made every lane of a load or store touch a
+ * cache line of its own, and the 256-entry scans between them are 4-entry sums here.  gfd_ex(x, which, wave): zeros / blocks
+ * covered of expansion x in the wave's tokens. */
+#define gfd_ex(x, which, w) gfd_sh[8 * (x) + 4 * (which) + (w)]
+
+__device__ static inline uint32_t gfd_exp_token(const GExp *e, uint32_t j) { return e->t8 ? (uint32_t)e->t8[j] : e->t32[j]; }
+
+__device__ static inline void gfd_exp_range(const GExp *e, int wave, uint32_t *lo, uint32_t *hi)
+{
+    const uint32_t per = ((e->ntok + GPW - 1) / GPW) * 64u;
+    *lo = per * (uint32_t)wave < e->ntok ? per * (uint32_t)wave : e->ntok;
+    *hi = *lo + per < e->ntok ? *lo + per : e->ntok;
+}
+
+__device__ static void gfd_exp_zeros(GPic *g, int x0, int x1, int tid)
+{
+    if (g->status || g->retry) return;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    for (int x = x0; x < x1; ++x) {
+        GExp e;
+        uint32_t lo, hi, z = 0;
+        if (!gf_exp(g, x, &e)) continue;
+        gfd_exp_range(&e, wave, &lo, &hi);
+        for (uint32_t jb = lo; jb < hi; jb += 64) {
+            const uint32_t j = jb + (uint32_t)lane;
+            z += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(j < hi && gfd_exp_token(&e, j) == 0));
+        }
+        if (lane == 0) gfd_ex(x, 0, wave) = z;
+    }
+}
+
+/* the tokens jb .. jb + 63 of the wave: token, whether it takes part, its length (1 + the run behind a zero token) */
+__device__ static inline uint32_t gfd_exp_step(const GExp *e, uint32_t jb, uint32_t hi, int lane, uint32_t *z, uint32_t *tok, bool *live, bool *short_runs)
+{
+    const uint32_t j = jb + (uint32_t)lane;
+    *live = j < hi;
+    *tok = *live ? gfd_exp_token(e, j) : 1u;
+    const bool zero = *live && *tok == 0;
+    const uint64_t bz = __builtin_amdgcn_ballot_w64(zero);
+    const uint32_t zr = *z + gfd_below(bz);
+    *z += (uint32_t)__builtin_popcountll(bz);
+    *short_runs = zero && zr >= e->nrun;                 /* a zero token without a run length */
+    return *live ? 1u + (zero && zr < e->nrun ? (uint32_t)e->run[zr] : 0u) : 0u;
+}
+
+__device__ static void gfd_exp_lens(GPic *g, int x0, int x1, int tid)
+{
+    if (g->status || g->retry) return;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    for (int x = x0; x < x1; ++x) {
+        GExp e;
+        uint32_t lo, hi, z = 0, len = 0;
+        if (!gf_exp(g, x, &e)) continue;
+        gfd_exp_range(&e, wave, &lo, &hi);
+        for (int w = 0; w < wave; ++w) z += gfd_ex(x, 0, w);
+        for (uint32_t jb = lo; jb < hi; jb += 64) {
+            uint32_t tok; bool live, bad;
+            len += gfd_wave_sum(gfd_exp_step(&e, jb, hi, lane, &z, &tok, &live, &bad));
+        }
+        if (lane == 0) gfd_ex(x, 1, wave) = len;
+    }
+}
+
+__device__ static void gfd_exp_write(GPic *g, int x0, int x1, int tid)
+{
+    if (g->status || g->retry) return;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    for (int x = x0; x < x1; ++x) {
+        GExp e;
+        uint32_t lo, hi, z = 0, at = 0;
+        if (!gf_exp(g, x, &e)) continue;
+        if (gfd_ex(x, 1, 0) + gfd_ex(x, 1, 1) + gfd_ex(x, 1, 2) + gfd_ex(x, 1, 3) < e.N) { g->retry = 1; continue; }       /* not enough tokens */
+        gfd_exp_range(&e, wave, &lo, &hi);
+        for (int w = 0; w < wave; ++w) { z += gfd_ex(x, 0, w); at += gfd_ex(x, 1, w); }
+        for (uint32_t jb = lo; jb < hi && at < e.N; jb += 64) {
+            uint32_t tok; bool live, bad;
+            const uint32_t len = gfd_exp_step(&e, jb, hi, lane, &z, &tok, &live, &bad);
+            const uint32_t incl = gfd_dpp_incl(len), mine = at + incl - len;
+            at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (live && mine < e.N) {                      /* tokens are consumed until the blocks are covered */
+                if (bad) g->retry = 1;                       /* not enough run lengths */
+                else if (tok) gf_exp_put(g, x, mine, tok);
+            }
+        }
+    }
+}
+
 /* gf_emit_count + its nine scans for gfd_emit_merge: what lies in front of every WAVE's entries (fixed-length bytes, coefficient
  * symbols, MC-residual blocks per plane) and the totals gf_emit_short asks for; consecutive entries on consecutive lanes */
-__shared__ uint32_t gfd_ec[9][4];
+#define gfd_ec(k, w) gfd_sh[4 * (k) + (w)]
 
-__device__ static inline uint32_t gfd_wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)gfd_dpp_incl(v), 63); }
 
 __device__ static void gfd_emit_count(GPic *g, int tid)
 {
@@ -414,14 +512,14 @@ __device__ static void gfd_emit_count(GPic *g, int tid)
             np += mode == GP_MODE_PREDI;
         }
         const uint32_t sb = gfd_wave_sum(bytes), sn = gfd_wave_sum(nb), sp = gfd_wave_sum(np);
-        if (lane == 0) { gfd_ec[3 * i][wave] = sb; gfd_ec[3 * i + 1][wave] = sn; gfd_ec[3 * i + 2][wave] = sp; }
+        if (lane == 0) { gfd_ec(3 * i, wave) = sb; gfd_ec(3 * i + 1, wave) = sn; gfd_ec(3 * i + 2, wave) = sp; }
     }
     __syncthreads();
     if (tid < 9) {                                      /* instance tid: exclusive prefix over the waves, total */
         const int i = tid / 3, what = tid - 3 * i;
         const int inst = what == 0 ? GF_I_FX(i) : (what == 1 ? GF_I_NB(i) : GF_I_PREDI(i));
         uint32_t run = 0;
-        for (int w = 0; w < 4; ++w) { g->part[GF_P(inst, 64 * w)] = run; run += gfd_ec[tid][w]; }
+        for (int w = 0; w < 4; ++w) { g->part[GF_P(inst, 64 * w)] = run; run += gfd_ec(tid, w); }
         if (inst >= 16) g->tot[inst - 16] = run;
     }
 }
@@ -430,12 +528,8 @@ __device__ static void gfd_emit_count(GPic *g, int tid)
  * picture's macroblocks): tag of every macroblock into the type byte of all its blocks, the lists of coded and of intra
  * macroblocks.  Ranks come from ballots, so the three passes are loads of neighbouring bytes and stores to neighbouring
  * entries; the thread-per-chunk form made every lane of a load touch a cache line of its own. */
-__shared__ uint32_t gfd_tl[12];
+#define gfd_tl gfd_sh
 
-__device__ static inline uint32_t gfd_below(uint64_t mask)      /* set bits of `mask` below this lane */
-{
-    return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 
 __device__ static void gfd_tags_lists(GPic *g, int tid)
 {
@@ -859,13 +953,12 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
         __syncthreads();
         /* round 1: DC symbols -> value ends | kinds: zero tokens */
         gf_dc_count(&g, tid, GPW);
-        gf_exp_zeros(&g, 0, 2, tid, GPW);
+        gfd_exp_zeros(&g, 0, 2, tid);
         __syncthreads();
         if (!g.retry && !g.status) {
-            for (int k = wave; k < 8; k += 4) {
+            for (int k = wave; k < 6; k += 4) {
                 if (k < 3) gfd_scan_add(&g, GF_I_TERM(k), lane, &g.nv[k]);
-                else if (k < 5) gfd_scan_add(&g, GF_I_ZERO(k - 3), lane, 0);
-                else gfd_scan_seg(&g, GF_I_DCF(k - 5), GF_I_DCV(k - 5), lane);
+                else gfd_scan_seg(&g, GF_I_DCF(k - 3), GF_I_DCV(k - 3), lane);
             }
         }
         __syncthreads();
@@ -874,24 +967,18 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
 #endif
         /* round 2: values | kinds: blocks covered */
         gf_dc_values(&g, tid, GPW);
-        gf_exp_lens(&g, 0, 2, tid, GPW);
-        __syncthreads();
-        if (!g.retry && !g.status && wave < 2) gfd_scan_add(&g, GF_I_LEN(wave), lane, 0);
+        gfd_exp_lens(&g, 0, 2, tid);
         __syncthreads();
 #ifdef GP_SUBSTAMPS
         if (is_pb) GP_STAMP(15);
 #endif
         if (!is_pb) {
-            gf_exp_write(&g, 0, 2, tid, GPW);
-            gf_exp_zeros(&g, 2, 5, tid, GPW);
+            gfd_exp_write(&g, 0, 2, tid);
+            gfd_exp_zeros(&g, 2, 5, tid);
             __syncthreads();
-            if (!g.retry && !g.status && wave < 3) gfd_scan_add(&g, GF_I_ZERO(2 + wave), lane, 0);
+            gfd_exp_lens(&g, 2, 5, tid);
             __syncthreads();
-            gf_exp_lens(&g, 2, 5, tid, GPW);
-            __syncthreads();
-            if (!g.retry && !g.status && wave < 3) gfd_scan_add(&g, GF_I_LEN(2 + wave), lane, 0);
-            __syncthreads();
-            gf_exp_write(&g, 2, 5, tid, GPW);
+            gfd_exp_write(&g, 2, 5, tid);
             __syncthreads();
             GP_STAMP(14);
             if (wave < 3) gf_idc_predict_wave(&g, wave, s_rowbuf + wave * rowbuf_stride, gp_stage + 192 * wave, lane);
@@ -899,7 +986,7 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
             GP_STAMP(3);
             if (!g.retry) gp_nest(&g, tid, GPW);
         } else {
-            gf_exp_write(&g, 0, 2, tid, GPW);
+            gfd_exp_write(&g, 0, 2, tid);
 #ifdef GP_SUBSTAMPS
             __syncthreads();
             GP_STAMP(2);
