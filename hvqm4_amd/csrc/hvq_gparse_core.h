@@ -311,12 +311,14 @@ GP_FN int32_t gsym_sovf(const GCode *c, GBits *b, int32_t lo, int32_t hi, uint32
     return (int32_t)total;
 }
 
+/* run lengths of the type / proc runs: ending on the cap is exact and raises no flag (hvq_parse.c sym_uovf: the capped total
+ * exceeds the picture's macroblocks, the run covers all that is left either way) */
 GP_FN int32_t gsym_uovf(const GCode *c, GBits *b, int cap, uint32_t *fl)        /* h4m:667-677 */
 {
     int32_t total = 0, v;
     int guard = 0;
+    (void)fl;
     do { v = gsym(c, b); total += v; } while (v >= 0xFF && ++guard < cap);
-    if (v >= 0xFF) *fl |= HVQ_F_CAPPED;
     return total;
 }
 

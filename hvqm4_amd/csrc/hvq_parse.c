@@ -144,12 +144,17 @@ static int32_t sym_sovf(const Code *c, BitRd *b, int32_t lo, int32_t hi, uint32_
     return (int32_t)total;
 }
 
+/* Run lengths of the macroblock type / proc runs.  A loop that ends on its cap is EXACT here and raises no flag (round 4; it did,
+ * and refused a picture the reference decodes: one clip in 14 000 of the randomized sweep writes "to the end of the picture" as a
+ * chain of seventeen 0xFF symbols): the capped total, cap x 255 with cap = UOVF_CAP(macroblocks) = macroblocks / 255 + 16, already
+ * exceeds the picture's macroblocks, so the run covers everything that is left exactly as the longer sum would, and nothing reads
+ * the section again behind a run that ends the picture. */
 static int32_t sym_uovf(const Code *c, BitRd *b, int cap, uint32_t *flags)     /* h4m:667-677 */
 {
     int32_t total = 0, v;
     int guard = 0;
+    (void)flags;
     do { v = sym(c, b); total += v; } while (v >= 0xFF && ++guard < cap);
-    if (v >= 0xFF) *flags |= HVQ_F_CAPPED;
     return total;
 }
 

@@ -46,6 +46,15 @@ SMALL = [
     ("literals96x96", SynthConfig(width=96, height=96, gop="IPB", seed=40, literal_weight=400.0, p_zero=0.02)),
 ]
 
+# Clips that once caught a defect; compared with the oracle like the others, not part of the golden manifest.
+# longrun88x96: clip 1708 of the randomized sweep with seed 6006 -- a macroblock-type run "to the end of the picture" written as
+# seventeen 0xFF symbols, one more than the parsers' cap: both parsers flagged HVQ_F_CAPPED and the back end refused a picture the
+# reference decodes (round 4; a capped run length is exact, hvq_parse.c sym_uovf)
+REGRESSION = [
+    ("longrun88x96", SynthConfig(width=88, height=96, version="1.3", gop="IPBB", n_gops=2, seed=782179942, preset="flat",
+                                 dc_shifts=(2, 0), unk_shifts=(9, 8), mv_res_bits=(1, 2), weird_kinds=True)),
+]
+
 MEDIUM = [
     ("c2_320x240_I", SynthConfig(width=320, height=240, gop="I", n_gops=4, seed=20)),
     ("c3_640x480", SynthConfig(width=640, height=480, gop="IPBBPBB", seed=21)),

@@ -100,7 +100,7 @@ def compare_clip(emul, clip, mode=FLAT_ONLY):
 
 
 @pytest.mark.parametrize("mode", [CHAINS, FLAT_ONLY], ids=["chains", "flat"])
-@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM, ids=lambda c: c[0])
+@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM + clips.REGRESSION, ids=lambda c: c[0])
 def test_gpu_parse_core_matches_host_parser(emul, case, mode):
     if case[0].startswith(("longescape", "bigscalars")) and mode == FLAT_ONLY:
         mode = FLAT        # overflow runs of hundreds of symbols are what the flat path hands to the chains by design

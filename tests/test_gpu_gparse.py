@@ -18,7 +18,7 @@ def gpu_ctx():
     ctx.close()
 
 
-@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM, ids=lambda c: c[0])
+@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM + clips.REGRESSION, ids=lambda c: c[0])
 def test_gpu_parsed_clip_matches_oracle(gpu_ctx, case):
     from hvqm4_amd import batch
     from oracle import bridge

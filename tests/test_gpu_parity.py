@@ -15,7 +15,7 @@ def _first_diff(a, b):
     return "equal"
 
 
-@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM, ids=lambda c: c[0])
+@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM + clips.REGRESSION, ids=lambda c: c[0])
 def test_batched_path_matches_oracle(case, gpu_ctx):
     from hvqm4_amd.batch import decode_clip
     from oracle import bridge

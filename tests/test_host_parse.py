@@ -47,7 +47,7 @@ def decode_via_descriptors(clip, truncate=None):
     return np.stack(out), flags
 
 
-@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM[:2], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM[:2] + clips.REGRESSION, ids=lambda c: c[0])
 def test_parse_plus_descriptor_spec_matches_oracle(case):
     from oracle import bridge
     clip = clips.get(case)

@@ -8,6 +8,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 from hvqm4_amd import batch  # noqa: E402
+from hvqm4_amd._lib import HvqError  # noqa: E402
 from hvqm4_amd.synth import SynthConfig, make_clip  # noqa: E402
 from oracle import bridge  # noqa: E402
 
@@ -48,7 +49,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
     which = sys.argv[3] if len(sys.argv) > 3 else "host"
     ctx = batch.Context(0)
-    bad = pics = 0
+    bad = pics = refused = 0
     t0 = time.time()
     for i in range(n):
         cfg = draw(rng)
@@ -58,12 +59,20 @@ def main():
         every = [None, 1, 3][int(rng.integers(0, 3))]          # flushes per clip (nest of the last I picture across batches)
         ok = True
         for gpu_parse in ([False, True] if which == "both" else [which == "gpu"]):
-            if nslots is None:
-                got = batch.decode_clip(ctx, clip.data, gpu_parse=gpu_parse, flush_every=every)
-                ok = ok and np.array_equal(got, want)
-            else:                                              # small ring: only the last picture is guaranteed resident
-                got = decode_last(ctx, clip.data, nslots, gpu_parse)
-                ok = ok and np.array_equal(got, want[-1])
+            try:
+                if nslots is None:
+                    got = batch.decode_clip(ctx, clip.data, gpu_parse=gpu_parse, flush_every=every)
+                    ok = ok and np.array_equal(got, want)
+                else:                                          # small ring: only the last picture is guaranteed resident
+                    got = decode_last(ctx, clip.data, nslots, gpu_parse)
+                    ok = ok and np.array_equal(got, want[-1])
+            except HvqError as e:
+                # both parsers refuse a picture whose overflow-symbol loop ends on their cap (HVQ_F_CAPPED): the
+                # reference sums for as long as the stream says.  Counted, not a mismatch; anything else is an error.
+                if "overflow-symbol run" not in str(e):
+                    raise
+                refused += 1
+                print("REFUSED (capped overflow run)", "gpu" if gpu_parse else "host", cfg, flush=True)
         pics += clip.n_pictures
         if not ok:
             bad += 1
@@ -71,7 +80,7 @@ def main():
         if (i + 1) % 50 == 0:
             print(f"{i + 1} clips, {pics} pictures, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     ctx.close()
-    print(f"sweep done: {n} clips, {pics} pictures, {bad} mismatches")
+    print(f"sweep done: {n} clips, {pics} pictures, {bad} mismatches" + (f", {refused} refused by design (capped overflow run)" if refused else ""))
     sys.exit(1 if bad else 0)
 
 
