@@ -81,7 +81,7 @@ __device__ static inline uint64_t gf_ring_window64(const uint32_t *ring, uint32_
  * is rare per lane but not per wave, so it is finished on the spot: the tree is walked bit by bit from the node the table
  * gave, the window is taken anew behind it, the other lanes wait for that one symbol only.  `a` = how far the lane's ring is
  * known to reach. */
-__device__ static inline uint32_t gf_four(const GCode *c, const uint16_t *tab, int bits, const uint32_t *ring, int l,
+__device__ static inline uint32_t gf_four(const uint16_t *kid, const uint16_t *tab, int bits, const uint32_t *ring, int l,
                                           uint32_t *ppos, uint32_t *pa, uint32_t nbits, uint32_t *guard)
 {
     uint32_t pos = *ppos;
@@ -118,7 +118,7 @@ __device__ static inline uint32_t gf_four(const GCode *c, const uint16_t *tab, i
         for (uint32_t left = 64; id >= 256; --left) {
             if (left == 0) { w = gf_ring_window64(ring, pos); left = 64; }
             const uint32_t bit = pos < nbits ? (uint32_t)(w >> 63) : 0u;
-            id = c->kid[bit][id - 256];
+            id = kid[bit * 256u + (uint32_t)id - 256u];
             w <<= 1; ++pos;
         }
         sy[k] = (uint32_t)id << 8;
@@ -144,7 +144,7 @@ __device__ static void gf_decode_wave(GPic *g, const GCode *codes, int lane, uin
     uint32_t pos = q->pos, n = 0, guard = 0;
     GP_G uint8_t *out = (GP_G uint8_t *)(g->sym + q->off);
     const uint32_t *ring = gf_ring(l);
-    const uint16_t *tab = gf_lane_table(c, (int)q->tree);
+    const uint16_t *tab = gf_lane_table(codes, (int)q->tree), *kid = gf_lane_kids(codes, (int)q->tree);
     const int bits = gf_lane_bits((int)q->tree);
 #ifdef GF_PROFILE
     uint64_t ta = 0, tb = 0, rounds = 0;
@@ -169,8 +169,8 @@ __device__ static void gf_decode_wave(GPic *g, const GCode *codes, int lane, uin
         if (guard > GF_SPIN_CAP) { g->retry = 1; break; }
         GF_T(t1);
         if (act) {
-            const uint32_t lo = gf_four(c, tab, bits, ring, l, &pos, &a, nbits, &guard);
-            const uint32_t hi = gf_four(c, tab, bits, ring, l, &pos, &a, nbits, &guard);
+            const uint32_t lo = gf_four(kid, tab, bits, ring, l, &pos, &a, nbits, &guard);
+            const uint32_t hi = gf_four(kid, tab, bits, ring, l, &pos, &a, nbits, &guard);
             *(GP_G uint2 *)(out + n) = make_uint2(lo, hi);
             n += 8;
         }
@@ -858,7 +858,11 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
     if (wave == 0) gp_collect_tree_status(&g, ntrees);
     /* the chains read 8-bit tables with the leaf's value in the entry; the flat path's lanes have their own (gf_fill_lane_tables) */
     for (int c = flat ? GC_MV : 0; c < ntrees; ++c) gc_fill_lut(&codes[c], tid, GPW);
-    if (flat) gf_fill_lane_tables(&g, codes, tid, GPW);
+    if (flat) {
+        gf_move_kids(&g, codes, tid, GPW);
+        __syncthreads();
+        gf_fill_lane_tables(&g, codes, tid, GPW);
+    }
     __syncthreads();
     GP_STAMP(1);
     __builtin_amdgcn_s_setprio(0);

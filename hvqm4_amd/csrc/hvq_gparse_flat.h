@@ -131,22 +131,40 @@ GP_FN void gf_setup_lanes(GPic *g)
 }
 
 /* The table a lane decodes with: 16-bit entries -- [5:0] bits consumed, [7] leaf reached, [15:8] the leaf byte or the inner node
- * (id - 256) -- in the LDS of the 8-bit tables with 32-bit entries the lanes' trees do not need on this path (their `lut`
- * arrays, 1 KB each) and of the 2 KB behind the trees: 10 bits for the block kinds (a chroma pair's code is 9 or 10 bits in a
- * dense stream: 45 % of them missed an 8-bit table, and every miss holds all lanes up for a walk through the tree), 9 bits for
- * run lengths, DC symbols (a third of whose rare long codes are 9 bits) and coefficient symbols (7 to 9 bits). */
-GP_FN int gf_lane_bits(int tree) { return tree == GC_BN ? 10 : 9; }
-GP_FN uint16_t *gf_lane_table(const GCode *c, int tree) { return (uint16_t *)(tree == GC_BN ? gp_stage + GP_XLUT_DWORD : (uint32_t *)c->lut); }
-GP_FN void gf_fill_lane_tables(const GPic *g, GCode *codes, int tid, int nthr)
+ * (id - 256) -- in the LDS of the 8-bit tables with 32-bit entries the lanes' trees do not need on this path and of the 2 KB
+ * behind the trees: 10 bits for the block kinds (a chroma pair's code is 9 or 10 bits in a dense stream: 45 % of them missed an
+ * 8-bit table, and every miss holds all lanes up for a walk through the tree) and for the DC symbols (63 % of whose long codes
+ * fit 10 bits, 38 % nine), 9 bits for run lengths and coefficient symbols (7 to 9 bits).  Where they lie: DC in the 2 KB behind
+ * the trees; run lengths and coefficient symbols in their trees' `lut` arrays (1 KB each); the block kinds in their tree's `lut`
+ * AND `kid` arrays, which are 2 KB in one piece -- the children of the block-kind tree (the walk of its rare longer codes needs
+ * them) move into the DC tree's `lut` array first (gf_move_kids, one barrier before gf_fill_lane_tables). */
+GP_FN int gf_lane_bits(int tree) { return tree == GC_BN || tree == GC_DC ? 10 : 9; }
+GP_FN uint16_t *gf_lane_table(const GCode *codes, int tree)
+{
+    return (uint16_t *)(tree == GC_DC ? gp_stage + GP_XLUT_DWORD : (uint32_t *)codes[tree].lut);
+}
+/* children of inner node `id` (256..510) of a lane's tree: kid[bit * 256 + id - 256] */
+GP_FN const uint16_t *gf_lane_kids(const GCode *codes, int tree)
+{
+    return tree == GC_BN ? (const uint16_t *)codes[GC_DC].lut : &codes[tree].kid[0][0];
+}
+GP_FN void gf_move_kids(const GPic *g, GCode *codes, int tid, int nthr)
+{
+    if (g->status) return;
+    const uint32_t *src = (const uint32_t *)&codes[GC_BN].kid[0][0];
+    uint32_t *dst = (uint32_t *)codes[GC_DC].lut;
+    for (int k = tid; k < 256; k += nthr) dst[k] = src[k];
+}
+GP_FN void gf_fill_lane_tables(const GPic *g, GCode *codes, int tid, int nthr)       /* after gf_move_kids */
 {
     if (g->status) return;
     for (int tree = GC_BN; tree <= GC_BT; ++tree) {
-        const GCode *c = &codes[tree];
-        uint16_t *tab = gf_lane_table(c, tree);
-        const int bits = gf_lane_bits(tree), root = c->root;
+        const uint16_t *kid = gf_lane_kids(codes, tree);
+        uint16_t *tab = gf_lane_table(codes, tree);
+        const int bits = gf_lane_bits(tree), root = codes[tree].root;
         for (int e = tid; e < (1 << bits); e += nthr) {
             int node = root, d = 0;
-            while (node >= 256 && d < bits) { node = c->kid[(e >> (bits - 1 - d)) & 1][node - 256]; ++d; }
+            while (node >= 256 && d < bits) { node = kid[((e >> (bits - 1 - d)) & 1) * 256 + node - 256]; ++d; }
             tab[e] = (uint16_t)((uint32_t)d | (node < 256 ? 0x80u | ((uint32_t)node << 8) : (uint32_t)(node - 256) << 8));
         }
     }
@@ -170,7 +188,7 @@ GP_FN void gf_decode_lane(GPic *g, const GCode *codes, int l)
     if (g->status) return;
     GLane *q = &g->lane[l];
     const GCode *c = &codes[q->tree];
-    const uint16_t *tab = gf_lane_table(c, (int)q->tree);
+    const uint16_t *tab = gf_lane_table(codes, (int)q->tree), *kid = gf_lane_kids(codes, (int)q->tree);
     const int bits = gf_lane_bits((int)q->tree);
     GP_G uint8_t *out = (GP_G uint8_t *)(g->sym + q->off);
     uint32_t pos = q->pos, n = 0;
@@ -182,7 +200,7 @@ GP_FN void gf_decode_lane(GPic *g, const GCode *codes, int l)
             int id = (int)(e >> 8);
             if (!(e & 0x80u)) {
                 id += 256;
-                while (id >= 256) { id = c->kid[gf_peek64(g, pos) >> 63][id - 256]; ++pos; }
+                while (id >= 256) { id = kid[(gf_peek64(g, pos) >> 63) * 256 + id - 256]; ++pos; }
             }
             out[n++] = (uint8_t)id;
         }

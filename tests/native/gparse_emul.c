@@ -93,6 +93,7 @@ again:
         for (int t = 0; t < NTHR; ++t) gp_lists_write(g, t, NTHR);
     }
     if (flat) {
+        for (int t = 0; t < NTHR; ++t) gf_move_kids(g, codes, t, NTHR);
         for (int t = 0; t < NTHR; ++t) gf_fill_lane_tables(g, codes, t, NTHR);
         gf_setup_lanes(g);
         for (int l = 0; l < (g->is_pb ? GF_RLE0 : GF_LANES); ++l) gf_decode_lane(g, codes, l);
