@@ -600,12 +600,12 @@ __device__ static void gfd_tags_lists(GPic *g, int tid)
     g->part[GP_PART2 + tid] = fl;
 }
 
-#ifdef GP_LAYOUT_COOP
-/* Not the default: measured 0.05 ms SLOWER than the thread-per-run passes with their batched loads (3.44 against 3.39 ms, r04ri / r04rj) --
- * a run is one load either way since the loads are requested eight at a time, and this form pays two wave reductions and a division per run. */
 /* gf_layout_sum / gf_layout_blocks with the 64 blocks of a run on the 64 lanes (a wave owns a quarter of the picture's tiles): one
  * load of neighbouring type bytes per run instead of 64 per thread, sums and offsets by DPP scans.  The sums go to the slots of the
- * waves' first threads (zeros elsewhere), so that gfd_layout_finish scans and reduces them as before. */
+ * waves' first threads (zeros elsewhere), so that gfd_layout_finish scans and reduces them as before.  Measured twice: with the roles
+ * piled on single SIMDs this form was 0.05 ms slower than the thread-per-run passes with their batched loads (two wave reductions and
+ * a division per run); with the roles spread evenly, where the pictures' all-thread passes run side by side and the vector-memory
+ * pipeline is what they share, it is 0.07 ms faster (3.10-3.12 -> 3.02-3.04 ms, r04rv). */
 __device__ static inline void gfd_run_types(const GPic *g, uint32_t r, int lane, uint32_t *t, uint32_t *by, uint32_t *bx, int *plane, bool *live)
 {
     const int i = gp_run_plane(g, r);
@@ -683,7 +683,6 @@ __device__ static void gfd_layout_blocks(GPic *g, int tid)
         pinfo[q->blk_first + at] = ent;
     }
 }
-#endif
 
 /* one wave: scan of the threads' tile totals, maxima and flags of the layout, then sizes and header (gf_layout_finish) */
 __device__ static void gfd_layout_finish(GPic *g, int lane)
@@ -1007,11 +1006,7 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
             GP_STAMP(3);
         }
         if (!g.retry) {
-#ifdef GP_LAYOUT_COOP
             gfd_layout_sum(&g, tid);
-#else
-            gf_layout_sum(&g, tid, GPW);
-#endif
             __syncthreads();
             GP_STAMP(4);
             if (wave == 0) gfd_layout_finish(&g, lane);
@@ -1019,11 +1014,7 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
 #ifndef GP_HWID
             GP_STAMP(8);
 #endif
-#ifdef GP_LAYOUT_COOP
             gfd_layout_blocks(&g, tid);
-#else
-            gf_layout_blocks(&g, tid, GPW);
-#endif
             __syncthreads();
             GP_STAMP(9);
             gfd_emit_count(&g, tid);                             /* gf_emit_count and its scans, per wave */
