@@ -287,7 +287,8 @@ __device__ static inline uint32_t gfd_below(uint64_t mask)      /* set bits of `
     return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-__shared__ uint32_t gfd_sh[40];                 /* per-wave partials of the wave-cooperative passes (one pass at a time) */
+__shared__ uint32_t gfd_sh[64];                 /* per-wave partials of the wave-cooperative passes; 0-39 one pass at a time, 40-63 the intra-DC
+                                                   pass, which starts in the same barrier interval as the last expansion pass reads its own */
 
 /* gf_emit_merge on the device.  A wave owns the entries of its 64 threads' chunks (whose starting offsets gf_emit_count + the
  * scans have already produced), walks them 64 at a time and gets every entry's position in the coefficient symbols, in the
@@ -486,6 +487,79 @@ __device__ static void gfd_exp_write(GPic *g, int x0, int x1, int tid)
                 if (bad) g->retry = 1;                       /* not enough run lengths */
                 else if (tok) gf_exp_put(g, x, mine, tok);
             }
+        }
+    }
+}
+
+/* gf_pbdc_sums / gf_pbdc_write (intra DC of a P/B picture, h4m:1742-1776) with consecutive values on consecutive lanes: value e of
+ * plane i belongs to block e % nblk of the intra macroblock t0[e / nblk]; the DC accumulates from 0x7F within a run of consecutive
+ * intra macroblocks, i.e. it is a segmented running sum over the values with a segment head at the first block of every run.
+ * gfd_pb(i, which, wave): does the wave's range hold a head / what has accumulated behind its last head (or over all of it). */
+#define gfd_pb(i, which, w) gfd_sh[40 + 8 * (i) + 4 * (which) + (w)]
+
+__device__ static inline void gfd_pbdc_step(const GPic *g, const GP_G uint32_t *V, const GP_G uint32_t *t0, uint32_t nblk, uint32_t e, uint32_t hi,
+                                            uint32_t *val, bool *head, uint32_t *mb, uint32_t *j)
+{
+    const bool live = e < hi;
+    const uint32_t r = nblk == 4 ? e >> 2 : (nblk == 1 ? e : e / nblk);
+    *j = e - r * nblk;
+    *val = live ? V[e] : 0u;
+    *mb = live ? t0[r] : 0u;
+    *head = live && *j == 0 && (r == 0 || *mb != t0[r - 1] + 1u);
+    (void)g;
+}
+
+__device__ static void gfd_pbdc_sums(GPic *g, int tid)
+{
+    if (g->status || g->retry) return;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t nblk = (uint32_t)g->pl[i].nblk, n = GP_UNI(g->ntype0) * nblk;
+        if (n > g->nv[i]) { g->retry = 1; continue; }
+        const GP_G uint32_t *V = GFD_UNIP(const GP_G uint32_t *, g->val + g->val_off[i]), *t0 = GFD_UNIP(const GP_G uint32_t *, g->t0);
+        const uint32_t per = ((n + GPW - 1) / GPW) * 64u, lo = per * (uint32_t)wave < n ? per * (uint32_t)wave : n, hi = lo + per < n ? lo + per : n;
+        uint32_t has = 0, tail = 0;
+        for (uint32_t eb = lo; eb < hi; eb += 64) {
+            uint32_t v, mb, j; bool head;
+            gfd_pbdc_step(g, V, t0, nblk, eb + (uint32_t)lane, hi, &v, &head, &mb, &j);
+            const uint64_t bh = __builtin_amdgcn_ballot_w64(head);
+            if (bh) {                                            /* what follows the step's last head, that head's value included */
+                const int last = 63 - __builtin_clzll(bh);
+                tail = gfd_wave_sum(lane >= last ? v : 0u);
+                has = 1;
+            } else tail += gfd_wave_sum(v);
+        }
+        if (lane == 0) { gfd_pb(i, 0, wave) = has; gfd_pb(i, 1, wave) = tail; }
+    }
+}
+
+__device__ static void gfd_pbdc_write(GPic *g, int tid)
+{
+    if (g->status || g->retry) return;
+    const int lane = tid & 63, wave = (int)GP_UNI(tid >> 6);
+    const uint32_t mw = GP_UNI(g->mw);
+    for (int i = 0; i < 3; ++i) {
+        const GPlane *q = &g->pl[i];
+        const uint32_t nblk = (uint32_t)q->nblk, n = GP_UNI(g->ntype0) * nblk;
+        const GP_G uint32_t *V = GFD_UNIP(const GP_G uint32_t *, g->val + g->val_off[i]), *t0 = GFD_UNIP(const GP_G uint32_t *, g->t0);
+        const uint32_t per = ((n + GPW - 1) / GPW) * 64u, lo = per * (uint32_t)wave < n ? per * (uint32_t)wave : n, hi = lo + per < n ? lo + per : n;
+        uint32_t carry = 0x7F;                                   /* the DC entering this wave's first value */
+        for (int w = 0; w < wave; ++w) carry = gfd_pb(i, 0, w) ? 0x7Fu + gfd_pb(i, 1, w) : carry + gfd_pb(i, 1, w);
+        for (uint32_t eb = lo; eb < hi; eb += 64) {
+            uint32_t v, mb, j; bool head;
+            gfd_pbdc_step(g, V, t0, nblk, eb + (uint32_t)lane, hi, &v, &head, &mb, &j);
+            const uint64_t bh = __builtin_amdgcn_ballot_w64(head);
+            const uint32_t incl = gfd_dpp_incl(v), excl = incl - v;
+            /* the last head at or before this lane: the sum restarts at 0x7F there */
+            const uint64_t mine = bh & ((2ull << lane) - 1ull);
+            const int hl = mine ? 63 - __builtin_clzll(mine) : 0;
+            const uint32_t before = (uint32_t)__shfl((int)excl, hl, 64);
+            const uint32_t acc = mine ? 0x7Fu + incl - before : carry + incl;
+            if (eb + (uint32_t)lane < hi) {
+                const int my = (int)(mb / mw), mx = (int)(mb - (uint32_t)my * mw);
+                gp_map_ent(g, i, my * q->by_per + gp_dy((int)j), mx * q->bx_per + gp_dx((int)j))[0] = (uint8_t)acc;
+            }
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)acc, 63);
         }
     }
 }
@@ -994,14 +1068,12 @@ void hvq_parse_kernel_t(const HvqParseJob *__restrict__ jobs, HvqParseResult *__
             __syncthreads();
             GP_STAMP(2);
 #endif
-            gf_pbdc_sums(&g, tid, GPW);
-            __syncthreads();
-            if (!g.retry && !g.status && wave < 3) gfd_scan_seg(&g, GF_I_PBF(wave), GF_I_PBV(wave), lane);
+            gfd_pbdc_sums(&g, tid);
             __syncthreads();
 #ifdef GP_SUBSTAMPS
             GP_STAMP(5);
 #endif
-            gf_pbdc_write(&g, tid, GPW);
+            gfd_pbdc_write(&g, tid);
             __syncthreads();
             GP_STAMP(3);
         }
