@@ -143,6 +143,7 @@ def gen_clips(cfgs, workers: int, cache: str = ""):
     out = [pickle.load(open(p, "rb")) if p and os.path.exists(p) else None for p in paths]
     todo = [i for i, o in enumerate(out) if o is None]
     if todo:
+        assert not (_GPU_OPEN and workers > 1 and len(todo) > 1), "no process pool once this process has opened the GPU"
         if workers <= 1 or len(todo) <= 1:
             made = [_make(cfgs[i]) for i in todo]
         else:
@@ -155,6 +156,9 @@ def gen_clips(cfgs, workers: int, cache: str = ""):
                 os.makedirs(cache, exist_ok=True)
                 pickle.dump(m, open(paths[i], "wb"))
     return out
+
+
+_GPU_OPEN = False       # set by main() right before the first batch.Context: no process pool may start afterwards
 
 
 def host_cores() -> int:
@@ -186,6 +190,7 @@ def pin_rank(local_rank: int, local_world: int):
 
 # ---------------------------------------------------------------------------------------------- one rank
 def main():
+    global _GPU_OPEN
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -224,6 +229,12 @@ def main():
         what = (f"C4: 64 clips (32 x 320x240 + 32 x 640x480, HVQM4 1.3/1.5 alternating, seeds 0..63, 4 x 16-picture GOPs), "
                 f"clip i -> rank i mod {world}, {args.preset} synthetic streams, descriptors resident in HBM")
     clips = gen_clips(cfgs, workers, args.clip_cache)
+    # every synthetic clip of the run is made HERE, before this process opens the GPU: a process pool started later would fork
+    # (spawn) from a GPU-initialised parent -- under rocprofv3 every child gets the tool injected (round 4's evidence logs ended
+    # in eight "Aborted" blocks from exactly that) -- and this pool is touchy about it
+    c4_share_clips = None
+    if rank == 0 and world == 1 and not args.no_sdk:
+        c4_share_clips = gen_clips(c4_share_configs(), workers, args.clip_cache)
     gen_s = time.time() - t0
     pics = [list(video_pictures(c.data)) for c in clips]
 
@@ -232,6 +243,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         c3 = clips[0] if (args.workload == "c5" and (args.width, args.height, args.gop) == (640, 480, GOP16)) else None
         cpu_base = cpu_baseline(args.cpu_seconds, c3, args.preset)
+    _GPU_OPEN = True                    # from here on gen_clips refuses to start a process pool
 
     # one rank per GPU; HVQM4_BENCH_SHARE_GPU=1 lets several ranks share device 0 (rehearsal on a 1-GPU box only)
     device = 0 if os.environ.get("HVQM4_BENCH_SHARE_GPU") else local_rank
@@ -334,31 +346,54 @@ def main():
         # 24 batches: on a shared host one batch in four or five waits 1-2 ms for its bitstreams (the host's copy of 160 MB into the
         # pinned arena), so a window of 8 says 4.7 or 5.2 ms by luck; the mean over the window is the number, the median beside it
         nwarm, nbatch = 2, int(os.environ.get("HVQM4_BENCH_STREAM_BATCHES", "24"))
-        barrier(); ctx2.sync()
-        ctx2.submit_many_device(a_sid2, a_ft, a_raw)
-        ctx2.flush_begin()
-        t_calls = [0.0, 0.0, 0.0]
-        t_end = []
-        for k in range(nwarm + nbatch - 1):
-            ta = time.perf_counter()
-            ctx2.submit_many_device(a_sid2, a_ft, a_raw)
-            tb = time.perf_counter()
-            ctx2.flush_end()
-            tc = time.perf_counter()
+        def stream_loop(submit):
+            """steady-state period of flush_begin / submit next / flush_end; returns (mean period, median period, mean ms of the
+            three calls, parse kernel ms of the last batch)"""
+            barrier(); ctx2.sync()
+            submit()
             ctx2.flush_begin()
-            td = time.perf_counter()
-            t_end.append(tc)
-            if k >= nwarm:
-                t_calls[0] += tb - ta; t_calls[1] += tc - tb; t_calls[2] += td - tc
-        ctx2.flush_end()
-        t_end.append(time.perf_counter())
-        ctx2.sync()
-        t_pipe = (t_end[-1] - t_end[nwarm]) / (len(t_end) - 1 - nwarm)
-        t_periods = sorted(b - a for a, b in zip(t_end[nwarm:], t_end[nwarm + 1:]))
-        t_pipe_median = t_periods[len(t_periods) // 2]
-        t_calls = [round(x / (nbatch - 1) * 1e3, 2) for x in t_calls]
-        parse_ms_streaming = ctx2.stats().gpu_parse_ms
-        n_done = 3 + nwarm + nbatch
+            calls = [0.0, 0.0, 0.0]
+            ends = []
+            for k in range(nwarm + nbatch - 1):
+                ta = time.perf_counter()
+                submit()
+                tb = time.perf_counter()
+                ctx2.flush_end()
+                tc = time.perf_counter()
+                ctx2.flush_begin()
+                td = time.perf_counter()
+                ends.append(tc)
+                if k >= nwarm:
+                    calls[0] += tb - ta; calls[1] += tc - tb; calls[2] += td - tc
+            ctx2.flush_end()
+            ends.append(time.perf_counter())
+            ctx2.sync()
+            pipe = (ends[-1] - ends[nwarm]) / (len(ends) - 1 - nwarm)
+            periods = sorted(b - a for a, b in zip(ends[nwarm:], ends[nwarm + 1:]))
+            return pipe, periods[len(periods) // 2], [round(x / (nbatch - 1) * 1e3, 2) for x in calls], ctx2.stats().gpu_parse_ms
+
+        # (a) the caller's buffers are copied into the pinned arena by the library's worker threads (hvq_submit_many_device_async)
+        st_c0 = ctx2.stats()
+        t_pipe, t_pipe_median, t_calls, parse_ms_streaming = stream_loop(lambda: ctx2.submit_many_device(a_sid2, a_ft, a_raw, defer=True))
+        st_c1 = ctx2.stats()
+        copy_gbs = (st_c1.copy_bytes - st_c0.copy_bytes) / max(st_c1.copy_seconds - st_c0.copy_seconds, 1e-9) / 1e9
+        # (b) zero copy: the bitstreams ARE in the pinned arena when the batch is submitted (hvq_arena_reserve: a reader's read()
+        # target).  Both arenas are filled once during the warm-up batches; afterwards a batch costs the host its bookkeeping only.
+        z_len = [len(p) for p in a_raw]
+        z_off, z_at = [], 0
+        for ln in z_len:
+            z_off.append(z_at); z_at += ctx2.arena_stride(ln)
+        z_fills = [0]
+
+        def submit_zero():
+            view = ctx2.arena_reserve(z_at)
+            if z_fills[0] < 2:                          # first use of each of the two arenas
+                for p, o in zip(a_raw, z_off):
+                    view[o:o + len(p)] = np.frombuffer(p, np.uint8)
+                z_fills[0] += 1
+            ctx2.submit_many_arena(a_sid2, a_ft, z_off, z_len)
+        z_pipe, z_median, z_calls, z_parse = stream_loop(submit_zero)
+        n_done = 3 + 2 * (nwarm + nbatch)
         ok = 0
         ok_per_stream = []
         n_seq = [len(pics[stream_clip[s]]) for s in range(len(sids))]
@@ -398,13 +433,13 @@ def main():
                     k_of.append(seen.get(s, 0)); seen[s] = k_of[-1] + 1
                 nb3, nwarm3 = 6, 2
                 barrier(); ctx3.sync()
-                ctx3.submit_many_device(a_sid3, a_ft, a_raw)
+                ctx3.submit_many_device(a_sid3, a_ft, a_raw, defer=True)
                 ctx3.flush_begin()
                 t_done = []
                 for b in range(nb3 + nwarm3):
                     last = b == nb3 + nwarm3 - 1
                     if not last:
-                        ctx3.submit_many_device(a_sid3, a_ft, a_raw)
+                        ctx3.submit_many_device(a_sid3, a_ft, a_raw, defer=True)
                     ctx3.flush_end()
                     if not last:
                         ctx3.flush_begin()
@@ -444,6 +479,14 @@ def main():
                    "parse_kernel_ms": round(min(parse_ms[1:]), 3), "pass_ms": [round(t * 1e3, 2) for t in t_pass],
                    "submit_flush_sync_ms": t_split,
                    "host_copy_threads": copy_threads,
+                   "host_copy_GBs": round(copy_gbs, 2), "host_copy_GBs_all_ranks": round(grp.sum(copy_gbs), 2),
+                   "host_copy_bytes_per_batch": int(sum(z_len)),
+                   "streaming_zero_copy": {"value": round(grp.sum(px / z_pipe / 1e6), 1), "unit": "Mpixels/s",
+                                           "ms_per_batch": round(z_pipe * 1e3, 2), "ms_per_batch_median": round(z_median * 1e3, 2),
+                                           "submit_end_begin_ms": z_calls, "parse_kernel_ms": round(z_parse, 3),
+                                           "what": "the same streaming loop with the bitstreams already in the library's pinned arena "
+                                                   "(hvq_arena_reserve / hvq_submit_many_arena: what a container reader that read()s into the "
+                                                   "reservation leaves): no host memcpy, the batch costs the host its bookkeeping and the DMA"},
                    "affinity": {"cores_of_rank0": len(my_cores), "first": my_cores[0], "last": my_cores[-1], "ranks_on_host": local_world,
                                 "pinned": local_world > 1},
                    "pictures_checked_against_host_parsed": ok,
@@ -501,7 +544,7 @@ def main():
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_over_algorithmic": traffic["over_algorithmic"] if traffic else None,
             "traffic_source": traffic["source"] if traffic else None,
-            "traffic_what": "HBM bytes per launch of the dominant kernel (hvq_recon_kernel), PMC passes",
+            "traffic_what": f"HBM bytes per launch of the dominant kernel ({'hvq_recon_kernel' if two_pass else 'hvq_recon_inline_kernel'}), PMC passes",
             "valu": pmc_valu(args),
             "kernel": "hvq_recon_kernel" if two_pass else "hvq_recon_inline_kernel", "algorithmic_bytes_per_launch": int(st.algorithmic_bytes // launches),
             "recon_only": {"achieved": round(recon_achieved, 1), "frac": round(recon_achieved / HBM_PEAK_GBS, 4),
@@ -634,54 +677,34 @@ def main():
     # BASELINE config 4 at the shape one GPU of eight sees it: clips 0, 8, ..., 56 of the 64 (4 x 320x240 + 4 x 640x480, HVQM4 1.3
     # and 1.5 alternating), every picture checked against the SHA-256 the REFERENCE decoder produced (tests/golden/manifest.json)
     if rank == 0 and world == 1 and not args.no_sdk:
-        out["c4_share"] = c4_share_leg(device, args.steps, args.warmup or 1, threads)
-
-    # (after the main context is closed: HIP maps streams onto four hardware queues, and two streams that share one do not overlap)
-    # the same resident-descriptor pass with the dependency levels of the even and of the odd streams on TWO HIP streams
-    # (HVQM4_AMD_QUEUES=2): while one chain drains a level the other keeps the CUs busy.  Reported beside the headline, never as
-    # `value` or `roofline`: overlapping launches make per-kernel durations incomparable with the elapsed time.
-    if rank == 0 and world == 1 and not args.no_sdk:
-        try:
-            os.environ["HVQM4_AMD_QUEUES"] = "2"
-            ctxq = batch.Context(device)
-            sidsq = [ctxq.open_stream(clips[ci].width, clips[ci].height, 2, 2, clips[ci].version == "1.5", args.nslots) for ci in stream_clip]
-            ctxq.submit_many([sidsq[s] for s in a_stream], a_ft, a_pic, threads)
-            ctxq.flush(); ctxq.sync()
-            ctxq.replay_stage(args.warmup or 1, 1)
-            msq_stage = ctxq.replay_stage(args.steps, 1)
-            msq = ctxq.replay(args.steps)
-            okq = all(np.array_equal(ctxq.read_picture(sidsq[s], len(pics[stream_clip[s]]) - 1), last_single[s]) for s in range(len(last_single)))
-            ctxq.close()
-            out["two_queues"] = {"value": round(px_step * args.steps / (msq_stage * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
-                                 "frac_of_roofline": round(st.algorithmic_bytes * args.steps / (msq_stage * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "recon_only_value": round(px_step * args.steps / (msq * 1e-3) / 1e6, 1),
-                                 "recon_only_frac": round(st.algorithmic_bytes * args.steps / (msq * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "pictures_equal_single_queue": bool(okq),
-                                 "what": "HVQM4_AMD_QUEUES=2: levels of even / odd streams on two HIP streams, HIP-event time over the same steps"}
-        except Exception as e:
-            out["two_queues"] = {"error": str(e)}
-        finally:
-            os.environ.pop("HVQM4_AMD_QUEUES", None)
+        out["c4_share"] = c4_share_leg(device, args.steps, args.warmup or 1, threads, c4_share_clips)
 
     if rank == 0:
         grp.emit(json.dumps(out))
     grp.close()
 
 
-def c4_share_leg(device, steps, warmup, threads):
+C4_SHARE_IDS = list(range(0, 64, 8))
+
+
+def c4_share_configs():
+    """the golden clips' configuration (tests/clips.py _c4) of the eight clips one GPU of eight gets"""
+    from hvqm4_amd.synth import SynthConfig
+    cfgs = []
+    for i in C4_SHARE_IDS:
+        small, v13 = (i // 8) % 2 == 0, ((i // 16) + i) % 2 == 0
+        cfgs.append(SynthConfig(width=320 if small else 640, height=240 if small else 480, version="1.3" if v13 else "1.5", gop=GOP16, seed=i))
+    return cfgs
+
+
+def c4_share_leg(device, steps, warmup, threads, cl):
     try:
         import hashlib
         import numpy as np
         from hvqm4_amd import batch
         from hvqm4_amd.container import video_pictures
-        from hvqm4_amd.synth import SynthConfig
         manifest = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["clips"]
-        ids = list(range(0, 64, 8))
-        cfgs = []
-        for i in ids:                                   # the golden clips' configuration (tests/clips.py _c4)
-            small, v13 = (i // 8) % 2 == 0, ((i // 16) + i) % 2 == 0
-            cfgs.append(SynthConfig(width=320 if small else 640, height=240 if small else 480, version="1.3" if v13 else "1.5", gop=GOP16, seed=i))
-        cl = gen_clips(cfgs, min(8, host_cores()))
+        ids = C4_SHARE_IDS
         for i, c in zip(ids, cl):
             if hashlib.sha256(c.data).hexdigest() != manifest[f"c4_clip{i:02d}"]["clip_sha256"]:
                 return {"error": f"clip {i} differs from the golden clip (generator drift)"}
@@ -710,7 +733,7 @@ def c4_share_leg(device, steps, warmup, threads):
                 "us_per_step": round(ms * 1e3 / steps, 2), "pictures_per_step": int(st.pictures), "launches_per_step": int(st.launches),
                 "pictures_checked_against_reference_sha256": checked,
                 "what": "per-GPU share of BASELINE config 4 at 8 GPUs: clips 0, 8, ..., 56 (4 x 320x240 + 4 x 640x480, HVQM4 1.3 / 1.5), "
-                        "one 16-picture GOP each per step, descriptors resident; 128 pictures in 8 launches: launch-latency bound"}
+                        f"one 16-picture GOP each per step, descriptors resident; 128 pictures in {int(st.launches)} launches"}
     except Exception as e:
         return {"error": str(e)}
 
@@ -746,7 +769,7 @@ def sdk_leg(clip, seq):
 
 
 def pmc_traffic(args):
-    """HBM bytes per launch of hvq_recon_kernel from the committed rocprofv3 --pmc passes of this same default workload
+    """HBM bytes per launch of the reconstruction kernel (hvq_recon_inline_kernel; the PMC scripts match `hvq_recon`) from the committed rocprofv3 --pmc passes of this same default workload
     (tools/pmc_passes.sh -> tools/pmc_traffic.py -> profiles/*_pmc_traffic.json, read side calibrated by
     tools/ubench/pmc_calib.hip as MI355X_MICROARCH.md prescribes); None for any other workload.  PMC counters cannot be
     collected from inside the timed process, so this is evidence from a separate run of the same command."""
@@ -765,7 +788,7 @@ def pmc_traffic(args):
 
 
 def pmc_valu(args):
-    """vector-instruction bound of hvq_recon_kernel beside the HBM fraction (which stays the contract number): instructions per
+    """vector-instruction bound of the reconstruction kernel (hvq_recon_inline_kernel) beside the HBM fraction (which stays the contract number): instructions per
     wave and VALU busy fraction from the committed PMC passes of this default workload (tools/pmc_valu.py); None otherwise"""
     if pmc_traffic(args) is None:
         return None

@@ -2,8 +2,8 @@
  * examples/h4m_batch.c -- the throughput path from C: N concurrent streams of one .h4m file, entropy parse on the GPU,
  * batches of one GOP per stream, streamed, and EVERY picture brought back to the host in DISPLAY order:
  *
- *     hvq_submit_many_device(batch 0); hvq_flush_begin();
- *     loop: hvq_submit_many_device(batch k + 1);      copied and uploaded while batch k is parsed
+ *     hvq_submit_many_device_async(batch 0); hvq_flush_begin();
+ *     loop: hvq_submit_many_device_async(batch k + 1);     copied and uploaded while batch k is parsed
  *           hvq_flush_end(batch k);                   reconstruction launched
  *           hvq_flush_begin(batch k + 1);             parse queued
  *           hvq_read_pictures(batch k);               one synchronisation; the copies run beside the parse of batch k + 1
@@ -96,7 +96,8 @@ int main(int argc, char **argv)
             int m = 0;
             for (int k = at; k < at + per && k < npic; ++k)          /* picture-major, like a player would submit them */
                 for (int s = 0; s < nstreams; ++s) { b_sid[m] = sid[s]; b_ft[m] = types[k]; b_pic[m] = pics[k]; b_len[m] = lens[k]; ++m; }
-            if (gpu_parse) CHECK(hvq_submit_many_device(ctx, m, b_sid, b_ft, b_pic, b_len, NULL));
+            /* the pictures point into the clip, which outlives the loop: the deferred copy (a worker thread of the library) is safe */
+            if (gpu_parse) CHECK(hvq_submit_many_device_async(ctx, m, b_sid, b_ft, b_pic, b_len, NULL));
             else CHECK(hvq_submit_many(ctx, m, b_sid, b_ft, b_pic, b_len, 8, NULL));
         }
         if (b > 0) CHECK(hvq_flush_end(ctx));                     /* batch b - 1: reconstruction launched */

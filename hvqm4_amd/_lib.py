@@ -61,7 +61,7 @@ class HvqStats(C.Structure):
                 ("descriptor_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32),
                 ("parse_seconds", C.c_double), ("flags_or", C.c_uint32), ("gpu_parsed", C.c_uint32),
                 ("gpu_parse_ms", C.c_double), ("gpu_parse_retried", C.c_uint32), ("dropped", C.c_uint32),
-                ("pad0", C.c_uint32), ("queue_bytes", C.c_uint64)]
+                ("pad0", C.c_uint32), ("queue_bytes", C.c_uint64), ("copy_bytes", C.c_uint64), ("copy_seconds", C.c_double)]
 
 
 # every symbol include/hvqm4.h and include/hvqm4_amd.h declare: (restype, argtypes)
@@ -88,6 +88,12 @@ SYMBOLS = {
                                   C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int)]),
     "hvq_submit_many_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p),
                                          C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "hvq_submit_many_device_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p),
+                                               C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "hvq_arena_reserve": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "hvq_arena_stride": (C.c_size_t, [C.c_size_t]),
+    "hvq_submit_many_arena": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "hvq_flush": (C.c_int, [C.c_void_p]),
     "hvq_flush_begin": (C.c_int, [C.c_void_p]),
     "hvq_flush_end": (C.c_int, [C.c_void_p]),

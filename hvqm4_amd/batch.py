@@ -36,18 +36,43 @@ class Context:
         check(lib().hvq_submit_many(self._h, n, a_s, a_t, a_p, a_l, threads, a_o))
         return list(a_o)
 
-    def submit_many_device(self, sids, frame_types, pictures):
-        """queue raw bitstreams; flush() parses them on the GPU (no host entropy parse at all)"""
+    def submit_many_device(self, sids, frame_types, pictures, defer: bool = False):
+        """queue raw bitstreams; flush() parses them on the GPU (no host entropy parse at all).  defer=True
+        (hvq_submit_many_device_async): the copy into the pinned arena runs on a worker thread of the library and the call returns at
+        once; the pictures are kept alive here until the next flush_begin / sync joins the worker"""
         n = len(pictures)
         a_s = (C.c_int * n)(*sids)
         a_t = (C.c_int * n)(*frame_types)
         a_p = (C.c_char_p * n)(*pictures)
         a_l = (C.c_size_t * n)(*[len(p) for p in pictures])
         a_o = (C.c_int * n)()
-        check(lib().hvq_submit_many_device(self._h, n, a_s, a_t, a_p, a_l, a_o))
-        # while a batch is in flight the library copies the bitstreams on a worker thread and returns at once: the pictures (and
-        # the pointer array) must stay alive until the next flush_begin
-        self._submit_keep = (a_p, pictures)
+        fn = lib().hvq_submit_many_device_async if defer else lib().hvq_submit_many_device
+        check(fn(self._h, n, a_s, a_t, a_p, a_l, a_o))
+        if defer:
+            self._submit_keep = (a_p, pictures)
+        return list(a_o)
+
+    def arena_reserve(self, nbytes: int):
+        """hvq_arena_reserve: a writable uint8 view of `nbytes` of the pinned arena the library uploads from (zero-copy submit);
+        valid until submit_many_arena / the next flush_begin"""
+        import numpy as np
+        ptr = C.c_void_p()
+        check(lib().hvq_arena_reserve(self._h, nbytes, C.byref(ptr)))
+        return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr.value))
+
+    @staticmethod
+    def arena_stride(length: int) -> int:
+        return int(lib().hvq_arena_stride(length))
+
+    def submit_many_arena(self, sids, frame_types, offsets, lengths):
+        """queue pictures the caller wrote into the reservation itself (picture i at offsets[i], lengths[i] bytes): no copy"""
+        n = len(offsets)
+        a_s = (C.c_int * n)(*sids)
+        a_t = (C.c_int * n)(*frame_types)
+        a_f = (C.c_size_t * n)(*offsets)
+        a_l = (C.c_size_t * n)(*lengths)
+        a_o = (C.c_int * n)()
+        check(lib().hvq_submit_many_arena(self._h, n, a_s, a_t, a_f, a_l, a_o))
         return list(a_o)
 
     def flush(self) -> None:

@@ -133,7 +133,7 @@ typedef struct HvqPlaneRec {       /* per-plane part (32 bytes) */
     uint32_t pw_sub;               /* samples per row | ws << 16 | hs << 24 (subsampling shifts relative to luma) */
 } HvqPlaneRec;
 
-typedef struct HvqJob {
+typedef struct HvqJob {                /* 232 bytes */
     uint64_t ring;                 /* the stream's picture slots: every reference read is ring + 32-bit offset (one SGPR base) */
     uint32_t ref0_off;             /* "past"   (macroblock type 1): byte offset of its slot inside the ring */
     uint32_t ref1_off;             /* "future" (macroblock type 2) */
@@ -156,16 +156,19 @@ typedef struct HvqJob {
     uint32_t q_recs_off;           /* byte offset from `tq` of the picture's block records */
     uint32_t q_offs_off;           /* HVQ_F_SELF_REF pictures: byte offset from `tq` of the blocks' pool offsets (u32 per block), else 0 */
     uint32_t pad2[2];
+    uint32_t hb_magic[3];          /* per plane, hb = blocks per row: floor(2^32 / hb) + 1 (0 for hb = 1: the quotient is the index itself)
+                                      -- mulhi(b, magic) is floor(b / hb) or one more for b < 2^22 (scalar split of a wave's first block) */
+    uint32_t hb_magic16[3];        /* ceil(2^16 / hb): (t * magic16) >> 16 = floor(t / hb) exactly for t < 128 + hb, hb < 64 */
 } HvqJob;
 #define HVQ_JOB_KIND_SHIFT  16
 #define HVQ_JOB_UNK_SHIFT   20
 
 #if defined(__cplusplus)
 static_assert(sizeof(HvqPlaneRec) == 32, "HvqPlaneRec must be 32 bytes");
-static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
+static_assert(sizeof(HvqJob) == 232, "HvqJob must be 232 bytes");
 #else
 _Static_assert(sizeof(HvqPlaneRec) == 32, "HvqPlaneRec must be 32 bytes");
-_Static_assert(sizeof(HvqJob) == 208, "HvqJob must be 208 bytes");
+_Static_assert(sizeof(HvqJob) == 232, "HvqJob must be 232 bytes");
 #endif
 
 /*

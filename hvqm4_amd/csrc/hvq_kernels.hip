@@ -1251,27 +1251,53 @@ extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_bu
 
 
 /* ------------------------------------------------------------------------------------------------------
- * Reconstruction WITHOUT a queue-build pass (round 4): the workgroup derives its block records, item queue and pair list from
- * the picture's descriptors itself -- in registers and LDS, nothing of it touches HBM.  The separate hvq_tileq_kernel costs
- * 0.70 ms per 2048 dense pictures (it writes and the reconstruction re-reads ~0.8 GB) against 1.02 ms for the reconstruction it
- * feeds; derived in place the same work is a few hundred vector instructions per wave (profiles/r04*).
+ * Reconstruction WITHOUT a queue-build pass (round 4; front end rewritten in round 5): the workgroup derives its block records,
+ * item queue and pair list from the picture's descriptors itself -- in registers and LDS, nothing of it touches HBM.
+ *
+ * Round 4's kernel was bound by vector-instruction issue (569 VALU per wave of 64 blocks, 0.8 busy), and two thirds of those
+ * instructions were not pixel work but addressing and classification.  Round 5 keeps the phases and trims their cost:
+ *   - a wave's 64 blocks are CONSECUTIVE in raster order, so their (row, column) is the wave's first block split ONCE on the
+ *     scalar unit (multiply-high by a per-plane constant of the job record) plus the lane index with at most one wrap; every
+ *     descriptor address is a scalar base + a 32-bit lane offset (no 64-bit vector address arithmetic, no float division);
+ *   - the class of a block is computed by code specialised for the plane's context (I-picture luma, I-picture chroma, P/B
+ *     picture; chosen by a scalar branch), so the selects on picture-uniform conditions are gone;
+ *   - payload offset, intra pair count and MC-residual pair count come out of ONE packed wave scan instead of two;
+ *   - the pair list is written by a short unrolled sequence of predicated stores at ascending addresses instead of a loop
+ *     with a bounds test per entry;
+ *   - phase C re-derives its rows' coordinates the same way.
  *
  *   trip 1  the picture's job record (scalar)
  *   trip 2  per block: map entry with both horizontal neighbours (one unaligned 8-byte load), the vertical neighbours, the
- *           macroblock vector; per wave: its pool offset (wave_base); the picture's nest share
- *   then    class from the type byte (computed), block record (block_record), payload offset and pair count by wave scans,
- *           item and pair slots from two LDS counters (intra items fill the accumulator rows from the bottom, MC-residual items
- *           from the top: no total is needed before a slot can be handed out -- one barrier instead of two)
- *   trip 3  motion-compensation rows; the tile's whole pool range, coalesced, into LDS: basis dwords, literal blocks and the
- *           scalars of MC-residual blocks are read from there, so the pair phase does not start with an HBM miss of its own
+ *           macroblock vector; per wave: its pool offset (wave_base); by LDS-DMA the nest and the tile's range of the payload pool
+ *   then    class, block operands (MC source offset with the version's half-sample rule h4m:1327-1355, weighted-DC neighbours
+ *           h4m:1437-1454), one packed scan, item and pair slots from ONE packed 64-bit LDS atomic per wave (intra items fill the
+ *           accumulator rows from the bottom, MC-residual items from the top: no total is needed before a slot can be handed out)
+ *   trip 3  motion-compensation rows
  *   barrier 1, phase B1 (lane = pair: basis dword from LDS, decoded here, nest rows from LDS or window rows from the
- *   reference), barrier 2, phase B2 (lane = item), barrier 3, phase C exactly as in hvq_recon_kernel.
+ *   reference), barrier 2, phase B2 (lane = item), barrier 3, phase C (16-byte row segments, complete 256-byte runs).
  */
+template <int CTX>   /* 0 I-picture luma (kind = the whole type byte, h4m:1093), 1 I-picture chroma, 2 P/B picture */
+__device__ __forceinline__ void inl_classify(u32 T, bool valid, u32 &cls, u32 &nb, u32 &npay, bool &lit, bool &mc, bool &wdc, bool &flat)
+{
+    const u32 kind = CTX == 0 ? T : (T & 0xFu);
+    const bool k0 = kind == 0u, k6 = kind == 6u, k8 = kind == 8u;
+    if (CTX == 2) {
+        const bool inter = T & 0x60u, proc = T & 0x10u;
+        const bool c1 = valid && !inter && !(k0 | k6 | k8), c2 = valid && inter && !proc && !(k0 | k6);
+        lit = valid && k6 && !(inter && proc);
+        mc = valid && inter && (proc || !k6); wdc = valid && !inter && k0; flat = valid && !inter && k8;
+        cls = c1 ? 1u : c2 ? 2u : 0u;
+        nb = c1 ? kind : c2 ? kind - 1u : 0u;
+        npay = lit ? 4u : nb + (c2 ? 2u : 0u);
+    } else {
+        const bool c1 = valid && !(k0 | k6 | k8);
+        lit = valid && k6; mc = false; wdc = valid && k0; flat = valid && k8;
+        cls = c1 ? 1u : 0u; nb = c1 ? kind : 0u; npay = lit ? 4u : nb;
+    }
+}
 
-/* BAR0 (two tiles per workgroup): class table in LDS and a barrier behind trip 2.  One tile per workgroup: the class is computed and
- * the only early barrier stands where nothing is outstanding yet -- dense +1 %; with two tiles the computed classes cost more than the
- * barrier (natural, flat -3.5 %), profiles/r04_recon_steps.txt */
-#define HVQ_INL_BAR0(TPW) ((TPW) == 2)
+template <int N> struct InlCtx { static constexpr int value = N; };
+
 template <int ITEMS_CAP, int TPW>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
 void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 pool_cap HVQ_STAMP_ARG)
@@ -1284,12 +1310,11 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     __shared__ u32 s_item1[ITEMS_CAP];   /* pool index of the block's payload */
     __shared__ u32 s_item2[ITEMS_CAP];   /* MC-residual items: ring offset of the origin of the 70x38 window (h4m:1865-1868), unclamped part + reference */
     __shared__ unsigned long long s_ctr64;   /* intra items | MC-residual items << 10 | intra pairs << 20 | MC-residual pairs << 42 handed out */
-    __shared__ u32 s_class[HVQ_INL_BAR0(TPW) ? 256 : 1];   /* block class by type byte for this plane's context (hvq_type_class) */
     u32 *const s_pair = s_dyn;
     u32 *const s_pool = s_dyn + pair_cap;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const u32 lane = (u32)tid & 63u;
     STAMP(0, 0);
     const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
     const u32 wg = blockIdx.y;
@@ -1303,11 +1328,13 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 #pragma unroll
     for (int i = 0; i < 18; ++i) cw[i] = CW[i];
     u32 wb_lo = CW[46], wb_hi = CW[47], q_offs_off = CW[49];
+    u32 mg0 = CW[52], mg1 = CW[53], mg2 = CW[54], ms0 = CW[55], ms1 = CW[56], ms2 = CW[57];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { HVQ_PIN(w0[i]); HVQ_PIN(w1[i]); HVQ_PIN(w2[i]); }
 #pragma unroll
     for (int i = 0; i < 18; ++i) HVQ_PIN(cw[i]);
     HVQ_PIN(wb_lo); HVQ_PIN(wb_hi); HVQ_PIN(q_offs_off);
+    HVQ_PIN(mg0); HVQ_PIN(mg1); HVQ_PIN(mg2); HVQ_PIN(ms0); HVQ_PIN(ms1); HVQ_PIN(ms2);
     const u32 total_tiles = cw[17];
     const u32 n0 = w1[5] - w0[5], n1 = w2[5] - w1[5], n2 = total_tiles - w2[5];
     const u32 pf1 = (n0 + TPW - 1) / TPW, pf2 = pf1 + (n1 + TPW - 1) / TPW, pend = pf2 + (n2 + TPW - 1) / TPW;
@@ -1316,6 +1343,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     u32 w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = p == 0 ? w0[i] : p == 1 ? w1[i] : w2[i];
+    const u32 magic = p == 0 ? mg0 : p == 1 ? mg1 : mg2, magic16 = p == 0 ? ms0 : p == 1 ? ms1 : ms2;
     const u32 hbvb = w[6], pw_sub = w[7], tile_first = w[5];
     const u32 nplane_tiles = p == 0 ? n0 : p == 1 ? n1 : n2;
     const u32 pairw = wg - (p == 0 ? 0u : p == 1 ? pf1 : pf2);
@@ -1323,20 +1351,19 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const int ntl = (int)min((u32)TPW, nplane_tiles - (u32)TPW * pairw);
     const uint64_t map_a = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
     const uint64_t dst_a = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-    const i32 plane_off = (i32)w[4];
-    const i32 hb = (i32)(hbvb & 0xFFFFu);
+    const u32 plane_off = w[4];
+    const u32 hb = hbvb & 0xFFFFu;
     const u32 flags = cw[13];
     const u32 pic_kind = (flags >> HVQ_JOB_KIND_SHIFT) & 3u;
     const i32 unk = (i32)((flags >> HVQ_JOB_UNK_SHIFT) & 31u);
     const bool is_pb = pic_kind != HVQ_PIC_I;
     const bool landscape = flags & HVQ_F_LANDSCAPE;
     const bool is15 = flags & HVQ_F_IS15;
-    const u32 nblocks = (u32)hb * (hbvb >> 16);
+    const u32 nblocks = hb * (hbvb >> 16);
     const u32 b0 = (u32)TPW * pairw * HVQ_TILE_BLOCKS;
-    const i32 ws = (i32)((pw_sub >> 16) & 0xFFu), hs = (i32)(pw_sub >> 24);
-    const i32 pw = (i32)(pw_sub & 0xFFFFu);
-    const i32 mstride = hb + 2;
-    const float rhb = 1.0f / (float)hb;
+    const u32 ws = (pw_sub >> 16) & 0xFFu, hs = pw_sub >> 24;
+    const u32 pw = pw_sub & 0xFFFFu;
+    const u32 mstride = hb + 2u;
     const GLB uint8_t *map = (const GLB uint8_t *)map_a;
     const GLB uint8_t *ring = (const GLB uint8_t *)HVQ_W64(0);
     const u32 ref0_off = cw[2], ref1_off = cw[3];
@@ -1347,176 +1374,72 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const GLB u32 *__restrict__ wave_base = (const GLB u32 *)((uint64_t)wb_lo | ((uint64_t)wb_hi << 32));
     GLB uint8_t *plane = (GLB uint8_t *)dst_a;
     const i32 slot = (i32)cw[12];
-    const i32 lw = (i32)cw[14];
-    const i32 mcb_w = (i32)cw[15];
+    const u32 lw = cw[14];
+    const u32 mcb_w = cw[15];
     const u32 pool_dwords = cw[16];
     const u32 wave = (u32)__builtin_amdgcn_readfirstlane(tid >> 6);
     STAMP(1, 0);                                                               /* job record here */
-    if constexpr (!HVQ_INL_BAR0(TPW)) {
     /* the slot counter is zero before any wave asks it: a barrier HERE, where no vector-memory operation is outstanding yet, instead
      * of one behind trip 2 that would hold every wave until the slowest wave's loads have landed */
     if (tid == 0) s_ctr64 = 0;
     __syncthreads();
-    }
 
-    /* ---- trip 2: the blocks' descriptors into registers; the tile range of the pool, the nest and the class table straight
-     * into LDS (LDS-DMA: no registers, and barrier 0 below waits for them with the rest) ---- */
-    if (HVQ_INL_BAR0(TPW) && tid == 0) s_ctr64 = 0;
+    /* ---- trip 2: the blocks' descriptors into registers; the tile range of the pool and the nest straight into LDS (LDS-DMA) ---- */
     u32 plo = wave_base[tile0 * HVQ_NW];
     u32 phi = tile0 + (u32)ntl < total_tiles ? wave_base[(tile0 + (u32)ntl) * HVQ_NW] : pool_dwords;
     u32 wbase[TPW];
 #pragma unroll
     for (int h = 0; h < TPW; ++h) wbase[h] = h < ntl ? wave_base[(tile0 + (u32)h) * HVQ_NW + wave] : 0u;
     bool valid[TPW];
-    i32 bx[TPW], by[TPW];
+    u32 bx[TPW], by[TPW], wby0[TPW], wbx0[TPW];
     uint64_t row8[TPW];
     u32 nt[TPW], nbt[TPW], mvw[TPW];
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
-        const u32 b = b0 + (u32)(h * HVQ_TILE_BLOCKS + tid);
-        valid[h] = h < ntl && b < nblocks;
-        block_coords(valid[h] ? b : 0u, hb, rhb, bx[h], by[h]);
-        const GLB uint8_t *ent = map + 2 * ((by[h] + 1) * mstride + bx[h] + 1);
-        row8[h] = *(const GLB u64u *)(ent - 2);                       /* left, own, right entries (the map has a border) */
-        nt[h] = *(const GLB uint16_t *)(ent - 2 * mstride); nbt[h] = *(const GLB uint16_t *)(ent + 2 * mstride);
+        /* A wave's 64 blocks are consecutive in raster order: the first one is split into (row, column) on the SCALAR unit --
+         * multiply-high by floor(2^32 / hb) + 1, which is the quotient or one more (block index < 2^22), put right by one compare --
+         * and a lane adds its index, wrapping into the next row(s): at most once in rows of 64 blocks and more; shorter rows
+         * (t < 128) divide exactly by a 16-bit reciprocal.  No per-lane division, and the map addresses below are a scalar base
+         * plus a 32-bit lane offset. */
+        const u32 bw = b0 + (u32)(h * HVQ_TILE_BLOCKS) + wave * 64u;          /* uniform */
+        const bool livew = h < ntl && bw < nblocks;
+        valid[h] = h < ntl && bw + lane < nblocks;
+        const u32 bws = livew ? bw : 0u;
+        u32 by0 = __umulhi(bws, magic);
+        if ((i32)(bws - by0 * hb) < 0) by0 -= 1u;
+        const u32 bx0 = bws - by0 * hb;
+        const u32 l = valid[h] ? lane : 0u;
+        const u32 t = bx0 + l;
+        u32 q;
+        if (hb >= 64u) q = t >= hb ? 1u : 0u;
+        else q = __umul24(t, magic16) >> 16;
+        bx[h] = t - __umul24(q, hb); by[h] = by0 + q;
+        wby0[h] = by0; wbx0[h] = bx0;
+        /* entry (by, bx) of the bordered map = b + 2 by + hb + 3 */
+        const GLB uint8_t *mw = map + 2u * (size_t)(bws + 2u * by0 + hb + 3u);
+        const u32 vo2 = 2u * (l + 2u * q);
+        row8[h] = *(const GLB u64u *)((mw - 2) + vo2);                         /* left, own, right entries (the map has a border) */
+        /* timing experiments (wrong pictures): 41 no vertical-neighbour loads, 42 neither those nor the vector load, 43 = 42 and no nest / pool staging */
+        if (HVQ_ABL >= 41 && HVQ_ABL <= 43) { nt[h] = (u32)row8[h] & 0xFFFFu; nbt[h] = (u32)(row8[h] >> 32) & 0xFFFFu; }
+        else { nt[h] = *(const GLB uint16_t *)((mw - 2u * (size_t)mstride) + vo2); nbt[h] = *(const GLB uint16_t *)((mw + 2u * (size_t)mstride) + vo2); }
         mvw[h] = 0;
-        if (is_pb) mvw[h] = mvs[(by[h] >> (1 - hs)) * mcb_w + (bx[h] >> (1 - ws))];
+        if (HVQ_ABL == 42 || HVQ_ABL == 43) { if (is_pb) { const u32 hh = ((bx[h] >> (1u - ws)) * 73u + (by[h] >> (1u - hs)) * 151u) * 2654435761u; mvw[h] = (((hh >> 8) & 1023u) + 16u) | ((((hh >> 18) & 511u) + 64u) << 16); } }
+        else if (is_pb) mvw[h] = *(const GLB u32 *)((const GLB uint8_t *)mvs + 4u * (__umul24(by[h] >> (1u - hs), mcb_w) + (bx[h] >> (1u - ws))));
     }
     typedef __attribute__((address_space(3))) u32 lds_u32;
-    if constexpr (HVQ_INL_BAR0(TPW)) {   /* block classes by type byte for this plane's context (hvq_type_class): one LDS read per block instead of ~40 selects */
-        const GLB u32 *tclass = (const GLB u32 *)g_type_class + (is_pb ? 512 : p == 0 ? 0 : 256);
-#pragma unroll
-        for (int r0 = 0; r0 < 256; r0 += HVQ_WG)
-            __builtin_amdgcn_global_load_lds(tclass + r0 + tid, (lds_u32 *)(s_class + r0 + wave * 64u), 4, 0, 0);
-    }
-    const bool has_nest = (HVQ_W64(10) != 0);
+    const bool has_nest = (HVQ_W64(10) != 0) && HVQ_ABL != 43;
     if (has_nest) {
 #pragma unroll
         for (int r0 = 0; r0 < (HVQ_NESTP_BYTES + 3) / 4; r0 += HVQ_WG)
             if (r0 + tid < (HVQ_NESTP_BYTES + 3) / 4)
-                __builtin_amdgcn_global_load_lds(nestp + r0 + tid, (lds_u32 *)((u32 *)s_nest + r0 + wave * 64u), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((const GLB u32 *)((const GLB uint8_t *)nestp + 4u * (u32)(r0 + tid)), (lds_u32 *)((u32 *)s_nest + r0 + wave * 64u), 4, 0, 0);
     }
     phi = max(phi, plo);
-    const u32 nst = min(phi - plo, pool_cap);                          /* staged dwords */
-    for (u32 r0 = 0; r0 < nst; r0 += HVQ_WG)
-        if (r0 + (u32)tid < nst) __builtin_amdgcn_global_load_lds(pool + plo + r0 + (u32)tid, (lds_u32 *)(s_pool + r0 + wave * 64u), 4, 0, 0);
-    if constexpr (HVQ_INL_BAR0(TPW)) __syncthreads();   /* barrier 0: trip 2 has landed; the slot counters are zero before any wave asks them */
-
-    STAMP(2, 0);                                                               /* trip 2 issued (the stamp itself waits for the scalar loads) */
-    STAMP(3, 1);                                                               /* ... and landed (stamped builds wait here) */
-    /* ---- classes, records, scans ---- */
-    u32x2 brec[TPW];
-    u32 off[TPW], cls[TPW], nb[TPW], e16v[TPW], pincl[TPW], pincl2[TPW];
-    bool lit[TPW];
-    unsigned long long m1[TPW], m2[TPW];
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        const u32 e16 = (u32)(row8[h] >> 16) & 0xFFFFu;
-        e16v[h] = e16;
-        u32 npay;
-        bool mcb, wdcb, flatb;
-        if constexpr (HVQ_INL_BAR0(TPW)) {
-            const u32 tc = valid[h] ? s_class[e16 >> 8] : 0u;
-            npay = HVQ_TC_NPAY(tc); cls[h] = HVQ_TC_CLS(tc); nb[h] = HVQ_TC_NB(tc); lit[h] = tc & HVQ_TC_LIT;
-            mcb = tc & HVQ_TC_MC; wdcb = tc & HVQ_TC_WDC; flatb = valid[h] && cls[h] == 0 && !lit[h];
-        } else {
-            /* hvq_type_class, computed without the detour through its packed word (a table would need a barrier or a dependent load) */
-            const u32 T = e16 >> 8;
-            const u32 kind = (!is_pb && p == 0) ? T : (T & 0xFu);                  /* I-picture luma: the whole byte (h4m:1093) */
-            const bool inter = is_pb && (T & 0x60u), proc = T & 0x10u;
-            const bool k0 = kind == 0u, k6 = kind == 6u, k8 = kind == 8u;
-            const bool c1 = valid[h] && !inter && !(k0 | k6 | k8), c2 = valid[h] && inter && !proc && !(k0 | k6);
-            lit[h] = valid[h] && k6 && !(inter && proc);
-            mcb = valid[h] && inter && (proc || !k6); wdcb = valid[h] && !inter && k0; flatb = valid[h] && !inter && k8;
-            cls[h] = c1 ? 1u : c2 ? 2u : 0u;
-            nb[h] = c1 ? kind : c2 ? kind - 1u : 0u;
-            npay = lit[h] ? 4u : c1 ? kind : c2 ? kind + 1u : 0u;
-        }
-        if (HVQ_ABL == 36 || HVQ_ABL == 37) { cls[h] = 0; nb[h] = 0; }          /* timing experiments: no queue derivation, no AOT work at all */
-        const BlkSrc src = { e16, nt[h], nbt[h], (u32)row8[h] & 0xFFFFu, (u32)(row8[h] >> 32) & 0xFFFFu, mvw[h] };
-        brec[h] = block_record_b(mcb, wdcb, flatb, is_pb, is15, src, bx[h], by[h], ws, hs, pw, plane_off, slot, ref0_off, ref1_off);
-        off[h] = wbase[h] + wave_incl_scan(npay) - npay;
-        m1[h] = __ballot(cls[h] == 1); m2[h] = __ballot(cls[h] == 2);
-        /* pairs of intra items and of MC-residual items are kept apart (intra pairs fill the list from the bottom, the others from
-         * the top): a wave of the pair phase then mostly runs ONE of the two gathers instead of both.  One scan for both counts:
-         * intra bases in the low half, MC-residual bases in the high half (a wave's sum stays below 2^16: 64 blocks x 255 bases) */
-        {
-            const u32 packed = (m1[h] | m2[h]) ? wave_incl_scan(cls[h] == 1 ? nb[h] : cls[h] == 2 ? nb[h] << 16 : 0u) : 0u;
-            pincl[h] = packed & 0xFFFFu; pincl2[h] = packed >> 16;
-        }
-    }
-    if (q_offs_off) {                                                   /* self-referencing P picture: hvq_selfref_kernel wants the pool offsets */
-#pragma unroll
-        for (int h = 0; h < TPW; ++h)
-            if (h < ntl) ((GLB u32 *)(qb + q_offs_off))[(size_t)(tile0 + (u32)h) * HVQ_TILE_BLOCKS + (u32)tid] = off[h];
-    }
-
-    STAMP(4, 0);                                                               /* classes, records, scans */
-    /* ---- trip 3: motion-compensation rows ---- */
-    McRows rows[TPW];
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        if (((brec[h].y >> 8) & 3u) == HVQ_BR_MC) {
-            const u32 vo = brec[h].x;
-            /* timing experiments (tools/variant.sh <name> -DHVQ_ABL=n; wrong pictures): 31 no phase-A arithmetic, 32 no item epilogues,
-             * 33 no pair work, 34 no motion-compensation row loads, 35 no stores */
-            if (HVQ_ABL == 34 || HVQ_ABL == 37) {
-#pragma unroll
-                for (int y = 0; y < 5; ++y) rows[h].q[y] = (uint64_t)vo * 0x0101010101ull + (uint64_t)y;
-                continue;
-            }
-#pragma unroll
-            for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(y * pw)));
-            rows[h].q[4] = 0;
-            if (brec[h].y & 0x800u) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(4 * pw)));
-        }
-    }
-
-    /* ---- slots: one lane per wave asks the counters (intra items upwards, MC-residual items downwards, pairs) ---- */
-    u32 slotq[TPW], pstart[TPW];
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        const u32 c1 = (u32)__popcll(m1[h]), c2 = (u32)__popcll(m2[h]);
-        const u32 np1 = (u32)__builtin_amdgcn_readlane((int)pincl[h], 63), np2 = (u32)__builtin_amdgcn_readlane((int)pincl2[h], 63);
-        /* ONE returning LDS atomic per wave and tile hands out all four ranges: intra items [9:0], MC-residual items [19:10],
-         * intra pairs [41:20], MC-residual pairs [63:42] */
-        u32 b1 = 0, b2 = 0, bp1 = 0, bp2 = 0;
-        if (c1 | c2) {
-            unsigned long long got = 0;
-            if (lane == 0)
-                got = __hip_atomic_fetch_add(&s_ctr64, (unsigned long long)c1 | ((unsigned long long)c2 << 10) | ((unsigned long long)np1 << 20) | ((unsigned long long)np2 << 42),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const u32 glo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)got), ghi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(got >> 32));
-            b1 = glo & 1023u; b2 = (glo >> 10) & 1023u;
-            bp1 = (glo >> 20) | ((ghi & 1023u) << 12); bp2 = ghi >> 10;
-        }
-        slotq[h] = cls[h] == 1 ? b1 + lanes_below(m1[h]) : (u32)ITEMS_CAP - 1u - (b2 + lanes_below(m2[h]));
-        pstart[h] = cls[h] == 1 ? bp1 + pincl[h] - nb[h] : bp2 + pincl2[h] - nb[h];      /* MC-residual pairs: counted from the top */
-    }
-    /* accumulators zeroed: 16 * ITEMS_CAP dwords, ITEMS_CAP a multiple of 32 */
+    const u32 nst = HVQ_ABL == 43 ? 0u : min(phi - plo, pool_cap);                          /* staged dwords */
     {
-        typedef u32 u32x4z __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (u32 i = (u32)tid; i < 4u * ITEMS_CAP; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
-    }
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        if (cls[h] && slotq[h] < (u32)ITEMS_CAP) {
-            s_item0[slotq[h]] = (u32)(h * HVQ_WG + tid) | (e16v[h] << 10);
-            s_item1[slotq[h]] = off[h];
-            if (cls[h] == 2) {
-                const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFF), ry = (i32)(int16_t)(mvw[h] >> 16);
-                s_item2[slotq[h]] = (u32)(landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16);   /* h4m:1865-1868 */
-            }
-            const u32 bidx = off[h] + (cls[h] == 2 ? 2u : 0u);
-            u32 ent = slotq[h] | (bidx << 9);
-            /* list index of the item's first pair and the step to its next one; an index beyond the list wraps to a huge value */
-            u32 pidx = cls[h] == 1 ? pstart[h] : pair_cap - 1u - pstart[h];
-            const u32 pstep = cls[h] == 1 ? 1u : 0xFFFFFFFFu;
-#pragma clang loop unroll(disable) vectorize(disable)
-            for (u32 k = 0; k < nb[h]; ++k, ent += 1u << 9, pidx += pstep)
-                if (pidx < pair_cap) s_pair[pidx] = ent;
-        }
+        const GLB uint8_t *pool_lo = (const GLB uint8_t *)(pool + plo);
+        for (u32 r0 = 0; r0 < nst; r0 += HVQ_WG)
+            if (r0 + (u32)tid < nst) __builtin_amdgcn_global_load_lds((const GLB u32 *)(pool_lo + 4u * (r0 + (u32)tid)), (lds_u32 *)(s_pool + r0 + wave * 64u), 4, 0, 0);
     }
     const bool all_staged = phi - plo <= pool_cap;                             /* uniform, and true unless a tile's payload exceeds the launch's LDS share */
     auto pool_at = [&](u32 idx) -> u32 {                                       /* a dword of the payload pool: staged, or (beyond the staging cap) from HBM */
@@ -1525,43 +1448,193 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         return j < nst ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
     };
 
-    STAMP(5, 0);                                                               /* rows requested, slots, items and pairs in LDS */
-    STAMP(6, 1);                                                               /* rows landed */
-    /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
+    STAMP(2, 0);                                                               /* trip 2 issued (the stamp itself waits for the scalar loads) */
+    STAMP(3, 1);                                                               /* ... and landed (stamped builds wait here) */
+    /* Everything from here to barrier 1 exists three times, once per context of the plane (I-picture luma, I-picture chroma, P/B
+     * picture), chosen by ONE scalar branch: no select on a picture-uniform condition is executed per lane, the I-picture copies
+     * contain no motion compensation at all, and the per-lane predicates never cross a merge point (where the compiler would park
+     * them in vector registers). */
+    auto front = [&](auto ctxc) {
+        constexpr int CTX = decltype(ctxc)::value;
+        u32 off[TPW], cls[TPW], nb[TPW], e16v[TPW], w0v[TPW], pinI[TPW], pinM[TPW];
+        bool lit[TPW], mcb[TPW], wdcb[TPW], flatb[TPW], hxb[TPW], hyb[TPW];
+        unsigned long long m1[TPW], m2[TPW];
+        McRows rows[TPW];
 #pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        const u32 act = (brec[h].y >> 8) & 3u;
-        const i32 V = brec[h].y & 0xFF;
-        Blk o;
-        if (HVQ_ABL == 31 && (act == HVQ_BR_MC || act == HVQ_BR_WDC)) {
-            o.r[0] = (u32)rows[h].q[0] ^ brec[h].x; o.r[1] = (u32)rows[h].q[1]; o.r[2] = (u32)rows[h].q[2]; o.r[3] = (u32)(rows[h].q[3] ^ rows[h].q[4]);
-        } else if (act == HVQ_BR_MC) {
-            o = mc_filter(rows[h], (brec[h].y >> 10) & 1, (brec[h].y >> 11) & 1);
-        } else if (act == HVQ_BR_WDC) {
-            const u32 nb4 = brec[h].x;
-            o = weight_block(V, (i32)(nb4 & 0xFF), (i32)((nb4 >> 8) & 0xFF), (i32)((nb4 >> 16) & 0xFF), (i32)(nb4 >> 24));
-        } else if (act == HVQ_BR_FLAT) {
-            const u32 v = (u32)V * 0x01010101u;
-            o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
-        } else if (HVQ_INL_BAR0(TPW) && lit[h]) {                               /* literal block (h4m:543-549): 16 samples from the staged pool */
-#pragma unroll
-            for (int y = 0; y < 4; ++y) o.r[y] = pool_at(off[h] + (u32)y);
-        } else continue;
-#pragma unroll
-        for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
-    }
-    STAMP(7, 0);                                                               /* phase A */
-    __syncthreads();                                                           /* barrier 1: queues, zeroed accumulators, staged pool and nest */
-    STAMP(8, 0);
-    if constexpr (!HVQ_INL_BAR0(TPW)) {
-    /* literal blocks (h4m:543-549): the owner copies its 16 samples from the staged pool (complete only now: other waves staged parts of it) */
-#pragma unroll
-    for (int h = 0; h < TPW; ++h)
-        if (lit[h]) {
-#pragma unroll
-            for (int y = 0; y < 4; ++y) s_out[h][y][tid] = pool_at(off[h] + (u32)y);
+        for (int h = 0; h < TPW; ++h) {
+            const u32 e16 = (u32)(row8[h] >> 16) & 0xFFFFu;
+            const u32 T = e16 >> 8, V = e16 & 0xFFu;
+            e16v[h] = e16;
+            u32 npay;
+            inl_classify<CTX>(T, valid[h], cls[h], nb[h], npay, lit[h], mcb[h], wdcb[h], flatb[h]);
+            if (HVQ_ABL == 36 || HVQ_ABL == 37) { cls[h] = 0; nb[h] = 0; }          /* timing experiments: no queue derivation, no AOT work at all */
+            w0v[h] = 0; hxb[h] = false; hyb[h] = false;
+            if (CTX == 2) {
+                /* plain MC and the MC part of MC-residual blocks (h4m:1327-1355): half-sample rule per version (h4m:1337-1343);
+                 * computed for every lane (a few operations), used by the motion-compensated ones */
+                const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFFu), ry = (i32)mvw[h] >> 16;
+                const u32 roff = (T & 0x60u) == 0x20u ? ref0_off : ref1_off;
+                const u32 hsx = is15 ? ws : 0u, hsy = is15 ? hs : 0u;                /* 1.5: the plane's own vector decides, 1.3: the luma vector */
+                hxb[h] = (rx >> hsx) & 1; hyb[h] = (ry >> hsy) & 1;
+                const i32 rowi = (ry >> (hs + 1u)) + (i32)((by[h] & (1u - hs)) << 2);   /* |rowi| < 2^15, pw < 2^14: a 24-bit multiply is exact */
+                const i32 coli = (rx >> (ws + 1u)) + (i32)((bx[h] & (1u - ws)) << 2) + (i32)plane_off;
+                i32 a = __mul24(rowi, (i32)pw) + coli;
+                /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
+                const i32 hi3 = slot - 8 - 3 * (i32)pw, hi4 = hi3 - (i32)pw;
+                a = clampi(a, 0, hyb[h] ? hi4 : hi3);
+                if (mcb[h]) w0v[h] = roff + (u32)a;
+            }
+            if (wdcb[h]) {
+                /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
+                 * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
+                const u32 nlf = (u32)row8[h] & 0xFFFFu, nr = (u32)(row8[h] >> 32) & 0xFFFFu;
+                const u32 Tt = (nt[h] & 0x7700u) ? V : (nt[h] & 0xFFu);
+                const u32 Bb = (nbt[h] & 0x7700u) ? V : (nbt[h] & 0xFFu);
+                const u32 Rr = (nr & 0x7700u) ? V : (nr & 0xFFu);
+                const bool lexp = CTX == 2 ? !(nlf & 0x7700u) : ((nlf >> 8) & ~8u) == 0u;
+                const u32 Ll = lexp ? (nlf & 0xFFu) : V;
+                w0v[h] = Tt | (Bb << 8) | (Ll << 16) | (Rr << 24);
+            }
+            /* ONE scan: payload dwords [10:0], intra bases [20:11], MC-residual bases [30:21] (P/B: kinds <= 15, a wave's sums stay
+             * below 2^10 / 2^11); I pictures have no MC-residual blocks and kinds up to 255: payload [15:0], intra bases [31:16] */
+            m1[h] = __ballot(cls[h] == 1); m2[h] = CTX == 2 ? __ballot(cls[h] == 2) : 0ull;
+            if (CTX == 2) {
+                const u32 inc = wave_incl_scan(npay + (nb[h] << (cls[h] == 1 ? 11 : 21)));
+                off[h] = wbase[h] + (inc & 0x7FFu) - npay;
+                pinI[h] = (inc >> 11) & 0x3FFu; pinM[h] = inc >> 21;
+            } else {
+                const u32 inc = wave_incl_scan(npay + (nb[h] << 16));
+                off[h] = wbase[h] + (inc & 0xFFFFu) - npay;
+                pinI[h] = inc >> 16; pinM[h] = 0;
+            }
         }
-    }
+        STAMP(4, 0);                                                           /* classes, operands, scan */
+        /* ---- trip 3: motion-compensation rows ---- */
+        if (CTX == 2) {
+#pragma unroll
+            for (int h = 0; h < TPW; ++h) {
+                if (mcb[h]) {
+                    const u32 vo = w0v[h];
+                    /* timing experiments (tools/variant.sh <name> -DHVQ_ABL=n; wrong pictures): 31 no phase-A arithmetic, 32 no item epilogues,
+                     * 33 no pair work, 34 no motion-compensation row loads, 35 no stores */
+                    if (HVQ_ABL == 34 || HVQ_ABL == 37) {
+#pragma unroll
+                        for (int y = 0; y < 5; ++y) rows[h].q[y] = (uint64_t)vo * 0x0101010101ull + (uint64_t)y;
+                        continue;
+                    }
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)y * pw));
+                    rows[h].q[4] = 0;
+                    if (hyb[h]) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + 4u * pw));
+                }
+            }
+        }
+        if (q_offs_off) {                                               /* self-referencing P picture: hvq_selfref_kernel wants the pool offsets */
+#pragma unroll
+            for (int h = 0; h < TPW; ++h)
+                if (h < ntl) ((GLB u32 *)(qb + q_offs_off))[(size_t)(tile0 + (u32)h) * HVQ_TILE_BLOCKS + (u32)tid] = off[h];
+        }
+
+        /* ---- slots: one lane per wave asks the counters (intra items upwards, MC-residual items downwards, pairs) ---- */
+        u32 slotq[TPW], pstart[TPW];
+#pragma unroll
+        for (int h = 0; h < TPW; ++h) {
+            const u32 c1 = (u32)__popcll(m1[h]), c2 = (u32)__popcll(m2[h]);
+            const u32 np1 = (u32)__builtin_amdgcn_readlane((int)pinI[h], 63), np2 = CTX == 2 ? (u32)__builtin_amdgcn_readlane((int)pinM[h], 63) : 0u;
+            /* ONE returning LDS atomic per wave and tile hands out all four ranges: intra items [9:0], MC-residual items [19:10],
+             * intra pairs [41:20], MC-residual pairs [63:42] */
+            u32 b1 = 0, b2 = 0, bp1 = 0, bp2 = 0;
+            if (c1 | c2) {
+                unsigned long long got = 0;
+                if (lane == 0)
+                    got = __hip_atomic_fetch_add(&s_ctr64, (unsigned long long)c1 | ((unsigned long long)c2 << 10) | ((unsigned long long)np1 << 20) | ((unsigned long long)np2 << 42),
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const u32 glo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)got), ghi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(got >> 32));
+                b1 = glo & 1023u; b2 = (glo >> 10) & 1023u;
+                bp1 = (glo >> 20) | ((ghi & 1023u) << 12); bp2 = ghi >> 10;
+            }
+            if (CTX == 2) {
+                slotq[h] = cls[h] == 1 ? b1 + lanes_below(m1[h]) : (u32)ITEMS_CAP - 1u - (b2 + lanes_below(m2[h]));
+                pstart[h] = cls[h] == 1 ? bp1 + pinI[h] - nb[h] : bp2 + pinM[h] - nb[h];      /* MC-residual pairs: counted from the top */
+            } else {
+                slotq[h] = b1 + lanes_below(m1[h]);
+                pstart[h] = bp1 + pinI[h] - nb[h];
+            }
+        }
+        /* accumulators zeroed: 16 * ITEMS_CAP dwords, ITEMS_CAP a multiple of 32 */
+        {
+            typedef u32 u32x4z __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (u32 i = (u32)tid; i < 4u * ITEMS_CAP; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
+        }
+#pragma unroll
+        for (int h = 0; h < TPW; ++h) {
+            if (cls[h] && slotq[h] < (u32)ITEMS_CAP) {
+                s_item0[slotq[h]] = (u32)(h * HVQ_WG + tid) | (e16v[h] << 10);
+                s_item1[slotq[h]] = off[h];
+                const bool up = CTX != 2 || cls[h] == 1;
+                if (!up) {
+                    /* origin of the 70x38 window (h4m:1865-1868): vector / 2 truncated towards zero, minus (32, 16) or (16, 32) samples */
+                    const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFFu), ry = (i32)mvw[h] >> 16;
+                    const i32 rx2 = (rx - (rx >> 31)) >> 1, ry2 = (ry - (ry >> 31)) >> 1;
+                    const i32 corner = landscape ? 16 * (i32)lw + 32 : 32 * (i32)lw + 16;
+                    s_item2[slotq[h]] = (u32)(__mul24(ry2, (i32)lw) + rx2 - corner);
+                }
+                /* the item's pairs, at ASCENDING list positions: intra pairs lie at pstart .. pstart + nb - 1 in basis order, MC-residual
+                 * pairs (counted from the top of the list) at pair_cap - pstart - nb .. in reverse basis order.  Entries beyond the list
+                 * (more pairs than the launch reserved: the tile turns serial and the list is not read) are cut off by the count. */
+                const u32 ent0 = slotq[h] | ((off[h] + (up ? 0u : 2u)) << 9);
+                const u32 room = max(pair_cap, pstart[h]) - pstart[h];         /* saturating */
+                const u32 kmax = min(nb[h], room);
+                const u32 pos = up ? pstart[h] : room - kmax;
+                const u32 val = up ? ent0 : ent0 + (kmax << 9) - 512u;
+                const u32 dv = up ? 512u : 0u - 512u;
+                u32 *const sp = s_pair + pos;
+#pragma unroll
+                for (u32 j = 0; j < 5; ++j)
+                    if (j < kmax) sp[j] = val + j * dv;
+                if (kmax > 5u) {
+#pragma clang loop unroll(disable) vectorize(disable)
+                    for (u32 j = 5; j < kmax; ++j) sp[j] = val + j * dv;
+                }
+            }
+        }
+
+        STAMP(5, 0);                                                           /* rows requested, slots, items and pairs in LDS */
+        STAMP(6, 1);                                                           /* rows landed */
+        /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
+#pragma unroll
+        for (int h = 0; h < TPW; ++h) {
+            const i32 V = (i32)(e16v[h] & 0xFFu);
+            Blk o;
+            if (HVQ_ABL == 31 && (mcb[h] || wdcb[h])) {
+                o.r[0] = (u32)rows[h].q[0] ^ w0v[h]; o.r[1] = (u32)rows[h].q[1]; o.r[2] = (u32)rows[h].q[2]; o.r[3] = (u32)(rows[h].q[3] ^ rows[h].q[4]);
+            } else if (CTX == 2 && mcb[h]) {
+                o = mc_filter(rows[h], hxb[h], hyb[h]);
+            } else if (wdcb[h]) {
+                const u32 nb4 = w0v[h];
+                o = weight_block(V, (i32)(nb4 & 0xFF), (i32)((nb4 >> 8) & 0xFF), (i32)((nb4 >> 16) & 0xFF), (i32)(nb4 >> 24));
+            } else if (flatb[h]) {
+                const u32 v = (u32)V * 0x01010101u;
+                o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
+            } else continue;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
+        }
+        STAMP(7, 0);                                                           /* phase A */
+        __syncthreads();                                                       /* barrier 1: queues, zeroed accumulators, staged pool and nest */
+        STAMP(8, 0);
+        /* literal blocks (h4m:543-549): the owner copies its 16 samples from the staged pool (complete only now: other waves staged parts of it) */
+#pragma unroll
+        for (int h = 0; h < TPW; ++h)
+            if (lit[h]) {
+#pragma unroll
+                for (int y = 0; y < 4; ++y) s_out[h][y][tid] = pool_at(off[h] + (u32)y);
+            }
+    };
+    if (is_pb) front(InlCtx<2>{});
+    else if (p == 0) front(InlCtx<0>{});
+    else front(InlCtx<1>{});
 
     const unsigned long long ctr = s_ctr64;
     const u32 nI = min((u32)ctr & 1023u, (u32)ITEMS_CAP), nP = min((u32)(ctr >> 10) & 1023u, (u32)ITEMS_CAP - nI);
@@ -1586,8 +1659,8 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             if (it >= nI) {
                 const u32 t16 = s_item0[it] >> 10;
                 const u32 roff = ((t16 >> 13) & 3u) == 1u ? ref0_off : ref1_off;
-                const i32 o = landscape ? lw * os + ol : lw * ol + os;
-                const i32 ys = lw << y2;
+                const i32 o = landscape ? (i32)lw * os + ol : (i32)lw * ol + os;
+                const i32 ys = (i32)lw << y2;
                 const u32 voff = roff + (u32)clampi((i32)s_item2[it] + o, 0, slot - 8 - 3 * ys);     /* one clamp: legal windows lie inside the slot */
                 uint64_t wq[4];
                 window_load(ring, voff, (u32)ys, wq);
@@ -1633,7 +1706,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                     const u32 d = pool_at(bases + k);
                     u32 e[16], lo, hi;
                     if (!item_mc) gather_nest(d, landscape, s_nest, e, lo, hi);
-                    else gather_window(d, landscape, ring + roff, origin, lw, slot, e, lo, hi);
+                    else gather_window(d, landscape, ring + roff, origin, (i32)lw, slot, e, lo, hi);
                     const u32 g = basis_gain(d, lo, hi);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) r[i] += g * e[i];
@@ -1661,24 +1734,31 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 
     /* ---- phase C: tiles -> HBM ---- */
     if ((HVQ_ABL == 35 || HVQ_ABL == 37) && s_out[0][0][tid] != 0x12345678u) return;
-    const int wv = tid >> 6;
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
         if (h >= ntl) continue;
-        if ((hb & 3) == 0) {
-            const int g = wv * 16 + (lane & 15), rr = lane >> 4;
-            const u32 gb = b0 + (u32)(h * HVQ_TILE_BLOCKS) + 4u * (u32)g;
+        const u32 bw = b0 + (u32)(h * HVQ_TILE_BLOCKS) + wave * 64u;
+        if ((hb & 3u) == 0) {
+            /* lane (g, r): sample row r of blocks 4g .. 4g + 3 = 16 contiguous bytes of the plane (rows are multiples of 4 blocks) */
+            const u32 g4 = 4u * (lane & 15u), rr = lane >> 4;
+            const u32 gb = bw + g4;
             if (gb < nblocks) {
-                i32 gx, gy;
-                block_coords(gb, hb, rhb, gx, gy);
+                /* the row's four blocks lie in one map row (rows are multiples of 4 blocks, the wave's first block is one of 64) */
+                const u32 t = wbx0[h] + g4;
+                u32 q;
+                if (hb >= 64u) q = t >= hb ? 1u : 0u;
+                else q = __umul24(t, magic16) >> 16;
+                const u32 gx = t - __umul24(q, hb), gy = wby0[h] + q;
                 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 v = *(const u32x4 *)&s_out[h][rr][4 * g];
-                if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));
-                else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
+                const u32x4 v = *(const u32x4 *)&s_out[h][rr][wave * 64u + g4];
+                GLB u32x4 *dstp = (GLB u32x4 *)(plane + (size_t)((gy * 4u + rr) * pw + gx * 4u));
+                /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors in L2 */
+                if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, dstp);
+                else *dstp = v;
             }
-        } else if (b0 + (u32)(h * HVQ_TILE_BLOCKS + tid) < nblocks) {
+        } else if (bw + lane < nblocks) {
             i32 sx, sy;
-            block_coords(b0 + (u32)(h * HVQ_TILE_BLOCKS + tid), hb, rhb, sx, sy);
+            block_coords(bw + lane, (i32)hb, __builtin_amdgcn_rcpf((float)hb), sx, sy);
             GLB uint8_t *dst = plane + (size_t)(sy * 4) * pw + sx * 4;
 #pragma unroll
             for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[h][y][tid];
@@ -1702,7 +1782,7 @@ static void launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_
 /* static LDS of hvq_recon_inline_kernel<items_cap, tpw> (the host sizes the dynamic part against the CU's 160 KB) */
 extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t items_cap)
 {
-    return (uint32_t)(HVQ_NESTP_BYTES + 8 + 15) / 16u * 16u + tiles_per_wg * 4u * HVQ_WG * 4u + 64u * items_cap + 12u * items_cap + 16u + (HVQ_INL_BAR0(tiles_per_wg) ? 1024u : 4u);
+    return (uint32_t)(HVQ_NESTP_BYTES + 8 + 15) / 16u * 16u + tiles_per_wg * 4u * HVQ_WG * 4u + 64u * items_cap + 12u * items_cap + 16u;
 }
 
 /* as hvq_launch_recon, for pictures without tile queues; pair_cap / pool_cap: dwords of dynamic LDS for the pair list and the staged pool */

@@ -170,7 +170,6 @@ struct Pending {
 };
 
 struct Launch {
-    int queue;                         /* 0: main HIP stream, 1: second stream (the other half of the clips) */
     int level;
     uint32_t first_tile, ntiles;       /* its picture slots in the launch table: first entry, count */
     uint32_t max_tiles, workgroups;    /* grid = (8, max_tiles, slots / 8) at the chosen tiles per workgroup; workgroups that do work */
@@ -194,7 +193,7 @@ static bool env_tile_queues()
 /* a P picture with future-referencing macroblocks, behind the launch of its level: previous content into the destination slot
  * (unless it is there already), then the raster-order walk (hvq_selfref_kernel) from the side buffer */
 struct SelfRef {
-    int level, queue;
+    int level;
     uint32_t job;                      /* launch slot */
     const uint8_t *old_dev;            /* device source of the previous content, nullptr: in place already */
     const void *old_host;              /* SDK path: host source */
@@ -206,8 +205,8 @@ struct SelfRef {
 struct HvqContext {
     int device = 0;
     bool tile_queues = false;          /* two-pass reconstruction over tile queues in HBM (HVQM4_AMD_TILE_QUEUES=1) */
-    hipStream_t stream = nullptr, stream2 = nullptr;   /* dependency levels of two halves of the clips overlap */
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream = nullptr;      /* every launch of a batch: its dependency levels in order */
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<Stream> streams;
     /* staging: pinned host arena mirrored by a device arena */
     uint8_t *host_arena = nullptr, *dev_arena = nullptr;
@@ -220,6 +219,8 @@ struct HvqContext {
     size_t arena_cap_alt = 0;
     int arena_id = 0;                  /* which of the two the current one is */
     bool arena_waited = false;         /* copy_stream already waits for the last batch that used the current arena */
+    bool resv_active = false;          /* hvq_arena_reserve: [resv_base, resv_base + resv_bytes) of the arena being filled is the caller's to write */
+    size_t resv_base = 0, resv_bytes = 0;
     hipStream_t copy_stream = nullptr, read_stream = nullptr;
     hipEvent_t ev_read = nullptr;
     hipEvent_t ev_copy = nullptr, ev_parse = nullptr, ev_arena_free[2] = { nullptr, nullptr };
@@ -232,7 +233,6 @@ struct HvqContext {
     std::vector<int> fl_nest_streams;  /* stream of each pair */
     uint8_t *fl_host = nullptr, *fl_dev = nullptr;
     int fl_arena_id = 0;
-    int fl_nq = 1;
     HvqParseResult *pr_host = nullptr; /* pinned */
     size_t pr_host_cap = 0;
     uint64_t *timing_dev = nullptr;
@@ -260,6 +260,8 @@ struct HvqContext {
     std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
     HvqStats stats{};
     double parse_seconds = 0;
+    std::atomic<uint64_t> copy_bytes{ 0 };     /* bitstream bytes copied into the pinned arena (copy threads), and their wall time in ns */
+    std::atomic<uint64_t> copy_ns{ 0 };
     uint8_t *rgb_dev = nullptr;        /* scratch of the display epilogue */
     size_t rgb_cap = 0;
     RgbJob *rgb_jobs_dev = nullptr;
@@ -285,6 +287,7 @@ struct HvqContext {
 static int arena_reserve(HvqContext *c, size_t need)
 {
     if (c->arena_used + need <= c->arena_cap) return HVQ_OK;
+    if (c->resv_active) return fail(HVQ_E_STATE, "the arena would have to grow while a reservation of it is outstanding (hvq_submit_many_arena first)");
     size_t ncap = c->arena_cap ? c->arena_cap : (size_t)64 << 20;
     while (ncap < c->arena_used + need) ncap *= 2;
     uint8_t *nh = nullptr, *nd = nullptr;
@@ -421,8 +424,6 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     HIPCHK(hipEventCreateWithFlags(&c->ev_arena_free[1], hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     guard.c = nullptr;
     *out = c;
     return HVQ_OK;
@@ -468,9 +469,6 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->rgb_jobs_dev) (void)hipFree(c->rgb_jobs_dev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -751,13 +749,33 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
     return HVQ_OK;
 }
 
-/* GPU entropy parse: queue the raw bitstreams; hvq_flush parses them on the device (hvq_gparse.hip) */
-HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, const int *frame_types,
-                                      const uint8_t *const *pics, const size_t *lens, int *ordinals)
+/* GPU entropy parse: queue the raw bitstreams; hvq_flush parses them on the device (hvq_gparse.hip).  Three ways for the bytes to
+ * reach the pinned arena:
+ *   SUBMIT_COPY        copied before the call returns (hvq_submit_many_device: the caller's buffers are free again on return)
+ *   SUBMIT_COPY_ASYNC  copied by a worker thread (hvq_submit_many_device_async: the buffers stay the caller's until the next
+ *                      hvq_flush_begin / hvq_sync joins the worker)
+ *   SUBMIT_ARENA       already there: the caller filled a reservation of the arena itself (hvq_arena_reserve) -- no copy at all */
+enum SubmitMode { SUBMIT_COPY, SUBMIT_COPY_ASYNC, SUBMIT_ARENA };
+static int submit_device(HvqContext *c, int n, const int *streams, const int *frame_types, const uint8_t *const *pics_in,
+                         const size_t *arena_offs, const size_t *lens, int *ordinals, SubmitMode mode)
 {
-    if (!c || n < 0 || !streams || !frame_types || !pics || !lens) return fail(HVQ_E_ARG, "bad arguments");
+    if (!c || n < 0 || !streams || !frame_types || !lens || (mode == SUBMIT_ARENA ? !arena_offs : !pics_in)) return fail(HVQ_E_ARG, "bad arguments");
     size_t need = 0;
     { int rcj = copy_join(c); if (rcj) return rcj; }
+    std::vector<const uint8_t *> arena_pics;
+    if (mode == SUBMIT_ARENA) {
+        if (!c->resv_active) return fail(HVQ_E_STATE, "no arena reservation outstanding (hvq_arena_reserve)");
+        arena_pics.resize((size_t)n);
+        size_t prev_end = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t span = align_up(lens[i] + 32, 256);
+            if ((arena_offs[i] & 255u) || arena_offs[i] < prev_end || arena_offs[i] > c->resv_bytes || span > c->resv_bytes - arena_offs[i])
+                return fail(HVQ_E_ARG, "picture %d: offset %zu (+ %zu bytes with its padding) is not a 256-byte aligned, ascending range of the reservation", i, arena_offs[i], span);
+            prev_end = arena_offs[i] + span;
+            arena_pics[(size_t)i] = c->host_arena + c->resv_base + arena_offs[i];
+        }
+    }
+    const uint8_t *const *pics = mode == SUBMIT_ARENA ? arena_pics.data() : pics_in;
     for (int i = 0; i < n; ++i) {
         int rc = check_submit_args(c, streams[i], frame_types[i], pics[i], lens[i], false);
         if (rc) return rc;
@@ -766,11 +784,13 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
             return fail(HVQ_E_STATE, "stream %d is parsed on the host; a stream keeps one parser for its lifetime", streams[i]);
         need += align_up(lens[i] + 32, 256);
     }
-    if (n == 0) return HVQ_OK;
+    if (n == 0) { if (mode == SUBMIT_ARENA) c->resv_active = false; return HVQ_OK; }
     { int rcr = check_resume_order(c, n, streams, frame_types); if (rcr) return rcr; }
     HIPCHK(hipSetDevice(c->device));
-    int rc = arena_reserve(c, need);
-    if (rc) return rc;
+    if (mode != SUBMIT_ARENA) {
+        int rc = arena_reserve(c, need);
+        if (rc) return rc;
+    }
     std::vector<size_t> offs((size_t)n);
     /* Everything below changes stream and queue state before the last thing that can fail (allocation, upload): a failed
      * call must leave the context as it found it, so the touched streams are saved and put back. */
@@ -805,8 +825,8 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
             HIPCHK_RB(hipMalloc((void **)&s.nest_keep, 2 * GP_ALIGN16(HVQ_NESTP_BYTES)));
             HIPCHK_RB(hipMemsetAsync(s.nest_keep, 0, 2 * GP_ALIGN16(HVQ_NESTP_BYTES), c->stream));
         }
-        offs[(size_t)i] = c->arena_used;
-        c->arena_used += align_up(lens[i] + 32, 256);
+        if (mode == SUBMIT_ARENA) offs[(size_t)i] = c->resv_base + arena_offs[i];      /* arena_used already covers the reservation */
+        else { offs[(size_t)i] = c->arena_used; c->arena_used += align_up(lens[i] + 32, 256); }
         Pending q{};
         q.dev = true;
         q.blob_off = offs[(size_t)i]; q.blob_len = lens[i];
@@ -836,6 +856,7 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
     job.host = c->host_arena;
     auto run_copy = [c](const CopyJob &j) -> int {
         const int n = (int)j.pics.size();
+        const auto tc0 = std::chrono::steady_clock::now();
         /* chunks of ~16 MB: a chunk's H2D is queued as soon as its last picture is in the arena.  The copy threads are started ONCE
          * per batch and take pictures off a shared counter (round 3 started and joined a set of threads per chunk: 70 thread
          * starts per 160 MB batch); the calling thread copies too and queues the uploads in chunk order. */
@@ -883,10 +904,30 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
             if (j.early && !rc) rc = arena_upload(c, k + 1 < chunk_end.size() ? j.offs[(size_t)chunk_end[k]] : j.end_used);
         }
         for (auto &t : pool) t.join();
+        c->copy_bytes += total;
+        c->copy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tc0).count();
+        /* test hook (tests/test_gpu_batch.py): the upload of this batch "fails" -- exercises the rollback of both copy modes */
+        if (!rc && getenv("HVQM4_AMD_TEST_FAIL_COPY")) rc = fail(HVQ_E_HIP, "bitstream upload failed (HVQM4_AMD_TEST_FAIL_COPY)");
         return rc;
     };
-    static const int async_env = getenv("HVQM4_AMD_ASYNC_SUBMIT") ? atoi(getenv("HVQM4_AMD_ASYNC_SUBMIT")) : -1;
-    if (async_env != 0 && (c->fl_active || async_env > 0)) {
+    if (mode == SUBMIT_ARENA) {
+        /* the bytes are in place: zero the padding behind every picture (the device reader sees zeros past the end) and queue the
+         * upload of the whole reservation at once */
+        for (int i = 0; i < n; ++i) {
+            uint8_t *dst = c->host_arena + offs[(size_t)i];
+            memset(dst + lens[i], 0, align_up(lens[i] + 32, 256) - lens[i]);
+        }
+        c->resv_active = false;
+        if (c->arena_uploaded == c->resv_base) {                    /* nothing older is waiting for the flush-time upload */
+            int rcu = arena_upload(c, c->resv_base + c->resv_bytes);
+            if (rcu) { rollback(); return rcu; }
+        }
+        return HVQ_OK;
+    }
+    /* HVQM4_AMD_ASYNC_SUBMIT=1: the plain call defers its copy too, as round 4 did by default while a batch was in flight (its
+     * callers then had to keep their buffers until the next flush_begin: a silent change of the buffer contract, advisor finding) */
+    static const int async_env = getenv("HVQM4_AMD_ASYNC_SUBMIT") ? atoi(getenv("HVQM4_AMD_ASYNC_SUBMIT")) : 0;
+    if (mode == SUBMIT_COPY_ASYNC || (async_env > 0 && c->fl_active)) {
         c->copy_rc = HVQ_OK;
         c->copy_err.clear();
         c->copy_active = true;
@@ -902,6 +943,44 @@ HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, 
     }
 #undef HIPCHK_RB
     return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_submit_many_device(HvqContext *c, int n, const int *streams, const int *frame_types,
+                                      const uint8_t *const *pics, const size_t *lens, int *ordinals)
+{
+    return submit_device(c, n, streams, frame_types, pics, nullptr, lens, ordinals, SUBMIT_COPY);
+}
+
+HVQ_EXPORT int hvq_submit_many_device_async(HvqContext *c, int n, const int *streams, const int *frame_types,
+                                            const uint8_t *const *pics, const size_t *lens, int *ordinals)
+{
+    return submit_device(c, n, streams, frame_types, pics, nullptr, lens, ordinals, SUBMIT_COPY_ASYNC);
+}
+
+/* Zero-copy submit: the caller fills a reservation of the pinned arena itself (a container reader read()s file bytes straight into
+ * it), so the 160 MB per batch the copying calls move through the host's caches and DRAM once more never move at all. */
+HVQ_EXPORT int hvq_arena_reserve(HvqContext *c, size_t bytes, void **ptr)
+{
+    if (!c || !ptr || bytes == 0) return fail(HVQ_E_ARG, "bad arguments");
+    { int rcj = copy_join(c); if (rcj) return rcj; }
+    if (c->resv_active) return fail(HVQ_E_STATE, "an arena reservation is outstanding already: submit it (hvq_submit_many_arena) first");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t base = align_up(c->arena_used, 256);
+    bytes = align_up(bytes, 256);
+    { int rc = arena_reserve(c, base - c->arena_used + bytes); if (rc) return rc; }
+    if (c->arena_uploaded == c->arena_used) c->arena_uploaded = base;      /* the alignment gap carries nothing */
+    c->resv_base = base; c->resv_bytes = bytes; c->resv_active = true;
+    c->arena_used = base + bytes;
+    *ptr = c->host_arena + base;
+    return HVQ_OK;
+}
+
+HVQ_EXPORT size_t hvq_arena_stride(size_t len) { return align_up(len + 32, 256); }
+
+HVQ_EXPORT int hvq_submit_many_arena(HvqContext *c, int n, const int *streams, const int *frame_types,
+                                     const size_t *offsets, const size_t *lens, int *ordinals)
+{
+    return submit_device(c, n, streams, frame_types, nullptr, offsets, lens, ordinals, SUBMIT_ARENA);
 }
 
 /* GPU-parsed pictures of the pending batch: lay their blobs out, queue the parse kernel and the read-back of its
@@ -1137,31 +1216,21 @@ static int run_queue_build(HvqContext *c, bool count_bytes)
     return HVQ_OK;
 }
 
-/* enqueue all launches of the resident batch once: the second queue forks from / joins into the main stream */
+/* enqueue all launches of the resident batch once, dependency level by dependency level, on the context's one launch stream.  (Rounds
+ * 1-4 could deal the levels of even and odd streams to two HIP streams, HVQM4_AMD_QUEUES=2: it lost 7-9 % in every evidence line of
+ * round 4 -- two grids of this kernel get in each other's way -- and was removed in round 5.) */
 static int run_launches(HvqContext *c)
 {
-    bool two = false;
-    for (auto &L : c->launches) two |= L.queue == 1;
-    if (two) {
-        /* created on demand: HIP maps a process's streams onto four hardware queues, a fifth stream would share one */
-        if (!c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    }
+    hipStream_t st = c->stream;
     for (auto &L : c->launches) {
-        hipStream_t st = L.queue ? c->stream2 : c->stream;
         if (L.inline_queues) HIPCHK(hvq_launch_recon_inline(c->jobs_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, L.pool_cap, st));
         else HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, st));
         for (const SelfRef &sr : c->selfrefs) {
-            if (sr.level != L.level || sr.queue != L.queue) continue;
+            if (sr.level != L.level) continue;
             if (sr.old_host) HIPCHK(hipMemcpyAsync(sr.dst, sr.old_host, sr.pic_bytes, hipMemcpyHostToDevice, st));
             else if (sr.old_dev) HIPCHK(hipMemcpyAsync(sr.dst, sr.old_dev, sr.pic_bytes, hipMemcpyDeviceToDevice, st));
             HIPCHK(hvq_launch_selfref(c->jobs_dev + sr.job, c->selfref_dev + sr.side_off, sr.dst, st));
         }
-    }
-    if (two) {
-        HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
     return HVQ_OK;
 }
@@ -1176,25 +1245,14 @@ static int build_tiles(HvqContext *c)
     c->fl_launches.clear();
     int max_level = 0;
     for (auto &p : c->fl_pending) max_level = std::max(max_level, p.level);
-    /* Two queues: clips are independent, so the dependency levels of the even and of the odd streams form two
-     * chains that run on two HIP streams -- while one chain drains a level the other keeps the CUs busy. */
-    const char *qenv = getenv("HVQM4_AMD_QUEUES");
-    /* measured +2.1 % on the bench workload (profiles/r01m_ab_two_queues.txt); off by default: with overlapping
-     * launches the per-kernel durations a profiler reports no longer add up to the elapsed time the roofline uses */
-    const int nq = (qenv && atoi(qenv) >= 2) ? 2 : 1;
-    for (int lvl = 0; lvl <= max_level; ++lvl)
-      for (int qi = 0; qi < nq; ++qi) {
+    for (int lvl = 0; lvl <= max_level; ++lvl) {
         Launch L{};
-        L.queue = qi; L.level = lvl; L.first_tile = (uint32_t)tiles.size();
-        std::vector<uint32_t> order;                     /* submission order (sorting same-stream pictures into one grid column of
-                                                            consecutive groups was tried: +1 % dense, -3 % flat, dropped) */
+        L.level = lvl; L.first_tile = (uint32_t)tiles.size();
+        /* submission order (sorting same-stream pictures into one grid column of consecutive groups was tried: +1 % dense, -3 % flat, dropped) */
         for (size_t i = 0; i < c->fl_pending.size(); ++i) {
             const Pending &p = c->fl_pending[i];
-            if (p.level == lvl && !(nq == 2 && (p.stream & 1) != qi)) order.push_back((uint32_t)i);
-        }
-        for (uint32_t i : order) {
-            const Pending &p = c->fl_pending[i];
-            tiles.push_back(HvqTileRef{ i, p.ntiles });
+            if (p.level != lvl) continue;
+            tiles.push_back(HvqTileRef{ (uint32_t)i, p.ntiles });
             L.max_wg[0] = std::max(L.max_wg[0], p.ntiles); L.wgs[0] += p.ntiles;
             L.max_wg[1] = std::max(L.max_wg[1], p.nwg); L.wgs[1] += p.nwg;
         }
@@ -1203,8 +1261,7 @@ static int build_tiles(HvqContext *c)
         if (L.ntiles >= 8)
             while (L.ntiles & 7u) { tiles.push_back(HvqTileRef{ 0xFFFFFFFFu, 0u }); ++L.ntiles; }   /* padding slots exit at once */
         c->fl_launches.push_back(L);
-      }
-    c->fl_nq = nq;
+    }
     return HVQ_OK;                     /* the slots become the ORDER of the job table (flush_end): a workgroup finds its job by its grid position */
 }
 
@@ -1258,6 +1315,7 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
     std::swap(c->arena_cap, c->arena_cap_alt);
     c->arena_id ^= 1;
     c->arena_used = 0; c->arena_uploaded = 0; c->arena_waited = false;
+    c->resv_active = false;            /* a reservation that was never submitted goes with its arena */
     c->fl_active = true;
     if (!rc) rc = build_tiles(c);
     if (rc) return flush_abandon(c, rc);
@@ -1425,7 +1483,7 @@ static int flush_end(HvqContext *c)
                 /* the data-parallel pass writes a side buffer; the walk behind this level's launch merges it into the slot */
                 j.q_offs_off = (uint32_t)offs;
                 SelfRef sr{};
-                sr.level = p.level; sr.queue = c->fl_nq == 2 ? (p.stream & 1) : 0; sr.job = (uint32_t)k;
+                sr.level = p.level; sr.job = (uint32_t)k;
                 sr.old_host = p.host_old;
                 sr.old_dev = (p.host_old || p.old_slot == p.dst) ? nullptr : s.slot_ptr(p.old_slot);     /* -1: the zero slot */
                 sr.dst = s.slot_ptr(p.dst);
@@ -1452,6 +1510,8 @@ static int flush_end(HvqContext *c)
             const uint32_t ws = k ? hd->wshift : 0, hs = k ? hd->hshift : 0;
             r.hbvb = (uint32_t)hd->hb[k] | ((uint32_t)hd->vb[k] << 16);
             r.pw_sub = (uint32_t)(hd->width >> ws) | (ws << 16) | (hs << 24);
+            j.hb_magic[k] = hd->hb[k] > 1 ? (uint32_t)(0x100000000ull / hd->hb[k]) + 1u : 0u;
+            j.hb_magic16[k] = hd->hb[k] ? (65536u + hd->hb[k] - 1u) / hd->hb[k] : 0u;
         }
         st.pictures++;
         st.luma_pixels += (uint64_t)p.w * p.h;
@@ -1469,7 +1529,7 @@ static int flush_end(HvqContext *c)
         if (p.dropped) continue;
         for (size_t l = 0; l < c->fl_launches.size(); ++l) {
             const Launch &L = c->fl_launches[l];
-            if (p.level != L.level || (c->fl_nq == 2 && (p.stream & 1) != L.queue)) continue;
+            if (p.level != L.level) continue;
             lmi[l] = std::max(lmi[l], p.max_items); lmp[l] = std::max(lmp[l], p.max_pairs);
             break;
         }
@@ -1641,7 +1701,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
                         if (q[from[k]] && q[to[k]]) { sum[k] += (double)(q[to[k]] - q[from[k]]); cnt[k]++; }
                     life += (double)(q[LAST] - q[0]); nw++;
                 }
-            fprintf(stderr, "stamps L%d q%d: %u workgroups, %zu waves, mean wave lifetime %.0f cycles;", L.level, L.queue, L.workgroups, nw, nw ? life / nw : 0.0);
+            fprintf(stderr, "stamps L%d: %u workgroups, %zu waves, mean wave lifetime %.0f cycles;", L.level, L.workgroups, nw, nw ? life / nw : 0.0);
             for (int k = 0; k < NS; ++k) fprintf(stderr, " %s %.0f |", seg[k], cnt[k] ? sum[k] / cnt[k] : 0.0);
             fprintf(stderr, "\n");
         }
@@ -1893,6 +1953,7 @@ HVQ_EXPORT int hvq_get_stats(HvqContext *c, HvqStats *out)
     { int rc = flush_end(c); if (rc) return rc; }
     *out = c->stats;
     out->parse_seconds = c->parse_seconds;
+    out->copy_bytes = c->copy_bytes.load(); out->copy_seconds = (double)c->copy_ns.load() * 1e-9;
     if (c->qbytes_dev && c->stats.pictures) {      /* summed on the device by the batch's queue build */
         unsigned long long q = 0;
         HIPCHK(hipSetDevice(c->device));

@@ -30,10 +30,12 @@ extern "C" {
 #define HVQ_E_HIP        -5
 #define HVQ_E_STATE      -6
 #define HVQ_E_CONTAINER  -7   /* malformed .h4m file (every case the reference exits on) */
-#define HVQ_E_UNSUPPORTED -8  /* a picture this back end refuses rather than decode differently from the reference: a P picture with
-                                 future-referencing macroblocks (h4m:2058-2061), or malformed input that had to be clamped
-                                 (HVQM4_AMD_ALLOW_CLAMPED=1 decodes the latter).  The picture is not decoded, `present` is untouched,
-                                 the stream resumes at its next I picture; other streams of the batch are unaffected. */
+#define HVQ_E_UNSUPPORTED -8  /* a picture this back end refuses rather than decode differently from the reference: malformed input
+                                 that had to be clamped (HVQM4_AMD_ALLOW_CLAMPED=1 decodes it), an overflow-symbol run that does not
+                                 end inside its section, or a P picture with future-referencing macroblocks (h4m:2058-2061, decoded
+                                 like the reference since round 3) whose previous buffer content has left the stream's slot ring.
+                                 The picture is not decoded, `present` is untouched, the stream resumes at its next I picture; other
+                                 streams of the batch are unaffected. */
 
 #define HVQ_FRAME_I 0x10   /* container frame ids, h4m:2065-2070 */
 #define HVQ_FRAME_P 0x20
@@ -58,6 +60,9 @@ typedef struct HvqStats {
     uint32_t pad0;
     uint64_t queue_bytes;       /* tile-queue bytes (block records, literal / item / pair lists actually filled) one reconstruction pass
                                    reads beside the blobs' payload pools: descriptor traffic, not credited in the roofline */
+    uint64_t copy_bytes;        /* hvq_submit_many_device / _async: bitstream bytes the library copied into its pinned arena, summed since
+                                   the context was created (hvq_submit_many_arena copies nothing) */
+    double   copy_seconds;      /* ... and the wall time its copy threads took over them: host_copy GB/s = copy_bytes / copy_seconds */
 } HvqStats;
 
 int  hvq_context_create(int device, HvqContext **out);
@@ -87,11 +92,27 @@ int  hvq_submit_many(HvqContext *ctx, int n, const int *streams, const int *fram
  * queueing semantics as hvq_submit_many.  A stream uses either the host parser or the GPU parser for its whole
  * lifetime (the host parser keeps the nest of the last I picture); lens[] must be the real picture lengths.
  * Errors of the device parse (HVQ_E_OVERFLOW, HVQ_E_ARG) are reported by hvq_flush.
- * Streaming: called while a batch is in flight (between hvq_flush_begin and hvq_flush_end) it returns at once and the bitstreams
- * are copied into the pinned arena by a worker thread -- `pics[i]` must then stay readable until the next hvq_flush_begin (or
- * hvq_sync), which joins the worker; a failed upload is reported there and drops the queued batch. */
+ * The bitstreams are copied into the library's pinned arena before the call returns: `pics[i]` are the caller's again on return. */
 int  hvq_submit_many_device(HvqContext *ctx, int n, const int *streams, const int *frame_types,
                             const uint8_t *const *pics, const size_t *lens, int *ordinals);
+/* The same with the copy DEFERRED to a worker thread of the library: the call returns at once, so a streaming caller reaches
+ * hvq_flush_end (and the batch in flight its reconstruction launches) without waiting for 160 MB of host memcpy.  `pics[i]` (and
+ * the arrays) must stay readable and unchanged until the next hvq_flush_begin or hvq_sync, which joins the worker; an upload that
+ * fails on the worker is reported there and drops the whole queued batch (its streams resume at their next I picture).
+ * (Round 4 did this inside hvq_submit_many_device whenever a batch was in flight; since round 5 it is opt-in by name.
+ * HVQM4_AMD_ASYNC_SUBMIT=1 restores the old behaviour of the plain call.) */
+int  hvq_submit_many_device_async(HvqContext *ctx, int n, const int *streams, const int *frame_types,
+                                  const uint8_t *const *pics, const size_t *lens, int *ordinals);
+/* Zero-copy submit.  hvq_arena_reserve hands out `bytes` of the pinned (DMA-able) arena the library uploads from; the caller
+ * writes its pictures there itself -- a container reader read()s file bytes straight into it -- at 256-byte aligned, ascending
+ * offsets, picture i occupying hvq_arena_stride(lens[i]) bytes (its length plus the zero padding the device reader needs, which
+ * the library writes).  hvq_submit_many_arena then queues them without touching a byte: no memcpy, no second pass over the
+ * host's memory.  One reservation at a time; the pointer is valid until its submit (or the next hvq_flush_begin, which drops an
+ * unsubmitted reservation).  Same queueing semantics and errors as hvq_submit_many_device. */
+int  hvq_arena_reserve(HvqContext *ctx, size_t bytes, void **ptr);
+size_t hvq_arena_stride(size_t len);
+int  hvq_submit_many_arena(HvqContext *ctx, int n, const int *streams, const int *frame_types,
+                           const size_t *offsets, const size_t *lens, int *ordinals);
 
 /* Upload queued descriptors, group queued pictures into dependency levels, launch. Async. */
 int  hvq_flush(HvqContext *ctx);
@@ -108,9 +129,10 @@ int  hvq_sync(HvqContext *ctx);
 /* Re-run the launches of the last flush `reps` times (descriptors already resident in HBM).
  * *gpu_ms = elapsed time between HIP events recorded on the launch stream around all reps. */
 int  hvq_replay(HvqContext *ctx, int reps, float *gpu_ms);
-/* The same with the per-picture queue build (hvq_tileq_kernel: block records, literal / item / pair lists from the descriptors)
- * inside the repeated region -- what a NEW batch costs behind its parse.  what = 0: reconstruction launches only (= hvq_replay);
- * 1: queue build + reconstruction launches per repetition; 2: queue build only. */
+/* What a NEW batch costs behind its parse, repeated `reps` times.  Default (hvq_recon_inline_kernel): the reconstruction launches and
+ * nothing else -- the workgroups derive their queues from the parser's descriptors themselves, so what = 1 equals hvq_replay and
+ * what = 2 is empty.  With HVQM4_AMD_TILE_QUEUES=1 (round 3's two-pass variant) the per-picture queue build (hvq_tileq_kernel) runs
+ * inside the repeated region: what = 0 reconstruction launches only, 1 queue build + launches, 2 queue build only. */
 int  hvq_replay_stage(HvqContext *ctx, int reps, int what, float *gpu_ms);
 
 /* Copy a still-resident picture (Y|U|V, pic_bytes) to host memory; synchronises. */

@@ -140,3 +140,130 @@ def test_threaded_submit_equals_sequential(gpu_ctx):
         for i in range(len(pics)):
             assert np.array_equal(gpu_ctx.read_picture(sid, i), want[i]), (cl.width, i)
         gpu_ctx.close_stream(sid)
+
+
+# ---------------------------------------------------------------------------------------------- round 5: the submit contracts
+def _device_pics(cl):
+    from hvqm4_amd.container import parse_header, video_pictures
+    hdr = parse_header(cl.data)
+    return hdr, [(ft, bytes(pic)) for ft, _d, pic in video_pictures(cl.data)]
+
+
+def test_synchronous_device_submit_lets_go_of_the_callers_buffers():
+    """hvq_submit_many_device copies before it returns (advisor finding of round 4: it silently deferred the copy while a batch was
+    in flight): the caller's buffers are poisoned right after every call -- also in streaming, with a batch in flight -- and the
+    pictures must still be the oracle's"""
+    import ctypes as C
+    from hvqm4_amd import batch
+    from hvqm4_amd._lib import check, lib
+    from oracle import bridge
+    cl = clips.get(clips.SMALL[3])
+    hdr, pics = _device_pics(cl)
+    want = bridge.oracle_decode(cl.data, cl.n_pictures)
+    ctx = batch.Context(0)
+    sid = ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, 3 * len(pics) + 3)
+    n = len(pics)
+
+    def submit_and_poison():
+        bufs = [C.create_string_buffer(p, len(p)) for _ft, p in pics]
+        a_p = (C.c_char_p * n)(*[C.cast(b, C.c_char_p) for b in bufs])
+        a_s = (C.c_int * n)(*([sid] * n)); a_t = (C.c_int * n)(*[ft for ft, _p in pics])
+        a_l = (C.c_size_t * n)(*[len(p) for _ft, p in pics]); a_o = (C.c_int * n)()
+        check(lib().hvq_submit_many_device(ctx._h, n, a_s, a_t, a_p, a_l, a_o))
+        for b in bufs:                               # the call has returned: the bytes are the caller's again
+            C.memset(b, 0xA5, len(b))
+        return list(a_o)
+
+    o1 = submit_and_poison()
+    ctx.flush_begin()
+    o2 = submit_and_poison()                         # a batch is in flight: round 4 deferred exactly this copy
+    ctx.flush_end()
+    ctx.flush()
+    for ords in (o1, o2):
+        for i, o in enumerate(ords):
+            assert np.array_equal(ctx.read_picture(sid, o), want[i]), (o, i)
+    ctx.close()
+
+
+def test_deferred_and_zero_copy_submits_decode_the_same_pictures():
+    """hvq_submit_many_device_async (copy on a worker, joined by flush_begin) and hvq_arena_reserve + hvq_submit_many_arena (the
+    caller writes the pinned arena itself, nothing is copied) against the oracle; bad arena layouts are refused"""
+    from hvqm4_amd import batch
+    from hvqm4_amd._lib import HVQ_E_ARG, HVQ_E_STATE, HvqError
+    from oracle import bridge
+    cl = clips.get(clips.SMALL[4])
+    hdr, pics = _device_pics(cl)
+    want = bridge.oracle_decode(cl.data, cl.n_pictures)
+    ctx = batch.Context(0)
+    sid = ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, 3 * len(pics) + 3)
+    n = len(pics)
+    fts = [ft for ft, _p in pics]
+    o1 = ctx.submit_many_device([sid] * n, fts, [p for _ft, p in pics], defer=True)
+    ctx.flush_begin()
+    # zero copy while that batch is in flight: lay the pictures out in a reservation of the OTHER arena
+    offs, at = [], 0
+    for _ft, p in pics:
+        offs.append(at); at += ctx.arena_stride(len(p))
+    view = ctx.arena_reserve(at)
+    with pytest.raises(HvqError) as e:               # one reservation at a time
+        ctx.arena_reserve(256)
+    assert e.value.code == HVQ_E_STATE
+    view[:] = 0x5A                                   # the library must write the padding itself
+    for (ft, p), o in zip(pics, offs):
+        view[o:o + len(p)] = np.frombuffer(p, np.uint8)
+    with pytest.raises(HvqError) as e:               # unaligned offset
+        ctx.submit_many_arena([sid] * n, fts, [o + 8 for o in offs], [len(p) for _ft, p in pics])
+    assert e.value.code == HVQ_E_ARG
+    with pytest.raises(HvqError) as e:               # beyond the reservation
+        ctx.submit_many_arena([sid] * n, fts, [o + at for o in offs], [len(p) for _ft, p in pics])
+    assert e.value.code == HVQ_E_ARG
+    o2 = ctx.submit_many_arena([sid] * n, fts, offs, [len(p) for _ft, p in pics])
+    with pytest.raises(HvqError) as e:               # the reservation is spent
+        ctx.submit_many_arena([sid] * n, fts, offs, [len(p) for _ft, p in pics])
+    assert e.value.code == HVQ_E_STATE
+    ctx.flush_end()
+    ctx.flush()
+    for ords in (o1, o2):
+        for i, o in enumerate(ords):
+            assert np.array_equal(ctx.read_picture(sid, o), want[i]), (o, i)
+    assert ctx.stats().gpu_parsed == n
+    ctx.close()
+
+
+@pytest.mark.parametrize("defer", [False, True], ids=["sync", "deferred"])
+def test_failed_bitstream_upload_drops_the_batch_and_the_stream_recovers(defer, monkeypatch):
+    """an upload that fails: synchronously the call fails and leaves the context as it was; on the worker the failure is reported by
+    the next flush_begin, the queued batch is gone, its stream waits for an I picture -- and then decodes again (copy_join's rollback)"""
+    from hvqm4_amd import batch
+    from hvqm4_amd._lib import HVQ_E_HIP, HVQ_E_STATE, HvqError
+    from oracle import bridge
+    cl = clips.get(clips.SMALL[3])
+    hdr, pics = _device_pics(cl)
+    want = bridge.oracle_decode(cl.data, cl.n_pictures)
+    ctx = batch.Context(0)
+    sid = ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, 2 * len(pics) + 3)
+    n = len(pics)
+    fts = [ft for ft, _p in pics]
+    raw = [p for _ft, p in pics]
+    monkeypatch.setenv("HVQM4_AMD_TEST_FAIL_COPY", "1")
+    if defer:
+        ctx.submit_many_device([sid] * n, fts, raw, defer=True)      # returns at once; the worker fails
+        with pytest.raises(HvqError) as e:
+            ctx.flush_begin()
+        assert e.value.code == HVQ_E_HIP and "dropped" in str(e.value)
+    else:
+        with pytest.raises(HvqError) as e:
+            ctx.submit_many_device([sid] * n, fts, raw)
+        assert e.value.code == HVQ_E_HIP
+    monkeypatch.delenv("HVQM4_AMD_TEST_FAIL_COPY")
+    ctx.flush()                                                       # nothing is queued
+    if defer:
+        # the dropped pictures consumed ordinals; none of them reads as resident
+        with pytest.raises(HvqError) as e:
+            ctx.read_picture(sid, 0)
+        assert e.value.code == HVQ_E_STATE
+    ords = ctx.submit_many_device([sid] * n, fts, raw)                # the clip starts with an I picture: the stream resumes
+    ctx.flush()
+    for i, o in enumerate(ords):
+        assert np.array_equal(ctx.read_picture(sid, o), want[i]), (o, i)
+    ctx.close()

@@ -24,6 +24,11 @@ def test_batched_path_matches_oracle(case, gpu_ctx):
     got = decode_clip(gpu_ctx, clip.data)
     assert got.shape == want.shape
     assert np.array_equal(got, want), _first_diff(got, want)      # integer pixel work: bit-exact
+    # the chain is closed HERE, on the GPU box: when the compiled reference travelled with the snapshot (oracle/_ref), the same
+    # pictures must equal what the unmodified reference decoder produces -- not only what this repo's restatement of it does
+    if case in clips.SMALL and bridge.have_ref():
+        ref = bridge.ref_decode(clip.data, clip.n_pictures)
+        assert np.array_equal(got, ref), "GPU vs compiled reference: " + _first_diff(got, ref)
 
 
 @pytest.mark.parametrize("case", clips.SMALL[:8] + clips.SMALL[17:18] + clips.MEDIUM[1:2], ids=lambda c: c[0])
@@ -146,3 +151,16 @@ def test_sdk_calls_with_exactly_sized_frames(trust, monkeypatch):
             if ft != 0x30:
                 pl.present, pl.future = pl.future, pl.present
         pl.close()
+
+
+def test_seeded_slice_of_the_randomised_parity_sweep(gpu_ctx):
+    """200 clips of tools/parity_sweep.py (geometry, version, sampling, preset, GOP, shifts, ring size and flush cadence drawn from a
+    fixed seed), host-parsed AND GPU-parsed, every picture against the oracle.  The full sweeps (thousands of clips per mode,
+    tools/r04_sweep.sh) found a real refusal bug in round 4 that no fixed clip had caught; this slice runs where the driver looks."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_sweep
+    bad, pics, refused = parity_sweep.sweep(gpu_ctx, 200, 5005, "both", log=lambda *a, **k: None)
+    assert bad == 0, f"{bad} of 200 random clips differ from the oracle"
+    assert pics > 800 and refused == 0

@@ -44,11 +44,10 @@ def decode_last(ctx, data, nslots, gpu_parse=False):
     return out
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
-    which = sys.argv[3] if len(sys.argv) > 3 else "host"
-    ctx = batch.Context(0)
+def sweep(ctx, n: int, seed: int, which: str = "both", log=print):
+    """`n` random clips drawn from `seed` through the batched path (host parser, GPU parser or both) against the CPU oracle;
+    returns (mismatching clips, pictures decoded, clips refused by design)"""
+    rng = np.random.default_rng(seed)
     bad = pics = refused = 0
     t0 = time.time()
     for i in range(n):
@@ -67,18 +66,27 @@ def main():
                     got = decode_last(ctx, clip.data, nslots, gpu_parse)
                     ok = ok and np.array_equal(got, want[-1])
             except HvqError as e:
-                # both parsers refuse a picture whose overflow-symbol loop ends on their cap (HVQ_F_CAPPED): the
-                # reference sums for as long as the stream says.  Counted, not a mismatch; anything else is an error.
+                # both fast parsers hand a picture whose overflow-symbol loop ends on their cap to the uncapped host parse (round 5);
+                # what even that refuses (a run that never ends) is counted, not a mismatch; anything else is an error.
                 if "overflow-symbol run" not in str(e):
                     raise
                 refused += 1
-                print("REFUSED (capped overflow run)", "gpu" if gpu_parse else "host", cfg, flush=True)
+                log("REFUSED (capped overflow run)", "gpu" if gpu_parse else "host", cfg, flush=True)
         pics += clip.n_pictures
         if not ok:
             bad += 1
-            print("MISMATCH", nslots, cfg, flush=True)
+            log("MISMATCH", nslots, cfg, flush=True)
         if (i + 1) % 50 == 0:
-            print(f"{i + 1} clips, {pics} pictures, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+            log(f"{i + 1} clips, {pics} pictures, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    return bad, pics, refused
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    which = sys.argv[3] if len(sys.argv) > 3 else "host"
+    ctx = batch.Context(0)
+    bad, pics, refused = sweep(ctx, n, seed, which)
     ctx.close()
     print(f"sweep done: {n} clips, {pics} pictures, {bad} mismatches" + (f", {refused} refused by design (capped overflow run)" if refused else ""))
     sys.exit(1 if bad else 0)

@@ -30,7 +30,7 @@ def main():
             a_s.append(sid); a_t.append(ft); a_p.append(bytes(pic))
     free0 = None
     t0 = time.time()
-    ctx.submit_many_device(a_s, a_t, a_p)
+    ctx.submit_many_device(a_s, a_t, a_p, defer=True)
     ctx.flush_begin()
     bad = 0
     for b in range(1, nb):
@@ -43,9 +43,9 @@ def main():
             free, _tot = torch.cuda.mem_get_info(0)
             free0 = free0 or free
             print(f"batch {b}: {bad} mismatches, device free {free >> 20} MiB (start {free0 >> 20}), {time.time() - t0:.1f} s", flush=True)
-            ctx.submit_many_device(a_s, a_t, a_p)
+            ctx.submit_many_device(a_s, a_t, a_p, defer=True)
         else:
-            ctx.submit_many_device(a_s, a_t, a_p)
+            ctx.submit_many_device(a_s, a_t, a_p, defer=True)
             ctx.flush_end()
         ctx.flush_begin()
     ctx.flush_end()
