@@ -175,17 +175,26 @@ def cpu_quota():
 
 
 def pin_rank(local_rank: int, local_world: int):
-    """One rank per GPU on a shared host (the scaling risk is host-side): every rank takes its own slice of the
-    cores the process may use -- its copy threads (which inherit the mask) then never compete with another rank's -- and
-    min(8, slice) copy threads.  Returns (copy threads, cores of the slice) for the result line."""
+    """One rank per GPU on a shared host (the scaling risk is host-side): every rank binds itself to cores of the NUMA
+    node ITS GPU hangs off (hvqm4_amd/topology.py: KFD topology -> PCI address -> numa_node -> cpulist; ranks that share a node split
+    its cores) -- its copy threads inherit the mask, and the pinned arenas, allocated after this call, are first touched from those
+    cores, so the bitstreams a rank copies and its GPU's DMA reads stay on one socket.  Where sysfs does not tell (a container without
+    /sys/class/kfd) the ranks take even linear slices of the allowed cores, as before round 5.  Reads sysfs only: no GPU call.
+    Returns (copy threads, cores of the slice, numa node or None, "numa" | "linear")."""
+    from hvqm4_amd import topology
     cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    per = max(1, len(cores) // max(1, local_world))
-    mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+    shared = bool(os.environ.get("HVQM4_BENCH_SHARE_GPU"))             # rehearsal: every rank drives device 0
+    devices = [0] * local_world if shared else None
+    if shared:                                                        # ... so the node of device 0 is everybody's: split linearly
+        mine, node, how = topology.rank_cores(local_rank, local_world, cores, sysfs=os.devnull)
+        node = topology.gpu_numa_node(0)
+    else:
+        mine, node, how = topology.rank_cores(local_rank, local_world, cores, devices=devices)
     if local_world > 1 and hasattr(os, "sched_setaffinity"):
         os.sched_setaffinity(0, mine)
     threads = int(os.environ.get("HVQM4_AMD_COPY_THREADS", "0")) or max(1, min(8, len(mine)))
     os.environ["HVQM4_AMD_COPY_THREADS"] = str(threads)
-    return threads, mine
+    return threads, mine, node, how
 
 
 # ---------------------------------------------------------------------------------------------- one rank
@@ -209,7 +218,7 @@ def main():
 
     mv_bits = tuple(int(x) for x in args.mv_bits.split(","))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    copy_threads, my_cores = pin_rank(local_rank % max(1, local_world), local_world)
+    copy_threads, my_cores, my_node, pin_how = pin_rank(local_rank % max(1, local_world), local_world)
     workers = args.gen_workers or max(1, host_cores())          # after pin_rank: the cores of this rank's slice
 
     # ---- synthetic inputs (fixed seeds) ----
@@ -488,7 +497,7 @@ def main():
                                                    "(hvq_arena_reserve / hvq_submit_many_arena: what a container reader that read()s into the "
                                                    "reservation leaves): no host memcpy, the batch costs the host its bookkeeping and the DMA"},
                    "affinity": {"cores_of_rank0": len(my_cores), "first": my_cores[0], "last": my_cores[-1], "ranks_on_host": local_world,
-                                "pinned": local_world > 1},
+                                "pinned": local_world > 1, "numa_node_of_gpu": my_node, "core_choice": pin_how},
                    "pictures_checked_against_host_parsed": ok,
                    "streaming_with_readback": rb,
                    "what": "raw bitstreams in host memory -> H2D -> entropy parse kernel (one workgroup per picture) -> "

@@ -32,6 +32,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "hvq_desc.h"
 
@@ -1426,24 +1427,31 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         if (HVQ_ABL == 42 || HVQ_ABL == 43) { if (is_pb) { const u32 hh = ((bx[h] >> (1u - ws)) * 73u + (by[h] >> (1u - hs)) * 151u) * 2654435761u; mvw[h] = (((hh >> 8) & 1023u) + 16u) | ((((hh >> 18) & 511u) + 64u) << 16); } }
         else if (is_pb) mvw[h] = *(const GLB u32 *)((const GLB uint8_t *)mvs + 4u * (__umul24(by[h] >> (1u - hs), mcb_w) + (bx[h] >> (1u - ws))));
     }
+    /* LDS-DMA in 16-byte pieces (gfx950: global_load_lds_dwordx4): the nest is 84 of them, a dense tile's pool range ~80 -- two
+     * instructions of the first two waves each instead of two per wave (round 4 moved dwords: the staging was 8 % of the step,
+     * profiles/r05_recon_steps.txt).  The pool range starts at the 16-byte boundary below `plo` (the pool section is 16-byte aligned). */
     typedef __attribute__((address_space(3))) u32 lds_u32;
     const bool has_nest = (HVQ_W64(10) != 0) && HVQ_ABL != 43;
     if (has_nest) {
+        constexpr u32 NCH = HVQ_NESTP_BYTES / 16u;                       /* 84 */
+        static_assert(HVQ_NESTP_BYTES % 16 == 0, "nest in 16-byte pieces");
 #pragma unroll
-        for (int r0 = 0; r0 < (HVQ_NESTP_BYTES + 3) / 4; r0 += HVQ_WG)
-            if (r0 + tid < (HVQ_NESTP_BYTES + 3) / 4)
-                __builtin_amdgcn_global_load_lds((const GLB u32 *)((const GLB uint8_t *)nestp + 4u * (u32)(r0 + tid)), (lds_u32 *)((u32 *)s_nest + r0 + wave * 64u), 4, 0, 0);
+        for (u32 r0 = 0; r0 < NCH; r0 += HVQ_WG)
+            if (r0 + (u32)tid < NCH)
+                __builtin_amdgcn_global_load_lds((const GLB u32 *)((const GLB uint8_t *)nestp + 16u * (r0 + (u32)tid)), (lds_u32 *)((u32 *)s_nest + 4u * (r0 + wave * 64u)), 16, 0, 0);
     }
     phi = max(phi, plo);
-    const u32 nst = HVQ_ABL == 43 ? 0u : min(phi - plo, pool_cap);                          /* staged dwords */
+    const u32 plo4 = plo & ~3u;
+    const u32 nst = HVQ_ABL == 43 ? 0u : min(phi - plo4, pool_cap);    /* staged dwords, from plo4 on (pool_cap is a multiple of 4) */
     {
-        const GLB uint8_t *pool_lo = (const GLB uint8_t *)(pool + plo);
-        for (u32 r0 = 0; r0 < nst; r0 += HVQ_WG)
-            if (r0 + (u32)tid < nst) __builtin_amdgcn_global_load_lds((const GLB u32 *)(pool_lo + 4u * (r0 + (u32)tid)), (lds_u32 *)(s_pool + r0 + wave * 64u), 4, 0, 0);
+        const GLB uint8_t *pool_lo = (const GLB uint8_t *)(pool + plo4);
+        const u32 nch = (nst + 3u) >> 2;
+        for (u32 r0 = 0; r0 < nch; r0 += HVQ_WG)
+            if (r0 + (u32)tid < nch) __builtin_amdgcn_global_load_lds((const GLB u32 *)(pool_lo + 16u * (r0 + (u32)tid)), (lds_u32 *)(s_pool + 4u * (r0 + wave * 64u)), 16, 0, 0);
     }
-    const bool all_staged = phi - plo <= pool_cap;                             /* uniform, and true unless a tile's payload exceeds the launch's LDS share */
+    const bool all_staged = phi - plo4 <= pool_cap;                            /* uniform, and true unless a tile's payload exceeds the launch's LDS share */
     auto pool_at = [&](u32 idx) -> u32 {                                       /* a dword of the payload pool: staged, or (beyond the staging cap) from HBM */
-        const u32 j = idx - plo;
+        const u32 j = idx - plo4;
         if (all_staged) return s_pool[j];                                       /* every index the descriptors produce lies inside the tile's range */
         return j < nst ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
     };
@@ -1779,6 +1787,12 @@ static void launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_
 #endif
 }
 
+/* dynamic LDS in bytes of a launch with these caps (as hvq_launch_recon_inline rounds them) */
+extern "C" uint32_t hvq_recon_inline_dyn_lds(uint32_t pair_cap, uint32_t pool_cap)
+{
+    return 4u * (((std::max(pair_cap, 1u) + 3u) & ~3u) + ((pool_cap + 3u) & ~3u));
+}
+
 /* static LDS of hvq_recon_inline_kernel<items_cap, tpw> (the host sizes the dynamic part against the CU's 160 KB) */
 extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t items_cap)
 {
@@ -1790,7 +1804,10 @@ extern "C" hipError_t hvq_launch_recon_inline(const HvqJob *jobs_dev, uint32_t n
                                               uint32_t items_cap, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream)
 {
     if (nslots == 0 || max_wgs == 0) return hipSuccess;
-    if (pair_cap == 0) pair_cap = 1;
+    /* the staged pool follows the pair list in dynamic LDS and is filled in 16-byte pieces: both sizes in multiples of 4 dwords
+     * (hvq_recon_inline_dyn_lds tells the host what that makes) */
+    pair_cap = (std::max(pair_cap, 1u) + 3u) & ~3u;
+    pool_cap = (pool_cap + 3u) & ~3u;
     if (tiles_per_wg >= 2) {
         if (items_cap <= 32) launch_recon_inline<32, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);
         else if (items_cap <= 64) launch_recon_inline<64, 2>(jobs_dev, nslots, max_wgs, pair_cap, pool_cap, stream);

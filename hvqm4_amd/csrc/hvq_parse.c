@@ -133,14 +133,28 @@ static inline int32_t sym(const Code *c, BitRd *b)                            /*
     return c->leaf[id];
 }
 
-/* `*flags` gets HVQ_F_CAPPED when the loop ends on its cap, not on the stream: the reference would have gone on summing */
+/* The reference sums overflow symbols for as long as the stream says (h4m:654-664).  The fast loop stops at SOVF_CAP symbols -- the
+ * cap the GPU parser shares; a run that long is not something an encoder writes -- and a run that is STILL open then is followed to
+ * its end by the slow loop below (round 5; rounds 3-4 refused such a picture): every symbol of a tree with two leaves or more
+ * consumes a bit, so the loop is bounded by the bits left in the picture, behind which the reader delivers zeros -- the reference
+ * would be reading foreign memory there.  `*flags` gets HVQ_F_CAPPED only when even that does not end the run (a one-leaf tree whose
+ * value lies outside the window: the reference never returns); the picture is refused then, and the rest of its parse returns at
+ * once (the values no longer matter, and a full-size picture of such reads must not take seconds). */
 static int32_t sym_sovf(const Code *c, BitRd *b, int32_t lo, int32_t hi, uint32_t *flags)       /* h4m:654-664 */
 {
     uint32_t total = 0;
     int32_t v;
     int guard = 0;
+    if (__builtin_expect(*flags & HVQ_F_CAPPED, 0)) return 0;
     do { v = sym(c, b); total += (uint32_t)v; } while ((v <= lo || v >= hi) && ++guard < SOVF_CAP);
-    if (v <= lo || v >= hi) *flags |= HVQ_F_CAPPED;
+    if (__builtin_expect(v <= lo || v >= hi, 0)) {
+        if (b->end != (const uint8_t *)UINTPTR_MAX) {            /* picture length known: the walk is bounded */
+            const uint8_t *at = b->p - (b->cnt >> 3);
+            size_t left = at < b->end ? (size_t)(b->end - at) * 8u + 64u : 64u;
+            while ((v <= lo || v >= hi) && left--) { v = sym(c, b); total += (uint32_t)v; }
+        }
+        if (v <= lo || v >= hi) *flags |= HVQ_F_CAPPED;
+    }
     return (int32_t)total;
 }
 
@@ -192,6 +206,11 @@ static void build_type_info(void);
 
 HvqParser *hvq_parser_create(int width, int height, int h_samp, int v_samp, int is15)
 {
+#if defined(__x86_64__) && defined(__AVX2__)
+    /* this file is built for x86-64-v3 (Makefile HOST_ARCH: BMI2 shifts in the bit reader): every entry point that parses goes through a
+     * parser object, so an older CPU is refused HERE with a NULL parser instead of dying on an illegal instruction in the first symbol */
+    if (!__builtin_cpu_supports("avx2") || !__builtin_cpu_supports("bmi2")) return NULL;
+#endif
     if (width < 8 || height < 8 || (width & 7) || (height & 7) || width > 8192 || height > 8192) return NULL;
     /* 4:2:0, 4:4:4, and 4:2:2 as h_samp 2 / v_samp 1 (two chroma blocks per macroblock, one above the other).  The fourth
      * combination the reference's setHVQPlaneDesc accepts, h_samp 1 / v_samp 2, is not decodable by the reference itself: with
@@ -432,6 +451,8 @@ static void pack_nest(uint8_t *dst, const uint8_t *nest)
     memset(dst, 0, ALIGN16(HVQ_NESTP_BYTES));
     for (int i = 0; i < HVQ_NEST_BYTES; i += 2) dst[i >> 1] = (uint8_t)((nest[i] & 0xF) | ((nest[i + 1] & 0xF) << 4));
 }
+
+void hvq_parser_packed_nest(const HvqParser *p, uint8_t *out) { pack_nest(out, p->nest); }
 
 /* ------------------------------------------------------------------ I pictures */
 static void ipic_kinds(HvqParser *p, uint8_t *blob)                              /* h4m:1073-1130 */

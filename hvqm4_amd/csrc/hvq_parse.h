@@ -50,6 +50,10 @@ void hvq_parser_layout(const HvqParser *p, HvqPicHeader *out);
 int hvq_parse_picture(HvqParser *p, int frame_type, const uint8_t *pic, size_t len,
                       uint8_t *blob, size_t cap, size_t *blob_len);
 
+/* the nest of the last I picture this parser has parsed (h4m:1132-1164), nibble-packed as the blobs carry it: `out` = ALIGN16(HVQ_NESTP_BYTES)
+ * bytes.  (An I picture's blob contains its nest only when one of its own blocks needs it; later P/B pictures may need it regardless.) */
+void hvq_parser_packed_nest(const HvqParser *p, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,9 @@
  * would produce pixels fails with HVQ_E_NOGPU.
  */
 #include <hip/hip_runtime.h>
+#if defined(__x86_64__)
 #include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -54,6 +56,7 @@ extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_jo
 extern "C" hipError_t hvq_launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_t max_wgs, uint32_t tiles_per_wg,
                                               uint32_t items_cap, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream);
 extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t items_cap);
+extern "C" uint32_t hvq_recon_inline_dyn_lds(uint32_t pair_cap, uint32_t pool_cap);
 extern "C" hipError_t hvq_launch_gather(const uint64_t *src_dev, uint8_t *dst_dev, uint32_t n, uint32_t pic_bytes, hipStream_t stream);
 extern "C" hipError_t hvq_launch_upload(const void *src_pinned, void *dst_dev, size_t bytes, hipStream_t stream);
 extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *side, uint8_t *dst, hipStream_t stream);
@@ -163,6 +166,10 @@ struct Pending {
     uint64_t dev_blob = 0, dev_nest = 0, nest_ptr = 0;
     uint32_t flags = 0, unk_shift = 0, pool_dwords = 0;
     int status = 0;                    /* device parse status bits (GP_ST_*) */
+    bool redo = false;                 /* GPU-parsed picture whose overflow run outlasted the device parser's cap: parsed again on the host,
+                                          its blob lies at rp_dev + redo_off, its header in redo_hd */
+    size_t redo_off = 0;
+    HvqPicHeader redo_hd{};
     bool dropped = false;              /* rejected at flush time (or follows a rejected picture of its stream): not reconstructed */
     int old_slot = -1;                 /* P pictures: slot that holds what the reference's `present` buffer held before this picture
                                           (-1: never written -> the zero slot; -2: that picture's slot has been reused since) */
@@ -238,7 +245,7 @@ struct HvqContext {
     uint64_t *timing_dev = nullptr;
     /* pinned staging of the table uploads, one set per arena id: an H2D from pageable memory would block the caller
      * until the stream has drained (the parse kernel!), which is exactly what hvq_flush_begin must not do */
-    struct Pinned { uint8_t *p = nullptr; size_t cap = 0; } pin[2][4];   /* [arena id][parse jobs, tiles, jobs, nest pairs] */
+    struct Pinned { uint8_t *p = nullptr; size_t cap = 0; } pin[2][5];   /* [arena id][parse jobs, tiles, jobs, nest pairs, re-parsed blobs] */
     std::vector<HvqJob> jobs_host;     /* the tables are built here, then copied into the pinned staging */
     std::vector<HvqTileRef> tiles_host;
     std::vector<HvqParseJob> pjobs_host;
@@ -257,6 +264,10 @@ struct HvqContext {
     size_t selfref_cap = 0;
     std::vector<SelfRef> selfrefs;
     std::vector<Launch> launches;
+    /* small resident batches (BASELINE config 4 at one GPU's share: 128 pictures in 7 launches of a few microseconds each) are launch-latency
+     * bound: their replay goes through a HIP graph of the pass, captured once per flush */
+    hipGraphExec_t graph_exec[3] = { nullptr, nullptr, nullptr };   /* per `what` of hvq_replay_stage */
+    bool graph_tried[3] = { false, false, false };
     std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
     HvqStats stats{};
     double parse_seconds = 0;
@@ -275,6 +286,9 @@ struct HvqContext {
     double gpu_parse_ms = 0;           /* device time of the parse kernel of the last flush */
     uint32_t gpu_parse_retried = 0;    /* pictures of the last flush the flat parse path handed to the chains */
     uint32_t *redo_dev = nullptr;      /* their indices, for the chains kernel */
+    uint8_t *rp_dev = nullptr;         /* blobs of the pictures parsed again on the host (overflow runs beyond the device parser's cap) */
+    size_t rp_cap = 0;
+    std::vector<uint8_t> rp_host;
     size_t redo_cap = 0;
     uint32_t fl_rowbuf = 0;
     /* streaming: the bitstream copy of the batch being queued runs on a worker while the batch in flight is finished */
@@ -283,6 +297,14 @@ struct HvqContext {
     int copy_rc = 0;
     std::string copy_err;
 };
+
+static void drop_graphs(HvqContext *c)
+{
+    for (int k = 0; k < 3; ++k) {
+        if (c->graph_exec[k]) { (void)hipGraphExecDestroy(c->graph_exec[k]); c->graph_exec[k] = nullptr; }
+        c->graph_tried[k] = false;
+    }
+}
 
 static int arena_reserve(HvqContext *c, size_t need)
 {
@@ -354,10 +376,20 @@ static double now_ms()
 /* A bitstream into the pinned arena with non-temporal stores: the arena is written once and read by the DMA engine, so fetching
  * its lines into the cache first (what a plain store does) doubles the memory traffic of a copy whose 160 MB per batch have to
  * fit into the 4.7 ms the GPU takes for the batch before (HVQM4_AMD_NT_COPY=0: memcpy). */
+static inline void cpu_relax()
+{
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
 static inline void copy_to_arena(uint8_t *dst, const uint8_t *src, size_t len)
 {
     static const bool nt = !(getenv("HVQM4_AMD_NT_COPY") && atoi(getenv("HVQM4_AMD_NT_COPY")) == 0);
     size_t i = 0;
+#if defined(__x86_64__)
     if (nt && ((uintptr_t)dst & 15u) == 0 && len >= 4096) {
         for (; i + 64 <= len; i += 64) {
             const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 16)),
@@ -366,6 +398,9 @@ static inline void copy_to_arena(uint8_t *dst, const uint8_t *src, size_t len)
             _mm_stream_si128((__m128i *)(dst + i + 32), c); _mm_stream_si128((__m128i *)(dst + i + 48), d);
         }
     }
+#else
+    (void)nt;
+#endif
     memcpy(dst + i, src + i, len - i);
 }
 
@@ -446,7 +481,9 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->pj_dev) (void)hipFree(c->pj_dev);
     if (c->np_dev) (void)hipFree(c->np_dev);
     if (c->host_arena) (void)hipHostFree(c->host_arena);
+    drop_graphs(c);
     if (c->redo_dev) (void)hipFree(c->redo_dev);
+    if (c->rp_dev) (void)hipFree(c->rp_dev);
     if (c->dev_arena) (void)hipFree(c->dev_arena);
     if (c->host_arena_alt) (void)hipHostFree(c->host_arena_alt);
     if (c->dev_arena_alt) (void)hipFree(c->dev_arena_alt);
@@ -526,6 +563,7 @@ HVQ_EXPORT int hvq_stream_close(HvqContext *c, int sid)
     HIPCHK(hipFree(s.dev)); s.dev = nullptr;
     if (s.nest_keep) { HIPCHK(hipFree(s.nest_keep)); s.nest_keep = nullptr; }
     c->launches.clear();               /* the resident batch may reference the freed slots: no replay after a close */
+    drop_graphs(c);
     s.open = false;
     return HVQ_OK;
 }
@@ -883,7 +921,11 @@ static int submit_device(HvqContext *c, int n, const int *streams, const int *fr
                 const size_t span = align_up(j.lens[(size_t)i] + 32, 256);
                 copy_to_arena(dst, j.pics[(size_t)i], j.lens[(size_t)i]);
                 memset(dst + j.lens[(size_t)i], 0, span - j.lens[(size_t)i]);
+#if defined(__x86_64__)
                 _mm_sfence();                            /* the streamed lines are in memory before the chunk's upload is queued */
+#else
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+#endif
                 left[(size_t)chunk_of[(size_t)i]].fetch_sub(1, std::memory_order_release);
                 any = true;
             }
@@ -1086,7 +1128,7 @@ static int device_parse_finish(HvqContext *c)
         static const bool spin = !(getenv("HVQM4_AMD_SPIN_WAIT") && atoi(getenv("HVQM4_AMD_SPIN_WAIT")) == 0);
         if (spin) {
             hipError_t q;
-            while ((q = hipEventQuery(c->ev_parse)) == hipErrorNotReady) { for (int k = 0; k < 32; ++k) __builtin_ia32_pause(); }
+            while ((q = hipEventQuery(c->ev_parse)) == hipErrorNotReady) { for (int k = 0; k < 32; ++k) cpu_relax(); }
             HIPCHK(q);
         } else HIPCHK(hipEventSynchronize(c->ev_parse));
     }
@@ -1182,13 +1224,54 @@ static int device_parse_finish(HvqContext *c)
         if (want_timing_print) fprintf(stderr, "hvqm4_amd parse: %u of %zu pictures handed to the chains; decode wave waited %.1f rounds per picture\n",
                                        retried, idx.size(), (double)spins / (double)idx.size());
     }
+    /* Overflow-symbol runs that outlast the device parser's cap (GP_SOVF_CAP symbols; the picture comes back HVQ_F_CAPPED): the
+     * reference sums for as long as the stream says (h4m:654-677), and so does the HOST parser since round 5 -- bounded by the bits
+     * the picture has left.  Such a picture (nothing an encoder writes; rounds 3-4 refused it) is parsed once more, here, from its
+     * bitstream in the pinned arena; its blob replaces the device parser's, an I picture's nest is put where the stream's later
+     * pictures look for it.  What even the host parser cannot end (a one-leaf tree outside the window) stays refused. */
+    c->rp_host.clear();
     for (size_t k = 0; k < idx.size(); ++k) {
         Pending &p = c->fl_pending[idx[k]];
+        const size_t raw_len = jobs_len_of(c, k);
         p.status = (int)res[k].status;                 /* judged per picture by flush_end: one bad clip must not poison the batch */
         p.max_items = res[k].max_items; p.max_pairs = res[k].max_pairs;
         p.flags = res[k].flags;
         p.pool_dwords = res[k].pool_dwords;
+        p.redo = false;
+        if (!p.status && (p.flags & HVQ_F_CAPPED) && !p.dropped && raw_len) {
+            Stream &s = c->streams[(size_t)p.stream];
+            const size_t bound = hvq_parser_blob_bound(s.parser), off = align_up(c->rp_host.size(), 256);
+            c->rp_host.resize(off + bound + 2048);
+            size_t out_len = 0;
+            const int ft = p.kind == HVQ_PIC_I ? HVQ_FRAME_I : p.kind == HVQ_PIC_P ? HVQ_FRAME_P : HVQ_FRAME_B;
+            const int rcp = hvq_parse_picture(s.parser, ft, c->fl_host + p.blob_off, raw_len, c->rp_host.data() + off, bound, &out_len);
+            const HvqPicHeader *hd = (const HvqPicHeader *)(c->rp_host.data() + off);
+            if (rcp == HVQ_OK && !(hd->flags & HVQ_F_CAPPED)) {
+                p.redo = true; p.redo_off = off; p.redo_hd = *hd;
+                out_len = align_up(out_len, 256);
+                if (p.kind == HVQ_PIC_I) hvq_parser_packed_nest(s.parser, c->rp_host.data() + off + out_len);   /* behind the blob: always, not only when the blob has one */
+                c->rp_host.resize(off + out_len + (p.kind == HVQ_PIC_I ? align_up(GP_ALIGN16(HVQ_NESTP_BYTES), 256) : 0));
+                p.flags = hd->flags; p.pool_dwords = hd->pool_dwords; p.max_items = hd->max_items; p.max_pairs = hd->max_pairs;
+                p.blob_len = hd->total_bytes;
+                continue;
+            }
+            c->rp_host.resize(off);                      /* still capped (or unparsable): refused by flush_end */
+        }
         p.blob_len = res[k].total_bytes;
+    }
+    if (!c->rp_host.empty()) {
+        if (c->rp_host.size() > c->rp_cap) {
+            if (c->rp_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->rp_dev)); c->rp_dev = nullptr; c->rp_cap = 0; }
+            HIPCHK(hipMalloc((void **)&c->rp_dev, c->rp_host.size() * 2));
+            c->rp_cap = c->rp_host.size() * 2;
+        }
+        { int rcu = staged_upload(c, c->fl_arena_id, 4, c->rp_dev, c->rp_host.data(), c->rp_host.size()); if (rcu) return rcu; }
+        for (size_t k = 0; k < idx.size(); ++k) {
+            const Pending &p = c->fl_pending[idx[k]];
+            if (p.redo && p.kind == HVQ_PIC_I && p.dev_nest)
+                HIPCHK(hipMemcpyAsync((void *)(uintptr_t)p.dev_nest, c->rp_dev + p.redo_off + align_up(p.redo_hd.total_bytes, 256),
+                                      GP_ALIGN16(HVQ_NESTP_BYTES), hipMemcpyDeviceToDevice, c->stream));
+        }
     }
     return HVQ_OK;
 }
@@ -1341,6 +1424,7 @@ static int flush_abandon(HvqContext *c, int rc)
     c->fl_pending.clear();
     c->fl_idx.clear();
     c->launches.clear();                           /* nothing coherent to replay */
+    drop_graphs(c);
     return rc;
 }
 #define HIPCHK_FL(expr)                                                                                              \
@@ -1436,14 +1520,15 @@ static int flush_end(HvqContext *c)
         const Pending &p = c->fl_pending[i];
         const Stream &s = c->streams[(size_t)p.stream];
         HvqPicHeader hdev;
-        if (p.dev) {                                   /* geometry from the stream, per-picture fields from the parse result */
+        if (p.dev && !p.redo) {                        /* geometry from the stream, per-picture fields from the parse result */
             hdev = s.layout;
             hdev.pic_kind = (uint8_t)p.kind; hdev.unk_shift = (uint8_t)p.unk_shift; hdev.flags = p.flags;
             if (p.kind == HVQ_PIC_I) hdev.mv_off = 0;
             hdev.nest_off = 1;
         }
-        const HvqPicHeader *hd = p.dev ? &hdev : (const HvqPicHeader *)(c->fl_host + p.blob_off);
-        const uint64_t blob = p.dev ? p.dev_blob : (uint64_t)(uintptr_t)(c->fl_dev + p.blob_off);
+        /* a GPU-parsed picture that was parsed again on the host (device_parse_finish): the host parser's blob and header */
+        const HvqPicHeader *hd = p.redo ? &p.redo_hd : p.dev ? &hdev : (const HvqPicHeader *)(c->fl_host + p.blob_off);
+        const uint64_t blob = p.redo ? (uint64_t)(uintptr_t)(c->rp_dev + p.redo_off) : p.dev ? p.dev_blob : (uint64_t)(uintptr_t)(c->fl_dev + p.blob_off);
         const uint64_t dst = (uint64_t)(uintptr_t)s.slot_ptr(p.dst);
         j.ring = (uint64_t)(uintptr_t)s.dev;                 /* every reference read is ring + a 32-bit offset */
         j.ref0_off = (uint32_t)(s.slot_ptr(p.ref0) - s.dev);
@@ -1457,7 +1542,7 @@ static int flush_end(HvqContext *c)
         j.flags = (hd->flags & 0xFFFFu) | ((uint32_t)hd->pic_kind << HVQ_JOB_KIND_SHIFT) | ((uint32_t)hd->unk_shift << HVQ_JOB_UNK_SHIFT);
         j.width = hd->width;
         j.mcb_w = hd->mcb_w;
-        j.pool_dwords = p.dev ? p.pool_dwords : hd->pool_dwords;
+        j.pool_dwords = (p.dev && !p.redo) ? p.pool_dwords : hd->pool_dwords;
         j.total_tiles = p.dropped ? 0u : hd->tile_first[3];          /* 0: the tile records of this picture become padding entries */
         if (p.dropped) continue;
         {   /* the picture's tile queues (HVQM4_AMD_TILE_QUEUES=1): per tile a record, a literal list, and item and pair lists sized
@@ -1564,7 +1649,8 @@ static int flush_end(HvqContext *c)
                  * whose payload exceeds it */
                 static const uint32_t pool_lim = getenv("HVQM4_AMD_POOL_CAP") ? (uint32_t)std::max(0, atoi(getenv("HVQM4_AMD_POOL_CAP"))) : 1536u;
                 *pool = std::min(pool_lim, t * (mp + 2u * mi + 128u));
-                return (hvq_recon_inline_static_lds(t, ic) + 4u * (*pairs + *pool) + 511u) & ~511u;
+                if (*pool) *pool = (*pool + 4u + 3u) & ~3u;      /* + 4: the staged range starts at the 16-byte boundary below the tile's first dword */
+                return (hvq_recon_inline_static_lds(t, ic) + hvq_recon_inline_dyn_lds(*pairs, *pool) + 511u) & ~511u;
             };
             uint32_t cap1, pr1, po1, cap2, pr2, po2;
             const uint32_t lds1 = sized(1, &cap1, &pr1, &po1), lds2 = sized(2, &cap2, &pr2, &po2);
@@ -1579,6 +1665,7 @@ static int flush_end(HvqContext *c)
         st.workgroups += L.workgroups;
     }
     c->launches = c->fl_launches;
+    drop_graphs(c);                    /* a graph of the previous batch's pass is stale now */
     st.launches = (uint32_t)c->launches.size();
     st.parse_seconds = c->parse_seconds;
     st.gpu_parse_ms = st.gpu_parsed ? c->gpu_parse_ms : 0.0;
@@ -1651,6 +1738,42 @@ HVQ_EXPORT int hvq_sync(HvqContext *c)
     return HVQ_OK;
 }
 
+/* One pass over the resident batch: what = 0 the reconstruction launches, 1 queue build + launches, 2 queue build only.  A small batch
+ * (few workgroups per launch: the launches themselves are what takes the time) replays from a HIP graph of the pass, captured on first
+ * use and dropped by the next flush; HVQM4_AMD_GRAPH=0 keeps plain launches, HVQM4_AMD_GRAPH=1 uses the graph for any size. */
+static int run_pass(HvqContext *c, int what)
+{
+    if (what != 0) { int rc = run_queue_build(c, false); if (rc) return rc; }
+    if (what != 2) { int rc = run_launches(c); if (rc) return rc; }
+    return HVQ_OK;
+}
+
+static int replay_passes(HvqContext *c, int what, int reps)
+{
+    static const int genv = getenv("HVQM4_AMD_GRAPH") ? atoi(getenv("HVQM4_AMD_GRAPH")) : -1;
+    const bool small = c->stats.workgroups && c->stats.workgroups <= 32768u;
+    bool use_graph = genv != 0 && (genv > 0 || small) && c->selfrefs.empty() && reps > 1;
+    if (use_graph && !c->graph_exec[what] && !c->graph_tried[what]) {
+        c->graph_tried[what] = true;
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int rc = run_pass(c, what);
+            const hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (rc == HVQ_OK && e == hipSuccess && g) {
+                if (hipGraphInstantiate(&c->graph_exec[what], g, nullptr, nullptr, 0) != hipSuccess) c->graph_exec[what] = nullptr;
+            }
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+        }
+    }
+    use_graph = use_graph && c->graph_exec[what];
+    for (int r = 0; r < reps; ++r) {
+        if (use_graph) HIPCHK(hipGraphLaunch(c->graph_exec[what], c->stream));
+        else { int rc = run_pass(c, what); if (rc) return rc; }
+    }
+    return HVQ_OK;
+}
+
 HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
 {
     if (!c || reps < 0) return fail(HVQ_E_ARG, "bad arguments");
@@ -1661,7 +1784,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
     if (!c->pending.empty()) return fail(HVQ_E_STATE, "pictures queued since the last flush");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; ++r) { int rc = run_launches(c); if (rc) return rc; }
+    { int rc = replay_passes(c, 0, reps); if (rc) return rc; }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0;
@@ -1723,10 +1846,7 @@ HVQ_EXPORT int hvq_replay_stage(HvqContext *c, int reps, int what, float *gpu_ms
     if (!c->pending.empty()) return fail(HVQ_E_STATE, "pictures queued since the last flush");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    for (int r = 0; r < reps; ++r) {
-        { int rc = run_queue_build(c, false); if (rc) return rc; }
-        if (what == 1) { int rc = run_launches(c); if (rc) return rc; }
-    }
+    { int rc = replay_passes(c, what, reps); if (rc) return rc; }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0;
@@ -1989,7 +2109,8 @@ struct SdkHeader {          /* lives at the start of the caller's work buffer */
     SdkBinding *binding;
 };
 
-std::mutex g_sdk_mu;                    /* the registry of bindings and the probe context only */
+std::mutex g_sdk_mu;                    /* the registry of bindings */
+std::mutex g_sdk_ctx_mu;                /* the probe context (its own lock: it is taken by a decode that holds its binding's lock) */
 HvqContext *g_sdk_ctx = nullptr;
 std::set<SdkBinding *> g_bindings;
 
@@ -2035,14 +2156,25 @@ void sdk_release_locked(SdkHeader *hd)
     hd->magic = 0; hd->binding = nullptr;
 }
 
-/* the SeqObj's binding, or nullptr + error */
-SdkBinding *sdk_lookup(SeqObj *seq)
+/* The SeqObj's binding with ITS lock held, or an unlocked lock + error.  The binding's lock is taken while the registry lock is still
+ * held (hand-over): a HVQM4SetBuffer / HVQM4ReleaseBuffer of the same SeqObj on another thread can then no longer free the binding
+ * between the look-up and the decode's own lock (advisor finding of round 4: it could).  try_lock + retry, so that a second thread
+ * decoding on the SAME SeqObj (it waits) never blocks the registry for the players of other SeqObjs; nothing that holds a binding's
+ * lock waits for the registry lock (the probe context has a lock of its own), so the order registry -> binding cannot deadlock. */
+std::unique_lock<std::mutex> sdk_lookup(SeqObj *seq, SdkBinding **out)
 {
-    std::lock_guard<std::mutex> lk(g_sdk_mu);
-    if (!seq || !seq->state) { fail(HVQ_E_ARG, "SeqObj has no work buffer (call HVQM4SetBuffer)"); sdk_fail(HVQ_E_ARG); return nullptr; }
-    SdkHeader *hd = (SdkHeader *)seq->state;
-    if (hd->magic != SDK_MAGIC || !g_bindings.count(hd->binding)) { fail(HVQ_E_STATE, "work buffer was not initialised by HVQM4SetBuffer"); sdk_fail(HVQ_E_STATE); return nullptr; }
-    return hd->binding;
+    *out = nullptr;
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(g_sdk_mu);
+            if (!seq || !seq->state) { fail(HVQ_E_ARG, "SeqObj has no work buffer (call HVQM4SetBuffer)"); sdk_fail(HVQ_E_ARG); return {}; }
+            SdkHeader *hd = (SdkHeader *)seq->state;
+            if (hd->magic != SDK_MAGIC || !g_bindings.count(hd->binding)) { fail(HVQ_E_STATE, "work buffer was not initialised by HVQM4SetBuffer"); sdk_fail(HVQ_E_STATE); return {}; }
+            std::unique_lock<std::mutex> bl(hd->binding->mu, std::try_to_lock);
+            if (bl.owns_lock()) { *out = hd->binding; return bl; }
+        }
+        std::this_thread::yield();
+    }
 }
 
 /* (re)open the device stream when the 1.3/1.5 switch byte changed (h4m:2414-2417); called with the binding's lock held */
@@ -2053,7 +2185,7 @@ bool sdk_open(SdkBinding *b, SeqObj *seq)
     if (b->stream < 0) {
         if (!b->ctx) {
             {   /* the context HVQM4InitDecoder probed the device with serves the first SeqObj */
-                std::lock_guard<std::mutex> lk(g_sdk_mu);
+                std::lock_guard<std::mutex> lk(g_sdk_ctx_mu);
                 b->ctx = g_sdk_ctx; g_sdk_ctx = nullptr;
             }
             if (!b->ctx) {
@@ -2078,9 +2210,9 @@ bool sdk_open(SdkBinding *b, SeqObj *seq)
  * valid for players that do not touch decoded pictures, which the SDK contract does not promise (hence opt-in). */
 void sdk_decode(SeqObj *seq, int ftype, const uint8_t *frame, void *present, const void *past, const void *future)
 {
-    SdkBinding *b = sdk_lookup(seq);
+    SdkBinding *b = nullptr;
+    std::unique_lock<std::mutex> lk = sdk_lookup(seq, &b);
     if (!b) return;
-    std::lock_guard<std::mutex> lk(b->mu);
     /* HVQM4_AMD_SDK_TIMING=1: where a call's time goes, on stderr (development aid) */
     static const bool timing = getenv("HVQM4_AMD_SDK_TIMING") != nullptr;
     double tm[6] = { 0, 0, 0, 0, 0, 0 };
@@ -2166,7 +2298,7 @@ HVQ_EXPORT void HVQM4InitDecoder(void)
 {
     /* the reference fills divTable/mcdivTable here (h4m:265-278); ours are compile-time constants
      * in the kernel.  Probe the device early so a missing GPU is reported at init time. */
-    std::lock_guard<std::mutex> lk(g_sdk_mu);
+    std::lock_guard<std::mutex> lk(g_sdk_ctx_mu);
     (void)sdk_context();
 }
 

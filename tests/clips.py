@@ -31,7 +31,7 @@ SMALL = [
     # fills the last cells of tests/test_fixture_coverage.py: inter kind 8 in a chroma plane, past (P) and future (B)
     ("weird160x128", SynthConfig(width=160, height=128, gop="IPPBBPBB", seed=34, weird_kinds=True)),
     # one DC delta of 300 overflow symbols (the reference sums for as long as the stream says, h4m:654-664): decoded like the
-    # reference; beyond the parsers' cap (4096 symbols) a picture is refused, never decoded differently (tests/test_gpu_reject.py)
+    # reference; beyond the fast parsers' cap (4096 symbols) the host parser follows the run to its end (round 5, tests/test_gpu_reject.py)
     ("longescape64x48", SynthConfig(width=64, height=48, gop="IPB", seed=35, long_escape=300)),
     # P pictures with future-referencing (type 2) macroblocks: the reference passes the picture being written as `future`
     # (h4m:2058-2061), so they read it in raster-order-dependent states and, where nothing has been written yet, what the player's

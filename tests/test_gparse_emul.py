@@ -148,7 +148,7 @@ def test_flat_path_hands_unusual_pictures_to_the_chains(emul):
     a = np.zeros(bound, dtype=np.uint8)
     b = np.zeros(bound, dtype=np.uint8)
     nest = np.zeros(NESTP, dtype=np.uint8)
-    retried = 0
+    retried = capped = 0
     for ft, pic in pics:
         n = C.c_size_t(0)
         rc = l.hvq_parse_picture(prs, ft, pic + b"\0" * 8, len(pic), a.ctypes.data, bound, C.byref(n))
@@ -158,14 +158,20 @@ def test_flat_path_hands_unusual_pictures_to_the_chains(emul):
         assert (rc == 0) == (res.status == 0)
         if rc == 0:
             ha = header(a.tobytes())
-            o, npool = ha["pool_off"], 4 * ha["pool_dwords"]
-            assert np.array_equal(a[o:o + npool], b[o:o + npool])
-            for i in range(3):
-                nmap = 2 * (ha["hb"][i] + 2) * (ha["vb"][i] + 2)
-                o = ha["map_off"][i]
-                assert np.array_equal(a[o:o + nmap], b[o:o + nmap])
+            # a run that never ends: both parsers flag the picture (HVQ_F_CAPPED, 0x40) and it is refused -- since round 5 the host
+            # parser follows a run beyond the fast cap to the end of the picture first and stops decoding values once the flag is
+            # up, so the blobs of a REFUSED picture are no longer comparable (nothing ever reads them); an unflagged one must match
+            assert bool(ha["flags"] & 0x40) == bool(res.flags & 0x40)
+            capped += bool(ha["flags"] & 0x40)
+            if not ha["flags"] & 0x40:
+                o, npool = ha["pool_off"], 4 * ha["pool_dwords"]
+                assert np.array_equal(a[o:o + npool], b[o:o + npool])
+                for i in range(3):
+                    nmap = 2 * (ha["hb"][i] + 2) * (ha["vb"][i] + 2)
+                    o = ha["map_off"][i]
+                    assert np.array_equal(a[o:o + nmap], b[o:o + nmap])
         retried += res.pad[0]
-    assert retried >= 1
+    assert retried >= 1 and capped >= 1
     l.hvq_parser_destroy(prs)
 
 

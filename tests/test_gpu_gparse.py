@@ -27,7 +27,7 @@ def test_gpu_parsed_clip_matches_oracle(gpu_ctx, case):
     got = batch.decode_clip(gpu_ctx, clip.data, gpu_parse=True)
     assert np.array_equal(got, want)
     if case in clips.SMALL and bridge.have_ref():       # ... and the unmodified reference decoder itself, when it is on this box (oracle/_ref)
-        assert np.array_equal(got, bridge.ref_decode(clip.data, clip.n_pictures)), "GPU-parsed pictures differ from the compiled reference"
+        assert np.array_equal(got, bridge.ref_decode(clip.data, clip.n_pictures)[0]), "GPU-parsed pictures differ from the compiled reference"
     st = gpu_ctx.stats()
     assert st.gpu_parsed == clip.n_pictures
     if not os.environ.get("HVQM4_AMD_PARSE_FLAT") == "0":

@@ -27,7 +27,7 @@ def test_batched_path_matches_oracle(case, gpu_ctx):
     # the chain is closed HERE, on the GPU box: when the compiled reference travelled with the snapshot (oracle/_ref), the same
     # pictures must equal what the unmodified reference decoder produces -- not only what this repo's restatement of it does
     if case in clips.SMALL and bridge.have_ref():
-        ref = bridge.ref_decode(clip.data, clip.n_pictures)
+        ref = bridge.ref_decode(clip.data, clip.n_pictures)[0]
         assert np.array_equal(got, ref), "GPU vs compiled reference: " + _first_diff(got, ref)
 
 

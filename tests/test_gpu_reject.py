@@ -1,10 +1,12 @@
 """GPU: pictures this back end refuses and what a refusal leaves behind.
 
-* A picture with an overflow-symbol run beyond the parsers' cap (4096 symbols; the reference sums for as long as the stream
-  says, h4m:654-677): HVQ_F_CAPPED -- the value would differ from the reference's.  Every entry point reports
+* A picture with an overflow-symbol run that NEVER ends (a one-leaf tree whose only value lies outside the overflow window: the
+  reference sums for as long as the stream says, h4m:654-677, and would not return): HVQ_F_CAPPED.  Every entry point reports
   HVQ_E_UNSUPPORTED instead of decoding something else, `present` stays untouched, the stream resumes at its next I picture.
-  (A 300-symbol run decodes exactly: tests/clips.py longescape64x48.  P pictures with future-referencing macroblocks,
-  refused in round 2, are decoded like the reference now: tests/clips.py pselfref*.)
+  (A run that is merely LONG -- 5 000 symbols, beyond the fast parsers' cap of 4096 -- is decoded like the reference since round 5:
+  the host parser follows it to its end, bounded by the bits the picture has left, and a GPU-parsed picture that comes back capped
+  is parsed again on the host; rounds 3-4 refused it.  P pictures with future-referencing macroblocks, refused in round 2, are
+  decoded like the reference: tests/clips.py pselfref*.)
 * One bad picture must not poison the batch: the other streams of the same flush decode bit-exactly."""
 import numpy as np
 import pytest
@@ -14,14 +16,37 @@ from tests import clips
 pytestmark = pytest.mark.gpu
 
 
-def _self_ref_clip(seed=5, w=64, h=48, gop="IPBBPB"):
-    """a clip whose SECOND picture (the first P) carries an overflow-symbol run of 5000 symbols: over the cap"""
+def _long_run_clip(seed=5, w=64, h=48, gop="IPBBPB"):
+    """a clip whose SECOND picture (the first P) carries an overflow-symbol run of 5000 symbols: over the fast parsers' cap"""
     from hvqm4_amd.synth import SynthConfig, make_clip
     return make_clip(SynthConfig(width=w, height=h, gop=gop, seed=seed, long_escape_pb=5000))
 
 
+class _Patched:
+    """a clip with one picture replaced (what the container iterator would hand out)"""
+    def __init__(self, clip, pics):
+        self.width, self.height, self.version, self.data, self.n_pictures, self.pics = clip.width, clip.height, clip.version, clip.data, clip.n_pictures, pics
+
+
+def _self_ref_clip(seed=5, w=64, h=48, gop="IPBBPB"):
+    """a clip whose SECOND picture (the first P) can never be decoded like the reference: its luma DC tree is a single leaf 0x7F
+    with dc_shift 0, outside the overflow window (-128, 127) -- every overflow read of the section spins for ever"""
+    import struct
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    clip = make_clip(SynthConfig(width=w, height=h, gop=gop, seed=seed))
+    pics = _pics(clip)
+    b = bytearray(pics[1][1])
+    off = 8 + 0x44 + struct.unpack_from(">I", b, 8 + 4 * 4)[0] + 4           # section 4 = DC buffer of the luma plane
+    b[0] = 0
+    b[off:off + 2] = b"\x3f\x80"
+    pics[1] = (pics[1][0], bytes(b))
+    return _Patched(clip, pics)
+
+
 def _pics(cl):
     from hvqm4_amd.container import video_pictures
+    if hasattr(cl, "pics"):
+        return list(cl.pics)
     return [(ft, bytes(p)) for ft, _d, p in video_pictures(cl.data)]
 
 
@@ -35,7 +60,7 @@ def test_host_parsed_capped_picture_is_refused_and_the_stream_resumes_at_an_I_pi
     sg = gpu_ctx.open_stream(good.width, good.height, 2, 2, True, len(gp) + 3)
     gpu_ctx.submit(sb, *bp[0])                                   # the I picture is fine
     with pytest.raises(HvqError) as e:
-        gpu_ctx.submit(sb, *bp[1])                               # P with an overflow run over the cap
+        gpu_ctx.submit(sb, *bp[1])                               # P with an overflow run that never ends
     assert e.value.code == HVQ_E_UNSUPPORTED and "overflow-symbol" in str(e.value)
     with pytest.raises(HvqError) as e:
         gpu_ctx.submit(sb, *bp[2])                               # the B picture would reference the refused P
@@ -209,3 +234,26 @@ def test_ring_of_4_gib_is_refused_before_anything_is_allocated(gpu_ctx):
     assert e.value.code == HVQ_E_OVERFLOW
     sid = gpu_ctx.open_stream(64, 48, 2, 2, True, 4)
     gpu_ctx.close_stream(sid)
+
+
+def test_an_overflow_run_beyond_the_fast_cap_is_decoded_like_the_reference_by_every_entry_point(gpu_ctx):
+    """5 000 overflow symbols in one value (the fast parsers stop at 4096): the reference sums them all (h4m:654-677).  SDK symbols,
+    batched path with the host parser and batched path with the GPU parser (whose capped picture is parsed again on the host) must
+    give the oracle's pictures -- and the compiled reference's, when it is on this box."""
+    from hvqm4_amd import sdk
+    from hvqm4_amd.batch import decode_clip
+    from oracle import bridge
+    for seed, gop in ((5, "IPBBPB"), (12, "IPB")):
+        clip = _long_run_clip(seed=seed, gop=gop)
+        want = bridge.oracle_decode(clip.data, clip.n_pictures)
+        if bridge.have_ref():
+            assert np.array_equal(want, bridge.ref_decode(clip.data, clip.n_pictures)[0])
+        got = decode_clip(gpu_ctx, clip.data)
+        assert np.array_equal(got, want), "host parser"
+        got = decode_clip(gpu_ctx, clip.data, gpu_parse=True)
+        assert np.array_equal(got, want), "GPU parser + host re-parse of the capped picture"
+        assert gpu_ctx.stats().dropped == 0
+        pl = sdk.Player(clip.width, clip.height, 2, 2, True)
+        got = np.stack([pl.decode(ft, p) for ft, p in _pics(clip)])
+        pl.close()
+        assert np.array_equal(got, want), "SDK symbols"

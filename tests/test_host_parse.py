@@ -120,3 +120,49 @@ def test_sdk_host_side_stays_inside_exactly_sized_frames_under_asan(tmp_path):
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
         assert "legal lengths exact" in r.stdout
+
+
+def test_overflow_runs_beyond_the_fast_cap_are_followed_to_their_end():
+    """The reference sums overflow symbols for as long as the stream says (h4m:654-677).  One value of 5 000 symbols -- beyond the
+    4096 the fast loops of both parsers stop at -- must come out of the host parser exactly (rounds 3-4 flagged the picture
+    HVQ_F_CAPPED and refused it), in an I picture's DC deltas and in a P picture's scalars; against the oracle and, when it is
+    built here, against the compiled reference."""
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    from oracle import bridge
+    for cfg in (SynthConfig(width=64, height=48, gop="IPBBPB", seed=5, long_escape_pb=5000),
+                SynthConfig(width=64, height=48, gop="IPB", seed=35, long_escape=5000),
+                SynthConfig(width=96, height=64, gop="IPB", seed=8, long_escape=9000, long_escape_pb=7000)):
+        clip = make_clip(cfg)
+        want = bridge.oracle_decode(clip.data, clip.n_pictures)
+        if bridge.have_ref():
+            assert np.array_equal(want, bridge.ref_decode(clip.data, clip.n_pictures)[0])
+        got, flags = decode_via_descriptors(clip)
+        assert not flags & 0x40, "a run that ends inside its picture must not be flagged CAPPED"
+        assert np.array_equal(got, want)
+
+
+def test_a_run_that_never_ends_is_flagged_and_costs_no_time():
+    """a one-leaf DC tree whose value lies outside the overflow window: the reference would sum for ever.  The host parser gives up
+    at the end of the picture (HVQ_F_CAPPED -> the back end refuses the picture) and does not spend the rest of a full-size picture
+    spinning through the same cap"""
+    import time
+    from hvqm4_amd._lib import lib
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    l = lib()
+    clip = make_clip(SynthConfig(width=640, height=480, gop="IP", seed=77))
+    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp_h, clip.samp_v, 1)
+    bound = l.hvq_parser_blob_bound(prs)
+    blob = np.zeros(bound, dtype=np.uint8)
+    t0 = time.time()
+    for ft, pic in zip(clip.kinds, clip.pictures):
+        p = bytearray(pic)
+        data = 8 + (0x40 if ft == I_FRAME else 0x44)
+        off = data + struct.unpack_from(">I", p, 8 + 4 * 4)[0] + 4          # section 4 = DC buffer of the luma plane
+        p[0] = 0
+        p[off:off + 2] = b"\x3f\x80"                                         # tree = single leaf 0x7F, window (-128, 127)
+        n = C.c_size_t(0)
+        rc = l.hvq_parse_picture(prs, ft, bytes(p) + b"\0" * 8, len(p), blob.ctypes.data, bound, C.byref(n))
+        assert rc == 0
+        assert struct.unpack_from("<I", blob[:128].tobytes(), 20)[0] & 0x40
+    assert time.time() - t0 < 2.0
+    l.hvq_parser_destroy(prs)
