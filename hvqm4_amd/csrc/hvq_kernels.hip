@@ -98,32 +98,28 @@ __device__ __forceinline__ McRows mc_load(const GLB uint8_t *ref, i32 a, i32 str
 
 __device__ __forceinline__ Blk mc_filter(const McRows &rows, int hx, int hy)
 {
+    /* ONE formula for the four half-sample cases (round 5; rounds 1-4 ran two code paths side by side in every wave):
+     * (a + b' + c' + d' + 2) >> 2 with b' = the right neighbour when hx, else a itself, and c', d' = the same pair of the row below
+     * when hy, else of this row -- (4a + 2) >> 2 = a, (2a + 2b + 2) >> 2 = (a + b + 1) >> 1, and the 4-tap case as it is.
+     * Four samples per instruction: with h = floor((a + b') / 2) per row (v_lerp_u8, no rounding bit) the result is
+     * (h + h' + 1) >> 1, plus one when both pair sums were odd and h + h' is even. */
     const uint64_t *q = rows.q;
     Blk o;
-    if (hx & hy) {
-        /* (a+b+c+d+2)>>2 exactly, four samples per instruction: with h = floor((a+b)/2), v = floor((c+d)/2) (v_lerp_u8,
-         * no rounding bit) the result is (h+v+1)>>1, plus one when both pair sums were odd and h+v is even */
-        u32 h[5], x[5];
+    /* rows are consumed one at a time (the pair of the previous row stays in two registers): all five at once cost six registers more
+     * than the kernel has */
+    u32 hp, xp;
+    {
+        const u32 p = (u32)q[0], n = hx ? (u32)(q[0] >> 8) : p;
+        hp = __builtin_amdgcn_lerp(p, n, 0u); xp = p ^ n;
+    }
 #pragma unroll
-        for (int y = 0; y < 5; ++y) {
-            const u32 p = (u32)q[y], n = (u32)(q[y] >> 8);
-            h[y] = __builtin_amdgcn_lerp(p, n, 0u);
-            x[y] = p ^ n;
-        }
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const u32 t = __builtin_amdgcn_lerp(h[y], h[y + 1], 0x01010101u);
-            o.r[y] = t + (x[y] & x[y + 1] & ~(h[y] ^ h[y + 1]) & 0x01010101u);
-        }
-    } else {
-        /* copy, horizontal or vertical 2-tap: v_lerp_u8 of the row with itself is the identity, so the three cases
-         * are one straight-line sequence with selected operands (no divergence) */
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            const u32 p = (u32)q[y];
-            const u32 other = hx ? (u32)(q[y] >> 8) : hy ? (u32)q[y + 1] : p;
-            o.r[y] = __builtin_amdgcn_lerp(p, other, 0x01010101u);
-        }
+    for (int y = 0; y < 4; ++y) {
+        const u32 p = (u32)q[y + 1], n = hx ? (u32)(q[y + 1] >> 8) : p;
+        const u32 hn = __builtin_amdgcn_lerp(p, n, 0u), xn = p ^ n;
+        const u32 h1 = hy ? hn : hp, x1 = hy ? xn : xp;
+        const u32 t = __builtin_amdgcn_lerp(hp, h1, 0x01010101u);
+        o.r[y] = t + (xp & x1 & ~(hp ^ h1) & 0x01010101u);
+        hp = hn; xp = xn;
     }
     return o;
 }
@@ -142,6 +138,18 @@ __device__ __forceinline__ u32 udiv_small(u32 num, u32 den)
     i32 r = (i32)(num - __umul24(q, den));
     if (r < 0) q -= 1;
     else if ((u32)r >= den) q += 1;
+    return den ? q : 0u;
+}
+
+/* floor(N / den) for the two numerators the tables use (N = 256 with den <= 15, N = 4096 with den <= 255), 0 for den = 0, without the
+ * integer fix-up: where N / den is an integer den is a power of two and its reciprocal exact; everywhere else the quotient lies at
+ * least 1 / 255 below the next integer, a hundred times the error of v_rcp_f32 (1 ulp) and the multiply -- and the bias of 1 / 1024
+ * added before truncation covers the integer cases against a reciprocal that came out an ulp low.  Checked against the tables for
+ * every den by the parity suite's kernels on the GPU (tests/test_gpu_parity.py::test_table_divisions_on_the_gpu). */
+template <int N>
+__device__ __forceinline__ u32 udiv_table(u32 den)
+{
+    const u32 q = (u32)__builtin_fmaf(__builtin_amdgcn_rcpf((float)den), (float)N, 0.0009765625f);
     return den ? q : 0u;
 }
 
@@ -172,7 +180,7 @@ __device__ __forceinline__ u32 pack4(i32 a, i32 b, i32 c, i32 d)
  */
 __device__ __forceinline__ u32 basis_gain(u32 d, u32 lo, u32 hi)
 {
-    const u32 q = udiv_small(256u, (hi - lo) & 15u);
+    const u32 q = udiv_table<256>((hi - lo) & 15u);
     const u32 s = d >> 14;
     const u32 g = s * (q << 4);
     return (d & 0x2000u) ? 0u - g : g;
@@ -259,6 +267,16 @@ __device__ __forceinline__ void gather_window(u32 d, bool landscape, const GLB u
     }
 }
 
+/* four samples: arithmetic shift right, clamp to [0, 255], pack -- gfx950's v_ashr_pk_u8_i32 does two samples per instruction (it
+ * writes the low 16 bits of its destination and leaves the upper 16 as they were: the compiler's own pattern match of the clamp
+ * assumed them cleared and corrupted samples 2 and 3, section 6 item 1 of DESIGN.md; v_perm takes exactly the two valid bytes of each) */
+__device__ __forceinline__ u32 shr_sat_pack4(u32 a, u32 b, u32 c, u32 d, i32 s)
+{
+    const u32 lo = (u32)__builtin_amdgcn_ashr_pk_u8_i32((i32)a, (i32)b, (u32)s);
+    const u32 hi = (u32)__builtin_amdgcn_ashr_pk_u8_i32((i32)c, (i32)d, (u32)s);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
 /* intra AOT epilogue (h4m:1367-1376): r = wrap-exact accumulators */
 __device__ __forceinline__ Blk intra_finish(const u32 r[16], i32 V, i32 unk)
 {
@@ -269,8 +287,7 @@ __device__ __forceinline__ Blk intra_finish(const u32 r[16], i32 V, i32 unk)
     Blk o4;
 #pragma unroll
     for (int y = 0; y < 4; ++y)
-        o4.r[y] = pack4(sar(r[4 * y] + delta, unk), sar(r[4 * y + 1] + delta, unk),
-                        sar(r[4 * y + 2] + delta, unk), sar(r[4 * y + 3] + delta, unk));
+        o4.r[y] = shr_sat_pack4(r[4 * y] + delta, r[4 * y + 1] + delta, r[4 * y + 2] + delta, r[4 * y + 3] + delta, unk);
     return o4;
 }
 
@@ -284,33 +301,31 @@ __device__ __forceinline__ Blk predi_finish(const u32 r[16], Blk m, u32 p0, u32 
     u32 sum = 8;
 #pragma unroll
     for (int y = 0; y < 4; ++y) sum = __builtin_amdgcn_sad_u8(m.r[y], 0u, sum);
-    const i32 mean = (i32)(sum >> 4);
-    i32 px[16];
+    const u32 mean = sum >> 4;
     u32 lo = 255, hi = 0;
 #pragma unroll
     for (int y = 0; y < 4; ++y)
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            u32 v = (m.r[y] >> (8 * x)) & 0xFFu;
-            px[4 * y + x] = (i32)v;
+            const u32 v = (m.r[y] >> (8 * x)) & 0xFFu;
             lo = min(lo, v);
             hi = max(hi, v);
         }
-    const u32 addend = p0 - mean_aot;
-    const i32 gain = (i32)p1;
-    const u32 mcd = udiv_small(0x1000u, hi - lo);                    /* mcdivTable[max-min], h4m:272, 1407 */
-    const u32 factor = (u32)gain * mcd;
+    const u32 mcd = udiv_table<4096>(hi - lo);                       /* mcdivTable[max-min], h4m:272, 1407 */
+    const u32 factor = p1 * mcd;
+    /* value = r + addend + (px - mean) * factor  with addend = p0 - mean_aot, all in uint32 wrap arithmetic (h4m:1405-1416):
+     * = r + px * factor + (p0 - mean_aot - mean * factor) */
+    const u32 c = p0 - mean_aot - mean * factor;
     Blk o4;
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
-        i32 v[4];
+        u32 v[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const int i = 4 * y + x;
-            const u32 t = (u32)(px[i] - mean) * factor;
-            v[x] = sar(r[i] + addend + t, unk) + px[i];
+            const u32 px = (m.r[y] >> (8 * x)) & 0xFFu;                 /* extracted again: sixteen live samples are registers the kernel does not have */
+            v[x] = (u32)(((i32)(r[4 * y + x] + c + px * factor) >> unk) + (i32)px);    /* the sample is added BEHIND the shift: exactly so */
         }
-        o4.r[y] = pack4(v[0], v[1], v[2], v[3]);
+        o4.r[y] = shr_sat_pack4(v[0], v[1], v[2], v[3], 0);
     }
     return o4;
 }
@@ -827,7 +842,7 @@ extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *s
  */
 __device__ __forceinline__ u32 gain_q(u32 w0, u32 lo, u32 hi)
 {
-    const u32 q = udiv_small(256u, (hi - lo) & 15u);                /* divTable[max - min] = 16 * (256 / r), h4m:265-271 */
+    const u32 q = udiv_table<256>((hi - lo) & 15u);                 /* divTable[max - min] = 16 * (256 / r), h4m:265-271 */
     const u32 g = (w0 & 0x3FFFFu) * (q << 4);
     return (w0 & HVQ_PQ_NEG) ? 0u - g : g;
 }
@@ -1386,6 +1401,8 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     __syncthreads();
 
     /* ---- trip 2: the blocks' descriptors into registers; the tile range of the pool and the nest straight into LDS (LDS-DMA) ---- */
+    /* (wave_base through the VECTOR path -- one load, v_readlane -- was measured: -4 % dense, profiles/r05_recon_steps.txt; the scalar
+     * loads stay: their latency overlaps the map loads, a vector load's wait does not) */
     u32 plo = wave_base[tile0 * HVQ_NW];
     u32 phi = tile0 + (u32)ntl < total_tiles ? wave_base[(tile0 + (u32)ntl) * HVQ_NW] : pool_dwords;
     u32 wbase[TPW];
@@ -1652,13 +1669,11 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const u32 npairs = (serial || HVQ_ABL == 33) ? 0u : npI + npM;
 
     if (nitems) {
-        /* ---- phase B1: one lane per (item, basis) pair: intra pairs first, then the MC-residual ones ---- */
+        /* ---- phase B1: one lane per (item, basis) pair ---- */
         const i32 nstride = landscape ? 70 : 38;
-        for (u32 v = (u32)tid; v < npairs; v += HVQ_WG) {
-            const u32 pr = s_pair[v < npI ? v : pair_cap - 1u - (v - npI)];
-            const u32 it = pr & 511u;
-            const u32 d = pool_at(pr >> 9);
-            const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;                       /* h4m:683-711 */
+        /* one basis of item `it` (dword d of the pool, h4m:683-711): nest or window gather, gain, 16 products into the item's accumulators */
+        auto do_basis = [&](u32 it, u32 d) {
+            const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
             const u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
             const bool x2 = landscape ? sl : ss;
             const u32 y2 = landscape ? ss : sl;
@@ -1678,6 +1693,34 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                 gather_nest_q(o, x2, nstride << y2, s_nest, e, lo, hi);
             }
             basis_scatter<ITEMS_CAP>(gain_q(wq0, lo, hi), e, s_acc + it);
+        };
+        if (!serial) {
+            /* intra pairs on the FIRST lanes of the workgroup, MC-residual pairs on the LAST ones (round 5; they followed each other before):
+             * with at most 256 pairs no wave runs both gathers unless the two ranges meet inside it -- a dense tile has ~60 of each */
+            const bool psplit = npairs <= (u32)HVQ_WG;
+            for (u32 v = (u32)tid; v < (psplit ? (u32)HVQ_WG : npairs); v += HVQ_WG) {
+                u32 pi;                                                        /* list position: intra pairs from the bottom, MC-residual pairs from the top */
+                if (psplit) {
+                    const u32 back = (u32)(HVQ_WG - 1) - v;
+                    if (v < npI) pi = v;
+                    else if (back < npM) pi = pair_cap - 1u - back;
+                    else continue;
+                } else pi = v < npI ? v : pair_cap - 1u - (v - npI);
+                const u32 pr = s_pair[pi];
+                do_basis(pr & 511u, pool_at(pr >> 9));
+            }
+        } else {
+            /* more pairs than the launch's list holds (pathological streams; HVQM4_AMD_PAIR_CAP in the tests): one lane per ITEM walks its
+             * bases -- into the same accumulators, so that the item phase below is the same code either way */
+            for (u32 v = (u32)tid; v < nitems; v += HVQ_WG) {
+                const u32 it = v < nI ? v : (u32)ITEMS_CAP - 1u - (v - nI);
+                const u32 q16 = s_item0[it] >> 10;
+                const u32 kind = (q16 >> 8) & ((is_pb || p != 0) ? 0xFu : 0xFFu);   /* I-picture luma: the kind is the whole byte (h4m:1093) */
+                const bool item_mc = v >= nI;
+                const u32 n = item_mc ? (kind & 0xFu) - 1u : kind;
+                const u32 bases = s_item1[it] + (item_mc ? 2u : 0u);
+                for (u32 k = 0; k < n; ++k) do_basis(it, pool_at(bases + k));
+            }
         }
         STAMP(9, 1);                                                           /* pair phase incl. its window rows */
         __syncthreads();                                                       /* barrier 2: accumulators complete */
@@ -1704,22 +1747,6 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             u32 r[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) r[i] = s_acc[i * ITEMS_CAP + it];
-            if (serial) {
-                const u32 kind = (q16 >> 8) & ((is_pb || p != 0) ? 0xFu : 0xFFu);   /* I-picture luma: the kind is the whole byte (h4m:1093) */
-                const u32 n = item_mc ? (kind & 0xFu) - 1u : kind;
-                const u32 bases = poff + (item_mc ? 2u : 0u);
-                const i32 origin = item_mc ? (i32)s_item2[it] : 0;
-                const u32 roff = ((q16 >> 13) & 3u) == 1u ? ref0_off : ref1_off;
-                for (u32 k = 0; k < n; ++k) {
-                    const u32 d = pool_at(bases + k);
-                    u32 e[16], lo, hi;
-                    if (!item_mc) gather_nest(d, landscape, s_nest, e, lo, hi);
-                    else gather_window(d, landscape, ring + roff, origin, (i32)lw, slot, e, lo, hi);
-                    const u32 g = basis_gain(d, lo, hi);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) r[i] += g * e[i];
-                }
-            }
             u32 *so = &s_out[0][0][0] + (owner >> 8) * (4 * HVQ_WG) + (owner & 255u);
             Blk o;
             if (HVQ_ABL == 32) {
@@ -1969,6 +1996,20 @@ extern "C" __global__ __launch_bounds__(256)
 void hvq_upload_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, u32 n16)
 {
     for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
+/* the two table divisions of the kernels for every divisor (self-test of udiv_table on the device: tests/test_gpu_parity.py) */
+__global__ void hvq_table_div_kernel(u32 *out)
+{
+    const u32 d = threadIdx.x;
+    if (d < 16u) out[d] = udiv_table<256>(d);
+    out[16u + d] = udiv_table<4096>(d);
+}
+
+extern "C" hipError_t hvq_launch_table_div(uint32_t *out_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hvq_table_div_kernel, dim3(1), dim3(256), 0, stream, out_dev);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t hvq_launch_upload(const void *src_pinned, void *dst_dev, size_t bytes, hipStream_t stream)

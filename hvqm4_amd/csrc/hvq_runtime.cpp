@@ -61,6 +61,7 @@ extern "C" hipError_t hvq_launch_gather(const uint64_t *src_dev, uint8_t *dst_de
 extern "C" hipError_t hvq_launch_upload(const void *src_pinned, void *dst_dev, size_t bytes, hipStream_t stream);
 extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *side, uint8_t *dst, hipStream_t stream);
 extern "C" hipError_t hvq_upload_tables(void);
+extern "C" hipError_t hvq_launch_table_div(uint32_t *out_dev, hipStream_t stream);
 
 #ifdef HVQ_STAMPS
 extern "C" void hvq_set_stamps(unsigned long long *p);
@@ -2064,6 +2065,21 @@ HVQ_EXPORT int hvq_rgb_bench(HvqContext *c, int reps, float *gpu_ms, uint64_t *b
     if (rc) return rc;
     if (bytes_per_rep) *bytes_per_rep = bytes;
     if (pictures) *pictures = (uint32_t)jobs.size();
+    return HVQ_OK;
+}
+
+/* self-test: out[0..15] = the kernels' divTable quotients 256 / d, out[16..271] = their mcdivTable quotients 4096 / d (h4m:265-273) */
+HVQ_EXPORT int hvq_debug_table_divisions(HvqContext *c, uint32_t *out)
+{
+    if (!c || !out) return fail(HVQ_E_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, 272 * sizeof(uint32_t)));
+    hipError_t e = hvq_launch_table_div(d, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d, 272 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIPCHK(e);
     return HVQ_OK;
 }
 

@@ -159,6 +159,9 @@ int  hvq_convert_yuv420_rgb(HvqContext *ctx, const void *yuv, int width, int hei
 int  hvq_rgb_bench(HvqContext *ctx, int reps, float *gpu_ms, uint64_t *bytes_per_rep, uint32_t *pictures);
 
 int  hvq_get_stats(HvqContext *ctx, HvqStats *out);
+/* self-test of the kernels' replacement for the reference's division tables (h4m:265-273): out[0..15] = 256 / d, out[16..271] = 4096 / d
+ * as the device computes them (0 for d = 0) */
+int  hvq_debug_table_divisions(HvqContext *ctx, uint32_t *out);
 const char *hvq_last_error_string(void);
 
 /* .h4m container demux in memory (header checks of load_header h4m:2175-2247, block/record walk of h4m:2427-2537).

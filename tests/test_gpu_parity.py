@@ -164,3 +164,14 @@ def test_seeded_slice_of_the_randomised_parity_sweep(gpu_ctx):
     bad, pics, refused = parity_sweep.sweep(gpu_ctx, 200, 5005, "both", log=lambda *a, **k: None)
     assert bad == 0, f"{bad} of 200 random clips differ from the oracle"
     assert pics > 800 and refused == 0
+
+
+def test_table_divisions_on_the_gpu(gpu_ctx):
+    """the kernels compute the reference's divTable / mcdivTable entries (h4m:265-273: 256 / d for d < 16 -- the table stores 16 times
+    that --, 0x1000 / d for d < 256, entry 0 = 0) with a reciprocal and no integer fix-up: every divisor, on the device"""
+    import ctypes as C
+    from hvqm4_amd._lib import check, lib
+    out = (C.c_uint32 * 272)()
+    check(lib().hvq_debug_table_divisions(gpu_ctx._h, out))
+    assert list(out[:16]) == [0] + [256 // d for d in range(1, 16)]
+    assert list(out[16:]) == [0] + [4096 // d for d in range(1, 256)]
