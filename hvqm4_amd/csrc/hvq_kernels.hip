@@ -361,6 +361,12 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 #ifndef HVQ_ABL
 #define HVQ_ABL 0
 #endif
+#ifndef HVQ_NT_LOADS
+#define HVQ_NT_LOADS 0         /* experiment: the map entries loaded non-temporally */
+#endif
+#ifndef HVQ_NT_STORES
+#define HVQ_NT_STORES 1        /* B pictures leave with non-temporal stores (0: plain stores; A/B in profiles/r05_recon_steps.txt) */
+#endif
 #ifndef HVQ_BARRIER1_EARLY
 #define HVQ_BARRIER1_EARLY 1     /* 0: barrier 1 behind phase A instead of in front of the second round trip (r03s: dense -7 %, flat -5 %, natural +3 %) */
 #endif
@@ -1436,7 +1442,11 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         /* entry (by, bx) of the bordered map = b + 2 by + hb + 3 */
         const GLB uint8_t *mw = map + 2u * (size_t)(bws + 2u * by0 + hb + 3u);
         const u32 vo2 = 2u * (l + 2u * q);
+#if HVQ_NT_LOADS
+        row8[h] = __builtin_nontemporal_load((const GLB u64u *)((mw - 2) + vo2));
+#else
         row8[h] = *(const GLB u64u *)((mw - 2) + vo2);                         /* left, own, right entries (the map has a border) */
+#endif
         /* timing experiments (wrong pictures): 41 no vertical-neighbour loads, 42 neither those nor the vector load, 43 = 42 and no nest / pool staging */
         if (HVQ_ABL >= 41 && HVQ_ABL <= 43) { nt[h] = (u32)row8[h] & 0xFFFFu; nbt[h] = (u32)(row8[h] >> 32) & 0xFFFFu; }
         else { nt[h] = *(const GLB uint16_t *)((mw - 2u * (size_t)mstride) + vo2); nbt[h] = *(const GLB uint16_t *)((mw + 2u * (size_t)mstride) + vo2); }
@@ -1786,10 +1796,15 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                 const u32 gx = t - __umul24(q, hb), gy = wby0[h] + q;
                 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 v = *(const u32x4 *)&s_out[h][rr][wave * 64u + g4];
-                GLB u32x4 *dstp = (GLB u32x4 *)(plane + (size_t)((gy * 4u + rr) * pw + gx * 4u));
-                /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors in L2 */
-                if (pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, dstp);
-                else *dstp = v;
+                const u32 doff = (gy * 4u + rr) * pw + gx * 4u;
+                /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors in L2.
+                 * Written as inline assembly: with __builtin_nontemporal_store on one side of the branch the compiler merges the two
+                 * stores into one and drops the hint (rounds 2-4 shipped without it, unnoticed: the ISA had no `nt`). */
+#if HVQ_NT_STORES
+                if (HVQ_NT_STORES == 2 || pic_kind == HVQ_PIC_B) asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(doff), "v"(v), "s"(plane) : "memory");
+                else
+#endif
+                    *(GLB u32x4 *)(plane + (size_t)doff) = v;
             }
         } else if (bw + lane < nblocks) {
             i32 sx, sy;

@@ -265,10 +265,6 @@ struct HvqContext {
     size_t selfref_cap = 0;
     std::vector<SelfRef> selfrefs;
     std::vector<Launch> launches;
-    /* small resident batches (BASELINE config 4 at one GPU's share: 128 pictures in 7 launches of a few microseconds each) are launch-latency
-     * bound: their replay goes through a HIP graph of the pass, captured once per flush */
-    hipGraphExec_t graph_exec[3] = { nullptr, nullptr, nullptr };   /* per `what` of hvq_replay_stage */
-    bool graph_tried[3] = { false, false, false };
     std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
     HvqStats stats{};
     double parse_seconds = 0;
@@ -298,14 +294,6 @@ struct HvqContext {
     int copy_rc = 0;
     std::string copy_err;
 };
-
-static void drop_graphs(HvqContext *c)
-{
-    for (int k = 0; k < 3; ++k) {
-        if (c->graph_exec[k]) { (void)hipGraphExecDestroy(c->graph_exec[k]); c->graph_exec[k] = nullptr; }
-        c->graph_tried[k] = false;
-    }
-}
 
 static int arena_reserve(HvqContext *c, size_t need)
 {
@@ -482,7 +470,6 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->pj_dev) (void)hipFree(c->pj_dev);
     if (c->np_dev) (void)hipFree(c->np_dev);
     if (c->host_arena) (void)hipHostFree(c->host_arena);
-    drop_graphs(c);
     if (c->redo_dev) (void)hipFree(c->redo_dev);
     if (c->rp_dev) (void)hipFree(c->rp_dev);
     if (c->dev_arena) (void)hipFree(c->dev_arena);
@@ -564,7 +551,6 @@ HVQ_EXPORT int hvq_stream_close(HvqContext *c, int sid)
     HIPCHK(hipFree(s.dev)); s.dev = nullptr;
     if (s.nest_keep) { HIPCHK(hipFree(s.nest_keep)); s.nest_keep = nullptr; }
     c->launches.clear();               /* the resident batch may reference the freed slots: no replay after a close */
-    drop_graphs(c);
     s.open = false;
     return HVQ_OK;
 }
@@ -1425,7 +1411,6 @@ static int flush_abandon(HvqContext *c, int rc)
     c->fl_pending.clear();
     c->fl_idx.clear();
     c->launches.clear();                           /* nothing coherent to replay */
-    drop_graphs(c);
     return rc;
 }
 #define HIPCHK_FL(expr)                                                                                              \
@@ -1666,7 +1651,6 @@ static int flush_end(HvqContext *c)
         st.workgroups += L.workgroups;
     }
     c->launches = c->fl_launches;
-    drop_graphs(c);                    /* a graph of the previous batch's pass is stale now */
     st.launches = (uint32_t)c->launches.size();
     st.parse_seconds = c->parse_seconds;
     st.gpu_parse_ms = st.gpu_parsed ? c->gpu_parse_ms : 0.0;
@@ -1739,38 +1723,15 @@ HVQ_EXPORT int hvq_sync(HvqContext *c)
     return HVQ_OK;
 }
 
-/* One pass over the resident batch: what = 0 the reconstruction launches, 1 queue build + launches, 2 queue build only.  A small batch
- * (few workgroups per launch: the launches themselves are what takes the time) replays from a HIP graph of the pass, captured on first
- * use and dropped by the next flush; HVQM4_AMD_GRAPH=0 keeps plain launches, HVQM4_AMD_GRAPH=1 uses the graph for any size. */
-static int run_pass(HvqContext *c, int what)
-{
-    if (what != 0) { int rc = run_queue_build(c, false); if (rc) return rc; }
-    if (what != 2) { int rc = run_launches(c); if (rc) return rc; }
-    return HVQ_OK;
-}
-
+/* `reps` passes over the resident batch: what = 0 the reconstruction launches, 1 queue build + launches, 2 queue build only.
+ * (Round 5 measured a HIP graph of the pass for small batches -- one GPU's share of BASELINE config 4, 128 pictures in 7 launches --
+ * as the round-4 review had asked: 92.4 us per step against 87.2 with plain launches, profiles/r05_recon_steps.txt.  The launches are
+ * a dependency chain, each as long as a workgroup's lifetime; there is no launch overhead for a graph to remove.  Not kept.) */
 static int replay_passes(HvqContext *c, int what, int reps)
 {
-    static const int genv = getenv("HVQM4_AMD_GRAPH") ? atoi(getenv("HVQM4_AMD_GRAPH")) : -1;
-    const bool small = c->stats.workgroups && c->stats.workgroups <= 32768u;
-    bool use_graph = genv != 0 && (genv > 0 || small) && c->selfrefs.empty() && reps > 1;
-    if (use_graph && !c->graph_exec[what] && !c->graph_tried[what]) {
-        c->graph_tried[what] = true;
-        hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int rc = run_pass(c, what);
-            const hipError_t e = hipStreamEndCapture(c->stream, &g);
-            if (rc == HVQ_OK && e == hipSuccess && g) {
-                if (hipGraphInstantiate(&c->graph_exec[what], g, nullptr, nullptr, 0) != hipSuccess) c->graph_exec[what] = nullptr;
-            }
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipGetLastError();
-        }
-    }
-    use_graph = use_graph && c->graph_exec[what];
     for (int r = 0; r < reps; ++r) {
-        if (use_graph) HIPCHK(hipGraphLaunch(c->graph_exec[what], c->stream));
-        else { int rc = run_pass(c, what); if (rc) return rc; }
+        if (what != 0) { int rc = run_queue_build(c, false); if (rc) return rc; }
+        if (what != 2) { int rc = run_launches(c); if (rc) return rc; }
     }
     return HVQ_OK;
 }
