@@ -1319,6 +1319,8 @@ static int build_tiles(HvqContext *c)
         Launch L{};
         L.level = lvl; L.first_tile = (uint32_t)tiles.size();
         /* submission order (sorting same-stream pictures into one grid column of consecutive groups was tried: +1 % dense, -3 % flat, dropped) */
+        /* (walking odd levels in reverse order, so that a level reads first the anchors its predecessor wrote last, was measured in
+         * round 5: dense -1.5 %, flat -3 %, profiles/r05_recon_steps.txt) */
         for (size_t i = 0; i < c->fl_pending.size(); ++i) {
             const Pending &p = c->fl_pending[i];
             if (p.level != lvl) continue;

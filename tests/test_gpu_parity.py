@@ -156,7 +156,7 @@ def test_sdk_calls_with_exactly_sized_frames(trust, monkeypatch):
 def test_seeded_slice_of_the_randomised_parity_sweep(gpu_ctx):
     """200 clips of tools/parity_sweep.py (geometry, version, sampling, preset, GOP, shifts, ring size and flush cadence drawn from a
     fixed seed), host-parsed AND GPU-parsed, every picture against the oracle.  The full sweeps (thousands of clips per mode,
-    tools/r04_sweep.sh) found a real refusal bug in round 4 that no fixed clip had caught; this slice runs where the driver looks."""
+    tools/sweep.sh) found a real refusal bug in round 4 that no fixed clip had caught; this slice runs where the driver looks."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: A/B of environment-selected variants (and/or library builds) on the resident-descriptor bench.
-# usage: tools/r04_ab.sh <tag> "<presets>" <reps> name[:ENV=v[,ENV=v...]] ...        (ENV may include HVQM4_AMD_LIB=path)
+# usage: tools/ab.sh <tag> "<presets>" <reps> name[:ENV=v[,ENV=v...]] ...        (ENV may include HVQM4_AMD_LIB=path)
 T=$1; P=$2; R=$3; shift 3
 O=gpurun_out/$T; mkdir -p $O
 C="--clip-cache /tmp/hvq_clip_cache --no-sdk --no-gpu-parse --cpu-seconds 0"

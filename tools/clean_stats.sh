@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: rocprofv3 --kernel-trace --stats of the bench's TIMED leg alone (resident-descriptor replays, no SDK / streaming / two-queue
 # legs on the same kernel), so that the profiler's average launch duration can be held against roofline.avg_launch_us.
-# usage: tools/r03_clean_stats.sh <tag>
+# usage: tools/clean_stats.sh <tag>
 T=$1
 O=$GRAFT_REPO_ROOT/gpurun_out/$T; mkdir -p $O
 CACHE=/tmp/hvq_clip_cache
