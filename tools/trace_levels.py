@@ -6,7 +6,7 @@ the streaming passes), which a plain --stats average mixes in.   usage: tools/tr
 import csv, json, sys
 from collections import defaultdict
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "hvq_recon_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "hvq_recon" in r["Kernel_Name"]]
 by = defaultdict(list)
 for r in rows:
     g = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
