@@ -4,12 +4,12 @@
 T=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$T; mkdir -p $OUT
 CACHE=/tmp/hvq_clip_cache
-python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-verify --no-gpu-parse --no-sdk --clip-cache $CACHE > $OUT/p0.json 2> $OUT/p0.err
+python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-verify --no-gpu-parse --no-sdk --clip-cache $CACHE $BENCH_EXTRA > $OUT/p0.json 2> $OUT/p0.err
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   L=$GRAFT_REPO_ROOT/hvqm4_amd/abl/libhvq_$v.so; [ $v = base ] && L=$GRAFT_REPO_ROOT/hvqm4_amd/libhvqm4_amd.so
   export HVQM4_AMD_LIB=$L
-  rocprofv3 --kernel-trace --output-format csv -d $OUT/$v --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-verify --no-gpu-parse --no-sdk --gen-workers 1 --clip-cache $CACHE > $OUT/$v.json 2> $OUT/$v.err
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/$v --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-verify --no-gpu-parse --no-sdk --gen-workers 1 --clip-cache $CACHE $BENCH_EXTRA > $OUT/$v.json 2> $OUT/$v.err
   python3 - $OUT/$v $v <<'PY'
 import csv,glob,collections,sys
 f=glob.glob(sys.argv[1]+'/**/*counter_collection.csv',recursive=True)
