@@ -1330,7 +1330,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     __shared__ __attribute__((aligned(16))) u32 s_acc[16 * ITEMS_CAP];
     __shared__ u32 s_item0[ITEMS_CAP];   /* owner (tile of the workgroup * 256 + lane) | map entry << 10 */
     __shared__ u32 s_item1[ITEMS_CAP];   /* pool index of the block's payload */
-    __shared__ u32 s_item2[ITEMS_CAP];   /* MC-residual items: ring offset of the origin of the 70x38 window (h4m:1865-1868), unclamped part + reference */
+    __shared__ u32 s_item2[ITEMS_CAP];   /* MC-residual items: the macroblock vector (the pair lanes derive the origin of the 70x38 window from it, h4m:1865-1868) */
     __shared__ unsigned long long s_ctr64;   /* intra items | MC-residual items << 10 | intra pairs << 20 | MC-residual pairs << 42 handed out */
     u32 *const s_pair = s_dyn;
     u32 *const s_pool = s_dyn + pair_cap;
@@ -1608,13 +1608,8 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                 s_item0[slotq[h]] = (u32)(h * HVQ_WG + tid) | (e16v[h] << 10);
                 s_item1[slotq[h]] = off[h];
                 const bool up = CTX != 2 || cls[h] == 1;
-                if (!up) {
-                    /* origin of the 70x38 window (h4m:1865-1868): vector / 2 truncated towards zero, minus (32, 16) or (16, 32) samples */
-                    const i32 rx = (i32)(int16_t)(mvw[h] & 0xFFFFu), ry = (i32)mvw[h] >> 16;
-                    const i32 rx2 = (rx - (rx >> 31)) >> 1, ry2 = (ry - (ry >> 31)) >> 1;
-                    const i32 corner = landscape ? 16 * (i32)lw + 32 : 32 * (i32)lw + 16;
-                    s_item2[slotq[h]] = (u32)(__mul24(ry2, (i32)lw) + rx2 - corner);
-                }
+                if (!up) s_item2[slotq[h]] = mvw[h];     /* the macroblock's vector: the pair lanes derive the window origin from it (a block lane doing it
+                                                            ran a dozen instructions with one or two lanes of its wave active) */
                 /* the item's pairs, at ASCENDING list positions: intra pairs lie at pstart .. pstart + nb - 1 in basis order, MC-residual
                  * pairs (counted from the top of the list) at pair_cap - pstart - nb .. in reverse basis order.  Entries beyond the list
                  * (more pairs than the launch reserved: the tile turns serial and the list is not read) are cut off by the count. */
@@ -1694,7 +1689,12 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                 const u32 roff = ((t16 >> 13) & 3u) == 1u ? ref0_off : ref1_off;
                 const i32 o = landscape ? (i32)lw * os + ol : (i32)lw * ol + os;
                 const i32 ys = (i32)lw << y2;
-                const u32 voff = roff + (u32)clampi((i32)s_item2[it] + o, 0, slot - 8 - 3 * ys);     /* one clamp: legal windows lie inside the slot */
+                /* origin of the item's 70x38 window (h4m:1865-1868): vector / 2 truncated towards zero, minus (32, 16) or (16, 32) samples */
+                const u32 mv = s_item2[it];
+                const i32 rx = (i32)(int16_t)(mv & 0xFFFFu), ry = (i32)mv >> 16;
+                const i32 rx2 = (rx - (rx >> 31)) >> 1, ry2 = (ry - (ry >> 31)) >> 1;
+                const i32 origin = __mul24(ry2, (i32)lw) + rx2 - (landscape ? 16 * (i32)lw + 32 : 32 * (i32)lw + 16);
+                const u32 voff = roff + (u32)clampi(origin + o, 0, slot - 8 - 3 * ys);     /* one clamp: legal windows lie inside the slot */
                 uint64_t wq[4];
                 window_load(ring, voff, (u32)ys, wq);
                 window_finish(wq, x2, e, lo, hi);
