@@ -355,9 +355,10 @@ def main():
         # 24 batches: on a shared host one batch in four or five waits 1-2 ms for its bitstreams (the host's copy of 160 MB into the
         # pinned arena), so a window of 8 says 4.7 or 5.2 ms by luck; the mean over the window is the number, the median beside it
         nwarm, nbatch = 2, int(os.environ.get("HVQM4_BENCH_STREAM_BATCHES", "24"))
-        def stream_loop(submit):
-            """steady-state period of flush_begin / submit next / flush_end; returns (mean period, median period, mean ms of the
-            three calls, parse kernel ms of the last batch)"""
+        def stream_loop(submit, plain_pair=False):
+            """steady-state period of submit next / hvq_flush_next (= flush_end of the batch in flight + flush_begin of the queued one,
+            the queued batch's parse kernel launched first; plain_pair: the two calls in their plain order); returns (mean period,
+            median period, mean ms of the calls [submit, end or next, begin], parse kernel ms of the last batch)"""
             barrier(); ctx2.sync()
             submit()
             ctx2.flush_begin()
@@ -367,9 +368,13 @@ def main():
                 ta = time.perf_counter()
                 submit()
                 tb = time.perf_counter()
-                ctx2.flush_end()
-                tc = time.perf_counter()
-                ctx2.flush_begin()
+                if plain_pair:
+                    ctx2.flush_end()
+                    tc = time.perf_counter()
+                    ctx2.flush_begin()
+                else:
+                    ctx2.flush_next()
+                    tc = time.perf_counter()
                 td = time.perf_counter()
                 ends.append(tc)
                 if k >= nwarm:
@@ -402,7 +407,10 @@ def main():
                 z_fills[0] += 1
             ctx2.submit_many_arena(a_sid2, a_ft, z_off, z_len)
         z_pipe, z_median, z_calls, z_parse = stream_loop(submit_zero)
-        n_done = 3 + 2 * (nwarm + nbatch)
+        # (c) the plain pair hvq_flush_end / hvq_flush_begin (rounds 2-4's loop): the GPU idles between a batch's parse kernel and its
+        # first reconstruction launch while the host reads the results and builds the tables
+        pp_pipe, pp_median, pp_calls, _pp = stream_loop(lambda: ctx2.submit_many_device(a_sid2, a_ft, a_raw, defer=True), plain_pair=True)
+        n_done = 3 + 3 * (nwarm + nbatch)
         ok = 0
         ok_per_stream = []
         n_seq = [len(pics[stream_clip[s]]) for s in range(len(sids))]
@@ -496,6 +504,11 @@ def main():
                                            "what": "the same streaming loop with the bitstreams already in the library's pinned arena "
                                                    "(hvq_arena_reserve / hvq_submit_many_arena: what a container reader that read()s into the "
                                                    "reservation leaves): no host memcpy, the batch costs the host its bookkeeping and the DMA"},
+                   "streaming_plain_pair": {"value": round(grp.sum(px / pp_pipe / 1e6), 1), "unit": "Mpixels/s",
+                                            "ms_per_batch": round(pp_pipe * 1e3, 2), "ms_per_batch_median": round(pp_median * 1e3, 2),
+                                            "submit_end_begin_ms": pp_calls,
+                                            "what": "the same loop with hvq_flush_end + hvq_flush_begin in place of hvq_flush_next (the loop of "
+                                                    "rounds 2-4): the host's part of a batch is not hidden behind the next batch's parse kernel"},
                    "affinity": {"cores_of_rank0": len(my_cores), "first": my_cores[0], "last": my_cores[-1], "ranks_on_host": local_world,
                                 "pinned": local_world > 1, "numa_node_of_gpu": my_node, "core_choice": pin_how},
                    "pictures_checked_against_host_parsed": ok,
@@ -503,8 +516,10 @@ def main():
                    "what": "raw bitstreams in host memory -> H2D -> entropy parse kernel (one workgroup per picture) -> "
                            "reconstruction launches -> pictures in HBM; no host entropy parse; all ranks at once (sum over ranks, "
                            "per-rank min and max of the streaming rate; the per-rank detail fields are rank 0's).  value: one "
-                           "batch start to finish; streaming_value: steady-state period of hvq_flush_begin / submit next / "
-                           "hvq_flush_end (next batch copied and uploaded while this one is parsed), mean over `streaming_batches` batches after 2 warm-up batches"}
+                           "batch start to finish; streaming_value: steady-state period of submit next / hvq_flush_next "
+                           "(next batch copied and uploaded while this one is parsed; its parse kernel queued before the host takes this "
+                           "batch's results, this batch's reconstruction on a second HIP stream beside it), mean over `streaming_batches` "
+                           "batches after 2 warm-up batches"}
         ctx2.close()
 
     px_step = int(st.luma_pixels)

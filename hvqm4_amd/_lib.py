@@ -97,6 +97,7 @@ SYMBOLS = {
     "hvq_flush": (C.c_int, [C.c_void_p]),
     "hvq_flush_begin": (C.c_int, [C.c_void_p]),
     "hvq_flush_end": (C.c_int, [C.c_void_p]),
+    "hvq_flush_next": (C.c_int, [C.c_void_p]),
     "hvq_sync": (C.c_int, [C.c_void_p]),
     "hvq_replay": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "hvq_replay_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),

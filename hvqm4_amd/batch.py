@@ -85,6 +85,11 @@ class Context:
     def flush_end(self) -> None:
         check(lib().hvq_flush_end(self._h))
 
+    def flush_next(self) -> None:
+        """streaming step: end the batch in flight and begin the queued one, the queued batch's parse kernel launched first
+        (hvq_flush_next); equals flush_end() + flush_begin() in effect"""
+        check(lib().hvq_flush_next(self._h))
+
     def sync(self) -> None:
         check(lib().hvq_sync(self._h))
 

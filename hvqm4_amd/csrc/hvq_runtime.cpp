@@ -231,25 +231,20 @@ struct HvqContext {
     size_t resv_base = 0, resv_bytes = 0;
     hipStream_t copy_stream = nullptr, read_stream = nullptr;
     hipEvent_t ev_read = nullptr;
-    hipEvent_t ev_copy = nullptr, ev_parse = nullptr, ev_arena_free[2] = { nullptr, nullptr };
+    hipEvent_t ev_copy = nullptr, ev_arena_free[2] = { nullptr, nullptr };
     std::vector<Pending> pending;
     /* batch in flight */
     bool fl_active = false;
     std::vector<Pending> fl_pending;
-    std::vector<size_t> fl_idx;        /* its GPU-parsed pictures (indices into fl_pending) */
     std::vector<uint64_t> fl_nest_pairs;
     std::vector<int> fl_nest_streams;  /* stream of each pair */
     uint8_t *fl_host = nullptr, *fl_dev = nullptr;
     int fl_arena_id = 0;
-    HvqParseResult *pr_host = nullptr; /* pinned */
-    size_t pr_host_cap = 0;
-    uint64_t *timing_dev = nullptr;
     /* pinned staging of the table uploads, one set per arena id: an H2D from pageable memory would block the caller
      * until the stream has drained (the parse kernel!), which is exactly what hvq_flush_begin must not do */
     struct Pinned { uint8_t *p = nullptr; size_t cap = 0; } pin[2][5];   /* [arena id][parse jobs, tiles, jobs, nest pairs, re-parsed blobs] */
     std::vector<HvqJob> jobs_host;     /* the tables are built here, then copied into the pinned staging */
     std::vector<HvqTileRef> tiles_host;
-    std::vector<HvqParseJob> pjobs_host;
     /* last flushed batch (kept resident for hvq_replay) */
     HvqJob *jobs_dev = nullptr;        /* one job per launch slot, in launch order (padding slots: total_tiles = 0) */
     size_t jobs_cap = 0;
@@ -274,12 +269,26 @@ struct HvqContext {
     size_t rgb_cap = 0;
     RgbJob *rgb_jobs_dev = nullptr;
     size_t rgb_jobs_cap = 0;
-    /* GPU entropy parse: blobs + scratch + nests of the batch, job and result tables */
-    uint8_t *gp_dev = nullptr;
-    size_t gp_cap = 0;
-    HvqParseJob *pj_dev = nullptr;
-    uint64_t *np_dev = nullptr;
-    size_t pj_cap = 0;
+    /* GPU entropy parse: blobs + scratch + nests of a batch, its job and result tables, the events around its parse kernel.  Two
+     * sets: hvq_flush_next queues the parse of batch k + 1 BEFORE it takes the results of batch k, so the reconstruction of batch k
+     * reads one set while the parse of batch k + 1 fills the other.  ps_live is the set the code below means by PS(c). */
+    struct ParseSet {
+        std::vector<size_t> fl_idx;        /* the batch's GPU-parsed pictures (indices into fl_pending) */
+        std::vector<HvqParseJob> pjobs_host;
+        HvqParseResult *pr_host = nullptr; /* pinned: the parse workgroups write their result records here */
+        size_t pr_host_cap = 0;
+        uint8_t *gp_dev = nullptr;
+        size_t gp_cap = 0;
+        HvqParseJob *pj_dev = nullptr;
+        uint64_t *np_dev = nullptr;
+        size_t pj_cap = 0;
+        hipEvent_t ev_parse = nullptr, evp0 = nullptr, evp1 = nullptr;   /* results complete; timing of the parse kernel */
+        uint32_t fl_rowbuf = 0;
+        uint64_t *timing_dev = nullptr;
+    } ps[2];
+    int ps_live = 0;
+    bool abandoned = false;                    /* flush_abandon ran since this was cleared */
+    bool arena_idle[2] = { false, false };     /* nothing on the GPU reads this arena or its staging any more (hvq_flush_next) */
     double gpu_parse_ms = 0;           /* device time of the parse kernel of the last flush */
     uint32_t gpu_parse_retried = 0;    /* pictures of the last flush the flat parse path handed to the chains */
     uint32_t *redo_dev = nullptr;      /* their indices, for the chains kernel */
@@ -287,13 +296,16 @@ struct HvqContext {
     size_t rp_cap = 0;
     std::vector<uint8_t> rp_host;
     size_t redo_cap = 0;
-    uint32_t fl_rowbuf = 0;
     /* streaming: the bitstream copy of the batch being queued runs on a worker while the batch in flight is finished */
     std::thread copy_worker;
     bool copy_active = false;
+    std::atomic<bool> copy_done{ false };      /* the worker has finished (hvq_flush_next polls it beside the parse event) */
     int copy_rc = 0;
     std::string copy_err;
 };
+
+static inline HvqContext::ParseSet &PS(HvqContext *c) { return c->ps[c->ps_live]; }
+static inline const HvqContext::ParseSet &PS(const HvqContext *c) { return c->ps[c->ps_live]; }
 
 static int arena_reserve(HvqContext *c, size_t need)
 {
@@ -321,7 +333,7 @@ static int arena_upload(HvqContext *c, size_t upto)
 {
     if (upto <= c->arena_uploaded) return HVQ_OK;
     if (!c->arena_waited) {            /* the batch that used this arena two flushes ago may still be reconstructing */
-        HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_arena_free[c->arena_id], 0));
+        if (!c->arena_idle[c->arena_id]) HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_arena_free[c->arena_id], 0));
         c->arena_waited = true;
     }
     HIPCHK(hipMemcpyAsync(c->dev_arena + c->arena_uploaded, c->host_arena + c->arena_uploaded, upto - c->arena_uploaded,
@@ -443,7 +455,11 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     HIPCHK(hipStreamCreateWithFlags(&c->read_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_parse, hipEventDisableTiming));
+    for (auto &S : c->ps) {
+        HIPCHK(hipEventCreateWithFlags(&S.ev_parse, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&S.evp0));
+        HIPCHK(hipEventCreate(&S.evp1));
+    }
     HIPCHK(hipEventCreateWithFlags(&c->ev_arena_free[0], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_arena_free[1], hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->ev0));
@@ -466,19 +482,24 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
         if (s.dev) (void)hipFree(s.dev);
         if (s.nest_keep) (void)hipFree(s.nest_keep);
     }
-    if (c->gp_dev) (void)hipFree(c->gp_dev);
-    if (c->pj_dev) (void)hipFree(c->pj_dev);
-    if (c->np_dev) (void)hipFree(c->np_dev);
+    for (auto &S : c->ps) {
+        if (S.gp_dev) (void)hipFree(S.gp_dev);
+        if (S.pj_dev) (void)hipFree(S.pj_dev);
+        if (S.np_dev) (void)hipFree(S.np_dev);
+        if (S.pr_host) (void)hipHostFree(S.pr_host);
+        if (S.timing_dev) (void)hipFree(S.timing_dev);
+        if (S.ev_parse) (void)hipEventDestroy(S.ev_parse);
+        if (S.evp0) (void)hipEventDestroy(S.evp0);
+        if (S.evp1) (void)hipEventDestroy(S.evp1);
+    }
     if (c->host_arena) (void)hipHostFree(c->host_arena);
     if (c->redo_dev) (void)hipFree(c->redo_dev);
     if (c->rp_dev) (void)hipFree(c->rp_dev);
     if (c->dev_arena) (void)hipFree(c->dev_arena);
     if (c->host_arena_alt) (void)hipHostFree(c->host_arena_alt);
     if (c->dev_arena_alt) (void)hipFree(c->dev_arena_alt);
-    if (c->pr_host) (void)hipHostFree(c->pr_host);
     for (auto &set : c->pin) for (auto &b : set) if (b.p) (void)hipHostFree(b.p);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
-    if (c->ev_parse) (void)hipEventDestroy(c->ev_parse);
     for (auto e : c->ev_arena_free) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->read_stream) { (void)hipStreamSynchronize(c->read_stream); (void)hipStreamDestroy(c->read_stream); }
@@ -960,11 +981,13 @@ static int submit_device(HvqContext *c, int n, const int *streams, const int *fr
         c->copy_rc = HVQ_OK;
         c->copy_err.clear();
         c->copy_active = true;
+        c->copy_done.store(false, std::memory_order_relaxed);
         const int dev = c->device;
         c->copy_worker = std::thread([c, dev, run_copy, job = std::move(job)]() {
             (void)hipSetDevice(dev);
             c->copy_rc = run_copy(job);
             if (c->copy_rc) c->copy_err = g_err;          /* the worker's thread-local error text */
+            c->copy_done.store(true, std::memory_order_release);
         });
     } else {
         int rcc = run_copy(job);
@@ -1016,7 +1039,7 @@ HVQ_EXPORT int hvq_submit_many_arena(HvqContext *c, int n, const int *streams, c
  * results on the compute stream (which already waits for the bitstreams' H2D).  Nothing here waits for the GPU. */
 static int device_parse_launch(HvqContext *c)
 {
-    std::vector<size_t> &idx = c->fl_idx;
+    std::vector<size_t> &idx = PS(c).fl_idx;
     idx.clear();
     size_t need = 0;
     uint32_t rowbuf = 0;
@@ -1029,32 +1052,32 @@ static int device_parse_launch(HvqContext *c)
         rowbuf = std::max(rowbuf, (uint32_t)s.layout.hb[0] + 2u);
     }
     if (idx.empty()) return HVQ_OK;
-    if (need > c->gp_cap) {
-        if (c->gp_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->gp_dev)); c->gp_dev = nullptr; c->gp_cap = 0; }
-        HIPCHK(hipMalloc((void **)&c->gp_dev, need));
-        c->gp_cap = need;
+    if (need > PS(c).gp_cap) {
+        if (PS(c).gp_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(PS(c).gp_dev)); PS(c).gp_dev = nullptr; PS(c).gp_cap = 0; }
+        HIPCHK(hipMalloc((void **)&PS(c).gp_dev, need));
+        PS(c).gp_cap = need;
     }
-    if (idx.size() > c->pj_cap) {
-        if (c->pj_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->pj_dev)); HIPCHK(hipFree(c->np_dev)); }
-        c->pj_cap = idx.size() * 2;
-        HIPCHK(hipMalloc((void **)&c->pj_dev, c->pj_cap * sizeof(HvqParseJob)));
-        HIPCHK(hipMalloc((void **)&c->np_dev, c->pj_cap * 2 * sizeof(uint64_t)));
+    if (idx.size() > PS(c).pj_cap) {
+        if (PS(c).pj_dev) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(PS(c).pj_dev)); HIPCHK(hipFree(PS(c).np_dev)); }
+        PS(c).pj_cap = idx.size() * 2;
+        HIPCHK(hipMalloc((void **)&PS(c).pj_dev, PS(c).pj_cap * sizeof(HvqParseJob)));
+        HIPCHK(hipMalloc((void **)&PS(c).np_dev, PS(c).pj_cap * 2 * sizeof(uint64_t)));
     }
-    if (idx.size() > c->pr_host_cap) {
-        if (c->pr_host) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(c->pr_host)); }
-        c->pr_host_cap = idx.size() * 2;
-        HIPCHK(hipHostMalloc((void **)&c->pr_host, c->pr_host_cap * sizeof(HvqParseResult), hipHostMallocDefault));
+    if (idx.size() > PS(c).pr_host_cap) {
+        if (PS(c).pr_host) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipHostFree(PS(c).pr_host)); }
+        PS(c).pr_host_cap = idx.size() * 2;
+        HIPCHK(hipHostMalloc((void **)&PS(c).pr_host, PS(c).pr_host_cap * sizeof(HvqParseResult), hipHostMallocDefault));
     }
-    std::vector<HvqParseJob> &jobs = c->pjobs_host;
+    std::vector<HvqParseJob> &jobs = PS(c).pjobs_host;
     jobs.assign(idx.size(), HvqParseJob{});
     size_t off = 0;
     for (size_t k = 0; k < idx.size(); ++k) {
         Pending &p = c->pending[idx[k]];
         const Stream &s = c->streams[(size_t)p.stream];
         HvqParseJob &j = jobs[k];
-        p.dev_blob = (uint64_t)(uintptr_t)(c->gp_dev + off);             off += s.blob_cap;
-        j.scratch = (uint64_t)(uintptr_t)(c->gp_dev + off);              off += s.scratch_bytes;
-        p.dev_nest = (uint64_t)(uintptr_t)(c->gp_dev + off);             off += align_up(GP_ALIGN16(HVQ_NESTP_BYTES), 256);
+        p.dev_blob = (uint64_t)(uintptr_t)(PS(c).gp_dev + off);             off += s.blob_cap;
+        j.scratch = (uint64_t)(uintptr_t)(PS(c).gp_dev + off);              off += s.scratch_bytes;
+        p.dev_nest = (uint64_t)(uintptr_t)(PS(c).gp_dev + off);             off += align_up(GP_ALIGN16(HVQ_NESTP_BYTES), 256);
         j.pic = (uint64_t)(uintptr_t)(c->dev_arena + p.blob_off);
         j.blob = p.dev_blob;
         j.nest_out = p.dev_nest;
@@ -1066,18 +1089,18 @@ static int device_parse_launch(HvqContext *c)
         j.h_samp = s.layout.wshift ? 2 : 1; j.v_samp = s.layout.hshift ? 2 : 1;
         j.is15 = (s.layout.flags & HVQ_F_IS15) ? 1 : 0;
     }
-    { int rcu = staged_upload(c, c->arena_id, 0, c->pj_dev, jobs.data(), jobs.size() * sizeof(HvqParseJob)); if (rcu) return rcu; }
-    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    { int rcu = staged_upload(c, c->arena_id, 0, PS(c).pj_dev, jobs.data(), jobs.size() * sizeof(HvqParseJob)); if (rcu) return rcu; }
+    HIPCHK(hipEventRecord(PS(c).evp0, c->stream));
     /* HVQM4_AMD_PARSE_TIMING=1: per-phase times of the parse kernel (development aid, prints to stderr) */
     static const bool want_timing = getenv("HVQM4_AMD_PARSE_TIMING") != nullptr;
-    c->timing_dev = nullptr;
+    PS(c).timing_dev = nullptr;
     if (want_timing) {
-        HIPCHK(hipMalloc((void **)&c->timing_dev, jobs.size() * 16 * sizeof(uint64_t)));
-        HIPCHK(hipMemsetAsync(c->timing_dev, 0, jobs.size() * 16 * sizeof(uint64_t), c->stream));
+        HIPCHK(hipMalloc((void **)&PS(c).timing_dev, jobs.size() * 16 * sizeof(uint64_t)));
+        HIPCHK(hipMemsetAsync(PS(c).timing_dev, 0, jobs.size() * 16 * sizeof(uint64_t), c->stream));
     }
     /* HVQM4_AMD_PARSE_FLAT=0: round 1's chains only (the flat path falls back to them by itself where it has to) */
     static const bool use_flat = !(getenv("HVQM4_AMD_PARSE_FLAT") && atoi(getenv("HVQM4_AMD_PARSE_FLAT")) == 0);
-    c->fl_rowbuf = rowbuf;
+    PS(c).fl_rowbuf = rowbuf;
     /* The parse workgroups write their result records straight into pinned host memory (one 48-byte record per picture).  A
      * read-back copy queued behind the parse kernel would sit on a DMA engine for the whole parse -- and every second batch the
      * NEXT batch's bitstream uploads (copy stream) were dealt to that same engine and started only when the parse ended: periods
@@ -1091,23 +1114,23 @@ static int device_parse_launch(HvqContext *c)
         else if (hipEventQuery(pe1) == hipSuccess) { float pm = 0; if (hipEventElapsedTime(&pm, pe0, pe1) == hipSuccess) last_ms = pm; }
         if (last_ms >= 0) fprintf(stderr, "hvqm4_amd parse probe: exit at stamp %d: %.3f ms (previous batch)\n", atoi(ex), last_ms);
         HIPCHK(hipEventRecord(pe0, c->stream));
-        HIPCHK(hvq_launch_parse_probe(c->pj_dev, c->pr_host, (uint32_t)jobs.size(), rowbuf, (uint32_t)atoi(ex), c->stream));
+        HIPCHK(hvq_launch_parse_probe(PS(c).pj_dev, PS(c).pr_host, (uint32_t)jobs.size(), rowbuf, (uint32_t)atoi(ex), c->stream));
         HIPCHK(hipEventRecord(pe1, c->stream));
-        HIPCHK(hipEventRecord(c->ev0, c->stream));
+        HIPCHK(hipEventRecord(PS(c).evp0, c->stream));
     }
 #endif
-    HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_host, (uint32_t)jobs.size(), rowbuf, use_flat ? 1u : 0u, nullptr, c->timing_dev, c->stream));
-    HIPCHK(hipEventRecord(c->ev1, c->stream));
-    HIPCHK(hipEventRecord(c->ev_parse, c->stream));
+    HIPCHK(hvq_launch_parse(PS(c).pj_dev, PS(c).pr_host, (uint32_t)jobs.size(), rowbuf, use_flat ? 1u : 0u, nullptr, PS(c).timing_dev, c->stream));
+    HIPCHK(hipEventRecord(PS(c).evp1, c->stream));
+    HIPCHK(hipEventRecord(PS(c).ev_parse, c->stream));
     return HVQ_OK;
 }
 
-static size_t jobs_len_of(const HvqContext *c, size_t k) { return k < c->pjobs_host.size() ? (size_t)c->pjobs_host[k].len : 0; }
+static size_t jobs_len_of(const HvqContext *c, size_t k) { return k < PS(c).pjobs_host.size() ? (size_t)PS(c).pjobs_host[k].len : 0; }
 
 /* wait for the parse results of the batch in flight and take them over */
 static int device_parse_finish(HvqContext *c)
 {
-    const std::vector<size_t> &idx = c->fl_idx;
+    const std::vector<size_t> &idx = PS(c).fl_idx;
     if (idx.empty()) return HVQ_OK;
     {   /* The reconstruction launches wait for this thread to have seen the parse results: the GPU idles for as long as the wake-up
          * takes.  Polling the event costs this thread a core for the length of the parse kernel and takes the results some tens of
@@ -1115,13 +1138,13 @@ static int device_parse_finish(HvqContext *c)
         static const bool spin = !(getenv("HVQM4_AMD_SPIN_WAIT") && atoi(getenv("HVQM4_AMD_SPIN_WAIT")) == 0);
         if (spin) {
             hipError_t q;
-            while ((q = hipEventQuery(c->ev_parse)) == hipErrorNotReady) { for (int k = 0; k < 32; ++k) cpu_relax(); }
+            while ((q = hipEventQuery(PS(c).ev_parse)) == hipErrorNotReady) { for (int k = 0; k < 32; ++k) cpu_relax(); }
             HIPCHK(q);
-        } else HIPCHK(hipEventSynchronize(c->ev_parse));
+        } else HIPCHK(hipEventSynchronize(PS(c).ev_parse));
     }
-    const HvqParseResult *res = c->pr_host;
+    const HvqParseResult *res = PS(c).pr_host;
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    HIPCHK(hipEventElapsedTime(&ms, PS(c).evp0, PS(c).evp1));
     c->gpu_parse_ms = ms;
     /* Pictures the flat parse path could not serve (sections in an unusual order, array capacities, overflow groups at
      * the chains' caps) come back marked: the chains kernel parses those, same blobs as they would have been. */
@@ -1138,7 +1161,7 @@ static int device_parse_finish(HvqContext *c)
             }
             HIPCHK(hipMemcpyAsync(c->redo_dev, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             HIPCHK(hipEventRecord(c->ev0, c->stream));
-            HIPCHK(hvq_launch_parse(c->pj_dev, c->pr_host, n_redo, c->fl_rowbuf, 0u, c->redo_dev, nullptr, c->stream));
+            HIPCHK(hvq_launch_parse(PS(c).pj_dev, PS(c).pr_host, n_redo, PS(c).fl_rowbuf, 0u, c->redo_dev, nullptr, c->stream));
             HIPCHK(hipEventRecord(c->ev1, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));       /* also keeps `redo` alive until its upload is done */
             float ms2 = 0;
@@ -1146,11 +1169,11 @@ static int device_parse_finish(HvqContext *c)
             c->gpu_parse_ms += ms2;                        /* the parse time of the batch includes the second launch */
         }
     }
-    const bool want_timing_print = c->timing_dev != nullptr;
-    if (c->timing_dev) {
+    const bool want_timing_print = PS(c).timing_dev != nullptr;
+    if (PS(c).timing_dev) {
         std::vector<uint64_t> tm(idx.size() * 16);
-        HIPCHK(hipMemcpy(tm.data(), c->timing_dev, tm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        HIPCHK(hipFree(c->timing_dev)); c->timing_dev = nullptr;
+        HIPCHK(hipMemcpy(tm.data(), PS(c).timing_dev, tm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipFree(PS(c).timing_dev)); PS(c).timing_dev = nullptr;
         /* stamp k of hvq_parse_kernel (GP_STAMP): average time since the picture's start, in the order they happened */
         static const char *label[16] = { "start", "trees", "mb types", "DC placed", "run sums", "chains ready or decoder", "coefficients/scans",
                                          "merge", "run scan", "entries", "emit count", "emit scan or MV x", "tags+lists", "kinds/DC or lanes",
@@ -1340,21 +1363,22 @@ static int build_tiles(HvqContext *c)
 /* First half of a flush: everything that can be queued without waiting for the GPU.  The pending batch becomes the
  * batch in flight; the caller may queue the NEXT batch (hvq_submit_*) before hvq_flush_end -- its bitstreams are copied
  * and uploaded (other arena, copy stream) while this batch is being parsed. */
-HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
+/* begin, part A: the queued batch's bitstreams go up (what the early uploads left); its parse kernel is queued behind them
+ * (device_parse_launch) */
+static int begin_upload(HvqContext *c)
 {
-    if (!c) return fail(HVQ_E_ARG, "null context");
-    HIPCHK(hipSetDevice(c->device));
-    { int rc = flush_end(c); if (rc) return rc; }            /* at most one batch in flight */
-    { int rcj = copy_join(c); if (rcj) return rcj; }         /* the queued batch's bitstreams are in the arena (streaming: copied by a worker) */
-    if (c->pending.empty()) return HVQ_OK;
-    const double tb0 = now_ms();
-    HIPCHK(hipEventSynchronize(c->ev_arena_free[c->arena_id]));   /* the pinned staging of this arena id is free again */
+    /* the pinned staging of this arena id is free again (hvq_flush_next knows that without asking: arena_idle) */
+    if (!c->arena_idle[c->arena_id]) HIPCHK(hipEventSynchronize(c->ev_arena_free[c->arena_id]));
     /* 1. descriptors / bitstreams -> HBM; the compute stream waits for the copy stream */
     { int rc = arena_upload(c, c->arena_used); if (rc) return rc; }
     HIPCHK(hipEventRecord(c->ev_copy, c->copy_stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
-    /* 1b. streams parsed on the GPU: bitstreams -> blobs, one launch */
-    int rc = device_parse_launch(c);
+    return HVQ_OK;
+}
+
+/* begin, part B: the queued batch becomes the batch in flight */
+static int begin_rest(HvqContext *c, int rc)
+{
     /* the nest a GPU-parsed P/B picture uses: its batch's governing I picture, else the stream's kept one; the last I
      * picture of every stream is committed to the other kept slot at the end of the batch */
     c->fl_nest_pairs.clear();
@@ -1382,6 +1406,7 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
     for (auto &s : c->streams)
         for (auto &sl : s.slots) { sl.w_level = -1; sl.r_level = -1; }
     c->fl_host = c->host_arena; c->fl_dev = c->dev_arena; c->fl_arena_id = c->arena_id;
+    c->arena_idle[c->arena_id] = false;
     std::swap(c->host_arena, c->host_arena_alt);
     std::swap(c->dev_arena, c->dev_arena_alt);
     std::swap(c->arena_cap, c->arena_cap_alt);
@@ -1391,8 +1416,81 @@ HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
     c->fl_active = true;
     if (!rc) rc = build_tiles(c);
     if (rc) return flush_abandon(c, rc);
-    if (flush_timing()) fprintf(stderr, "flush_begin %.3f -> %.3f ms\n", tb0, now_ms());
     return HVQ_OK;
+}
+
+/* First half of a flush: everything that can be queued without waiting for the GPU.  The pending batch becomes the
+ * batch in flight; the caller may queue the NEXT batch (hvq_submit_*) before hvq_flush_end -- its bitstreams are copied
+ * and uploaded (other arena, copy stream) while this batch is being parsed. */
+HVQ_EXPORT int hvq_flush_begin(HvqContext *c)
+{
+    if (!c) return fail(HVQ_E_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    { int rc = flush_end(c); if (rc) return rc; }            /* at most one batch in flight */
+    { int rcj = copy_join(c); if (rcj) return rcj; }         /* the queued batch's bitstreams are in the arena (streaming: copied by a worker) */
+    if (c->pending.empty()) return HVQ_OK;
+    const double tb0 = now_ms();
+    { int rc = begin_upload(c); if (rc) return rc; }
+    /* 1b. streams parsed on the GPU: bitstreams -> blobs, one launch */
+    int rc = device_parse_launch(c);
+    rc = begin_rest(c, rc);
+    if (flush_timing()) fprintf(stderr, "flush_begin %.3f -> %.3f ms\n", tb0, now_ms());
+    return rc;
+}
+
+/* Streaming step: end the batch in flight (k) and begin the queued one (k + 1) -- in the order that keeps the GPU busy.  The plain
+ * pair hvq_flush_end / hvq_flush_begin leaves the GPU idle between the parse kernel of batch k and its first reconstruction launch
+ * for as long as the host takes over the parse results and the job table (0.13-0.3 ms of a 4 ms period, measured); here the parse
+ * kernel of batch k + 1 is queued FIRST, on its own set of buffers, so the host's part of batch k runs beside it and the launches of
+ * batch k line up behind it.  Taken only when it is safe and useful: both batches parsed on the GPU throughout (a host-parsed blob
+ * lives in the arena until its reconstruction ends) and the queued batch's bitstreams in the arena before batch k's parse results
+ * arrive; otherwise this IS hvq_flush_end followed by hvq_flush_begin.  Returns the first error of either half; the state
+ * afterwards is the one the plain pair leaves. */
+HVQ_EXPORT int hvq_flush_next(HvqContext *c)
+{
+    if (!c) return fail(HVQ_E_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    static const bool allow = !(getenv("HVQM4_AMD_FLUSH_NEXT") && atoi(getenv("HVQM4_AMD_FLUSH_NEXT")) == 0);
+    bool ahead = allow && c->fl_active && !c->pending.empty() && !c->tile_queues && !PS(c).fl_idx.empty();
+    if (ahead) {
+        for (auto &p : c->fl_pending) if (!p.dev) { ahead = false; break; }
+        for (auto &p : c->pending) if (!p.dev) { ahead = false; break; }
+    }
+    if (ahead && c->copy_active) {
+        /* whichever comes first: the queued batch's bitstreams are in the arena (go ahead), or batch k's parse results are there
+         * (its launches must not wait for a slow copy: plain order) */
+        for (;;) {
+            if (c->copy_done.load(std::memory_order_acquire)) break;
+            if (hipEventQuery(PS(c).ev_parse) != hipErrorNotReady) { ahead = false; break; }
+            for (int k = 0; k < 32; ++k) cpu_relax();
+        }
+    }
+    if (!ahead) {
+        if (flush_timing()) fprintf(stderr, "flush_next  %.3f: plain order\n", now_ms());
+        const int rc_end = flush_end(c);
+        const int rc_begin = hvq_flush_begin(c);
+        return rc_end ? rc_end : rc_begin;
+    }
+    { int rcj = copy_join(c); if (rcj) { const int rc_end = flush_end(c); return rc_end ? rc_end : rcj; } }
+    const double tb0 = now_ms();
+    const int fl_arena = c->fl_arena_id;
+    /* Everything stays on the one launch stream: parse k + 1, then the launches of batch k, in that order.  The parse kernel on a
+     * stream of its own, so that the reconstruction of batch k runs BESIDE it, was built and measured (profiles/r05_flush_next.txt):
+     * both kernels are bound by instruction issue, whichever reaches the CUs first keeps the other out until its workgroups thin
+     * out, periods alternate 3.45 / 4.9 ms and their mean (4.17) is worse than this order's 3.94. */
+    { int rcu = begin_upload(c); if (rcu) { const int rc_end = flush_end(c); return rc_end ? rc_end : rcu; } }   /* the queued batch stays queued */
+    c->ps_live ^= 1;                   /* batch k + 1 parses into the other set ... */
+    const int rc_parse = device_parse_launch(c);
+    c->ps_live ^= 1;                   /* ... while batch k is finished from its own */
+    c->abandoned = false;
+    const int rc_end = flush_end(c);
+    /* every GPU reader of batch k's arena is done (its parse results were taken, a second parse launch was waited for), and what
+     * its staging buffers still feed is consumed before the host writes them again (behind the parse of the batch after next) */
+    if (!c->abandoned) c->arena_idle[fl_arena] = true;
+    c->ps_live ^= 1;
+    const int rc_begin = begin_rest(c, rc_parse);
+    if (flush_timing()) fprintf(stderr, "flush_next  %.3f -> %.3f ms\n", tb0, now_ms());
+    return rc_end ? rc_end : rc_begin;
 }
 
 /* a flush that fails half way: the pictures of the batch in flight were never reconstructed -- they must not read as resident
@@ -1410,8 +1508,9 @@ static int flush_abandon(HvqContext *c, int rc)
     }
     for (auto &s : c->streams) s.inflight_from = 0x7FFFFFFF;
     c->fl_active = false;
+    c->abandoned = true;
     c->fl_pending.clear();
-    c->fl_idx.clear();
+    PS(c).fl_idx.clear();
     c->launches.clear();                           /* nothing coherent to replay */
     return rc;
 }
@@ -1689,15 +1788,15 @@ static int flush_end(HvqContext *c)
     /* 3. one launch per level */
     { int rc = run_launches(c); if (rc) return flush_abandon(c, rc); }
     if (!c->fl_nest_pairs.empty()) {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
-        { int rcu = staged_upload(c, c->fl_arena_id, 3, c->np_dev, c->fl_nest_pairs.data(), c->fl_nest_pairs.size() * sizeof(uint64_t)); if (rcu) return flush_abandon(c, rcu); }
-        HIPCHK_FL(hvq_launch_nest_commit(c->np_dev, (uint32_t)(c->fl_nest_pairs.size() / 2), c->stream));
+        { int rcu = staged_upload(c, c->fl_arena_id, 3, PS(c).np_dev, c->fl_nest_pairs.data(), c->fl_nest_pairs.size() * sizeof(uint64_t)); if (rcu) return flush_abandon(c, rcu); }
+        HIPCHK_FL(hvq_launch_nest_commit(PS(c).np_dev, (uint32_t)(c->fl_nest_pairs.size() / 2), c->stream));
     }
     HIPCHK_FL(hipEventRecord(c->ev_arena_free[c->fl_arena_id], c->stream));    /* this batch's arena may be refilled after this */
     HIPCHK_FL(hipEventRecord(c->ev_read, c->stream));                           /* every picture flushed so far is complete behind this */
     for (auto &s : c->streams) s.inflight_from = 0x7FFFFFFF;
     c->stats = st;
     c->fl_pending.clear();
-    c->fl_idx.clear();
+    PS(c).fl_idx.clear();
     if (flush_timing()) fprintf(stderr, "flush_end   %.3f: parse results at %.3f, launches queued %.3f ms (parse kernel %.3f ms)\n", te0, te1, now_ms(), c->gpu_parse_ms);
     return first_rc;
 }

@@ -124,6 +124,14 @@ int  hvq_flush(HvqContext *ctx);
  * in flight; every call that needs its pictures (sync, read, replay, stats, close) ends it implicitly. */
 int  hvq_flush_begin(HvqContext *ctx);
 int  hvq_flush_end(HvqContext *ctx);
+/* The streaming step in one call: end the batch in flight and begin the queued one -- hvq_flush_end + hvq_flush_begin in effect,
+ * errors and state included (the first error of either half is returned) -- but with the queued batch's parse kernel launched
+ * BEFORE the host takes the results of the batch in flight, so that the GPU parses batch k + 1 while the host builds the tables
+ * of batch k, whose reconstruction launches line up behind that parse.  Taken when both batches are GPU-parsed throughout and the
+ * queued batch's bitstreams are in the arena before the parse results of the batch in flight arrive; in every other case the two
+ * halves run in the plain order.  A streaming loop is: submit(k + 1) [deferred or zero-copy], hvq_flush_next, use batch k.
+ * HVQM4_AMD_FLUSH_NEXT=0: always the plain order. */
+int  hvq_flush_next(HvqContext *ctx);
 int  hvq_sync(HvqContext *ctx);
 
 /* Re-run the launches of the last flush `reps` times (descriptors already resident in HBM).

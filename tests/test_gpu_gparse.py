@@ -182,6 +182,91 @@ def test_pipelined_batches_begin_submit_next_end(gpu_ctx, gpu_parse):
         gpu_ctx.close_stream(sid)
 
 
+@pytest.mark.parametrize("submit_form", ["copy", "deferred", "arena", "host_parse"])
+def test_flush_next_streams_like_the_plain_pair(gpu_ctx, submit_form):
+    """hvq_flush_next = hvq_flush_end + hvq_flush_begin with the queued batch's parse kernel launched first: many small batches, so
+    that the two parse-buffer sets and the two arenas each come round several times; three streams of different length (one runs
+    out early, its later batches carry the others only); every picture against the oracle.  Host-parsed batches take the plain
+    order inside the call."""
+    from hvqm4_amd.container import parse_header, video_pictures
+    from oracle import bridge
+    cases = [clips.get(c) for c in (clips.SMALL[14], clips.SMALL[3], clips.SMALL[15])]      # 3 GOPs / 1 GOP / 1 GOP
+    hdrs = [parse_header(cl.data) for cl in cases]
+    pics = [list(video_pictures(cl.data)) for cl in cases]
+    sids = [gpu_ctx.open_stream(h.width, h.height, h.h_samp, h.v_samp, h.is15, len(p) + 3) for h, p in zip(hdrs, pics)]
+    step = 2
+    nb = max((len(p) + step - 1) // step for p in pics)
+    keep = []                                                    # deferred copies read the caller's buffers until the next flush
+
+    def submit(b):
+        a_s, a_t, a_p = [], [], []
+        for sid, p in zip(sids, pics):
+            for ft, _d, pic in p[b * step:(b + 1) * step]:
+                a_s.append(sid); a_t.append(ft); a_p.append(bytes(pic))
+        if not a_p:
+            return
+        keep.append(a_p)
+        if submit_form == "host_parse":
+            gpu_ctx.submit_many(a_s, a_t, a_p, 2)
+        elif submit_form == "arena":
+            offs, at = [], 0
+            for q in a_p:
+                offs.append(at); at += gpu_ctx.arena_stride(len(q))
+            view = gpu_ctx.arena_reserve(at)
+            for q, o in zip(a_p, offs):
+                view[o:o + len(q)] = np.frombuffer(q, np.uint8)
+            gpu_ctx.submit_many_arena(a_s, a_t, offs, [len(q) for q in a_p])
+        else:
+            gpu_ctx.submit_many_device(a_s, a_t, a_p, defer=submit_form == "deferred")
+
+    assert nb >= 6
+    submit(0)
+    gpu_ctx.flush_next()                                         # nothing in flight yet: a plain begin
+    for b in range(1, nb):
+        submit(b)
+        gpu_ctx.flush_next()
+    gpu_ctx.flush_next()                                         # nothing queued: a plain end
+    for sid, cl in zip(sids, cases):
+        want = bridge.oracle_decode(cl.data, cl.n_pictures)
+        for k in range(cl.n_pictures):
+            assert np.array_equal(gpu_ctx.read_picture(sid, k), want[k]), (cl.width, k)
+        gpu_ctx.close_stream(sid)
+
+
+def test_flush_next_and_the_plain_pair_mix(gpu_ctx):
+    """a caller may change between the two forms batch by batch (the parse-buffer set in use follows the batch in flight), and a
+    replay of the last ended batch still reads that batch's blobs"""
+    from hvqm4_amd.container import parse_header, video_pictures
+    from oracle import bridge
+    cl = clips.get(clips.SMALL[14])
+    hdr = parse_header(cl.data)
+    pics = list(video_pictures(cl.data))
+    sid = gpu_ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, len(pics) + 3)
+    step = 2
+    nb = (len(pics) + step - 1) // step
+
+    def submit(b):
+        part = pics[b * step:(b + 1) * step]
+        gpu_ctx.submit_many_device([sid] * len(part), [ft for ft, _d, _p in part], [bytes(p) for _ft, _d, p in part])
+
+    submit(0)
+    gpu_ctx.flush_begin()
+    for b in range(1, nb):
+        submit(b)
+        if b % 3 == 0:
+            gpu_ctx.flush_end(); gpu_ctx.flush_begin()
+        elif b % 3 == 1:
+            gpu_ctx.flush_next()
+        else:
+            gpu_ctx.flush_next()
+            gpu_ctx.replay(2)                                    # ends the batch begun just now, replays it twice
+    gpu_ctx.flush_end()
+    want = bridge.oracle_decode(cl.data, cl.n_pictures)
+    for k in range(cl.n_pictures):
+        assert np.array_equal(gpu_ctx.read_picture(sid, k), want[k]), k
+    gpu_ctx.close_stream(sid)
+
+
 def test_pathological_trees_cannot_stall_the_gpu_parser(gpu_ctx):
     """A one-leaf DC tree whose only value lies outside the overflow window makes every DC read spin until its cap
     (the reference would never return).  Full-size pictures of that kind, of zeros and of ones must come back

@@ -185,8 +185,10 @@ def test_clamped_nest_origin_is_refused_unless_opted_in(gpu_ctx, monkeypatch):
     gpu_ctx.close_stream(sid)
 
 
-def test_rejection_while_the_next_batch_of_the_stream_is_already_queued(gpu_ctx):
-    """Streaming: batch N is judged in hvq_flush_end when batch N+1 is queued already.  The P/B pictures of the rejected stream
+@pytest.mark.parametrize("step", ["flush_end", "flush_next"])
+def test_rejection_while_the_next_batch_of_the_stream_is_already_queued(gpu_ctx, step):
+    """Streaming: batch N is judged in hvq_flush_end (or hvq_flush_next, which has queued the parse of N+1 by then) when batch N+1 is
+    queued already.  The P/B pictures of the rejected stream
     in N+1 follow the rejected picture: they are dropped -- and must read as NOT resident, not as whatever their slot held --
     up to the stream's next I picture, which restarts it without any HVQ_E_STATE in between."""
     from hvqm4_amd._lib import HVQ_E_STATE, HVQ_E_UNSUPPORTED, HvqError
@@ -204,9 +206,9 @@ def test_rejection_while_the_next_batch_of_the_stream_is_already_queued(gpu_ctx)
     o_g = gpu_ctx.submit_many_device([sb] * len(gp), [p[0] for p in gp], [p[1] for p in gp])
     o_o = gpu_ctx.submit_many_device([so] * (len(gp) - 2), [p[0] for p in gp[2:]], [p[1] for p in gp[2:]])
     with pytest.raises(HvqError) as e:
-        gpu_ctx.flush_end()
+        getattr(gpu_ctx, step)()
     assert e.value.code == HVQ_E_UNSUPPORTED and f"stream {sb} picture 1" in str(e.value)
-    gpu_ctx.flush()                                              # batch N+1: no error of its own
+    gpu_ctx.flush()                                              # batch N+1 (begun already by flush_next): no error of its own
     assert gpu_ctx.stats().dropped == 2
     for o in o_b:                                                # the B pictures behind the rejected P: not resident
         with pytest.raises(HvqError) as e2:
