@@ -1491,7 +1491,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
      * them in vector registers). */
     auto front = [&](auto ctxc) {
         constexpr int CTX = decltype(ctxc)::value;
-        u32 off[TPW], cls[TPW], nb[TPW], e16v[TPW], w0v[TPW], pinI[TPW], pinM[TPW];
+        u32 off[TPW], cls[TPW], nb[TPW], e16v[TPW], w0v[TPW], pinI[TPW], pinM[TPW], npayv[TPW];
         bool lit[TPW], mcb[TPW], wdcb[TPW], flatb[TPW], hxb[TPW], hyb[TPW];
         unsigned long long m1[TPW], m2[TPW];
         McRows rows[TPW];
@@ -1502,6 +1502,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             e16v[h] = e16;
             u32 npay;
             inl_classify<CTX>(T, valid[h], cls[h], nb[h], npay, lit[h], mcb[h], wdcb[h], flatb[h]);
+            npayv[h] = npay;
             if (HVQ_ABL == 36 || HVQ_ABL == 37) { cls[h] = 0; nb[h] = 0; }          /* timing experiments: no queue derivation, no AOT work at all */
             w0v[h] = 0; hxb[h] = false; hyb[h] = false;
             if (CTX == 2) {
@@ -1519,6 +1520,32 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                 a = clampi(a, 0, hyb[h] ? hi4 : hi3);
                 if (mcb[h]) w0v[h] = roff + (u32)a;
             }
+        }
+        /* ---- trip 3: motion-compensation rows, requested before the rest of the front (neighbour values, scan, slots, lists) so that
+         * those 6 000 cycles run beside the gathers instead of in front of them ---- */
+        if (CTX == 2) {
+#pragma unroll
+            for (int h = 0; h < TPW; ++h) {
+                if (mcb[h]) {
+                    const u32 vo = w0v[h];
+                    /* timing experiments (tools/variant.sh <name> -DHVQ_ABL=n; wrong pictures): 31 no phase-A arithmetic, 32 no item epilogues,
+                     * 33 no pair work, 34 no motion-compensation row loads, 35 no stores */
+                    if (HVQ_ABL == 34 || HVQ_ABL == 37) {
+#pragma unroll
+                        for (int y = 0; y < 5; ++y) rows[h].q[y] = (uint64_t)vo * 0x0101010101ull + (uint64_t)y;
+                        continue;
+                    }
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)y * pw));
+                    rows[h].q[4] = 0;
+                    if (hyb[h]) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + 4u * pw));
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < TPW; ++h) {
+            const u32 V = e16v[h] & 0xFFu;
+            const u32 npay = npayv[h];
             if (wdcb[h]) {
                 /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
                  * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
@@ -1543,27 +1570,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                 pinI[h] = inc >> 16; pinM[h] = 0;
             }
         }
-        STAMP(4, 0);                                                           /* classes, operands, scan */
-        /* ---- trip 3: motion-compensation rows ---- */
-        if (CTX == 2) {
-#pragma unroll
-            for (int h = 0; h < TPW; ++h) {
-                if (mcb[h]) {
-                    const u32 vo = w0v[h];
-                    /* timing experiments (tools/variant.sh <name> -DHVQ_ABL=n; wrong pictures): 31 no phase-A arithmetic, 32 no item epilogues,
-                     * 33 no pair work, 34 no motion-compensation row loads, 35 no stores */
-                    if (HVQ_ABL == 34 || HVQ_ABL == 37) {
-#pragma unroll
-                        for (int y = 0; y < 5; ++y) rows[h].q[y] = (uint64_t)vo * 0x0101010101ull + (uint64_t)y;
-                        continue;
-                    }
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)y * pw));
-                    rows[h].q[4] = 0;
-                    if (hyb[h]) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + 4u * pw));
-                }
-            }
-        }
+        STAMP(4, 0);                                                           /* classes, rows requested, operands, scan */
         if (q_offs_off) {                                               /* self-referencing P picture: hvq_selfref_kernel wants the pool offsets */
 #pragma unroll
             for (int h = 0; h < TPW; ++h)
