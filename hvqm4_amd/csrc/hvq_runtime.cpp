@@ -1859,7 +1859,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
         static const char *seg_q[10] = { "job + queue records", "prologue loads issue + land", "phase A (MC rows, cheap kinds, literals)", "barrier 1",
                                          "B1 pairs", "barrier 2 (item record in flight)", "B2 items", "barrier 3", "store issue", "stores land" };
         static const int from_q[10] = { 0, 1, 2, 3, 4, 7, 8, 9, 10, 12 }, to_q[10] = { 1, 2, 3, 4, 7, 8, 9, 10, 12, 13 };
-        static const char *seg_i[14] = { "job record (+ early barrier)", "trip 2 issue", "trip 2 lands", "classes, records, scans", "rows requested, slots, lists",
+        static const char *seg_i[14] = { "job record (+ early barrier)", "trip 2 issue", "trip 2 lands", "classes, rows requested, scans", "slots, lists",
                                          "rows land", "phase A", "barrier 1", "pair phase (B1)", "barrier 2", "item phase (B2)", "barrier 3", "store issue", "stores land" };
         static const int from_i[14] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13 }, to_i[14] = { 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14 };
         for (auto &L : c->launches) {
