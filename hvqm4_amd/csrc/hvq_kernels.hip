@@ -1512,8 +1512,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                 const u32 roff = (T & 0x60u) == 0x20u ? ref0_off : ref1_off;
                 const u32 hsx = is15 ? ws : 0u, hsy = is15 ? hs : 0u;                /* 1.5: the plane's own vector decides, 1.3: the luma vector */
                 hxb[h] = (rx >> hsx) & 1; hyb[h] = (ry >> hsy) & 1;
-                const i32 rowi = (ry >> (hs + 1u)) + (i32)((by[h] & (1u - hs)) << 2);   /* |rowi| < 2^15, pw < 2^14: a 24-bit multiply is exact */
-                const i32 coli = (rx >> (ws + 1u)) + (i32)((bx[h] & (1u - ws)) << 2) + (i32)plane_off;
+                /* HVQ_ABL 38 (timing experiment): every block fetched from its own position (vector 0), half-sample flags kept: prices the scatter */
+                const i32 rowi = HVQ_ABL == 38 ? (i32)(by[h] << 2) : (ry >> (hs + 1u)) + (i32)((by[h] & (1u - hs)) << 2);   /* |rowi| < 2^15, pw < 2^14: a 24-bit multiply is exact */
+                const i32 coli = (HVQ_ABL == 38 ? (i32)(bx[h] << 2) : (rx >> (ws + 1u)) + (i32)((bx[h] & (1u - ws)) << 2)) + (i32)plane_off;
                 i32 a = __mul24(rowi, (i32)pw) + coli;
                 /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
                 const i32 hi3 = slot - 8 - 3 * (i32)pw, hi4 = hi3 - (i32)pw;
