@@ -364,6 +364,9 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 #ifndef HVQ_NT_LOADS
 #define HVQ_NT_LOADS 0         /* experiment: the map entries loaded non-temporally */
 #endif
+#ifndef HVQ_PRIO
+#define HVQ_PRIO 0            /* 1: head at issue priority 3 until trip 2 is issued; 2: until the motion-compensation rows are requested */
+#endif
 #ifndef HVQ_NT_STORES
 #define HVQ_NT_STORES 1        /* B pictures leave with non-temporal stores (0: plain stores; A/B in profiles/r05_recon_steps.txt) */
 #endif
@@ -1338,6 +1341,11 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const int tid = threadIdx.x;
     const u32 lane = (u32)tid & 63u;
     STAMP(0, 0);
+#if HVQ_PRIO == 1 || HVQ_PRIO == 2
+    /* issue priority experiment: a new wave's head (a few instructions between long waits) goes in front of the older waves' arithmetic,
+     * so that its loads are under way while they compute (the arbiter is oldest-first otherwise) */
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
     const u32 wg = blockIdx.y;
     const HvqJob *__restrict__ J = jobs + slot_id;
@@ -1483,6 +1491,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         return j < nst ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
     };
 
+#if HVQ_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     STAMP(2, 0);                                                               /* trip 2 issued (the stamp itself waits for the scalar loads) */
     STAMP(3, 1);                                                               /* ... and landed (stamped builds wait here) */
     /* Everything from here to barrier 1 exists three times, once per context of the plane (I-picture luma, I-picture chroma, P/B
@@ -1543,6 +1554,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
                 }
             }
         }
+#if HVQ_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int h = 0; h < TPW; ++h) {
             const u32 V = e16v[h] & 0xFFu;
@@ -1638,6 +1652,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             }
         }
 
+#if HVQ_PRIO == 4
+        __builtin_amdgcn_s_setprio(3);                                         /* 4: everything from phase A on goes first */
+#endif
         STAMP(5, 0);                                                           /* rows requested, slots, items and pairs in LDS */
         STAMP(6, 1);                                                           /* rows landed */
         /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
@@ -1782,6 +1799,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         }
     }
     STAMP(11, 0);                                                              /* item phase */
+#if HVQ_PRIO == 3
+    __builtin_amdgcn_s_setprio(3);                                             /* 3: the stores of a finished tile go first */
+#endif
     __syncthreads();                                                           /* barrier 3: tiles complete in LDS */
     STAMP(12, 0);
 
