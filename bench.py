@@ -311,7 +311,7 @@ def main():
     # records, literal / item / pair lists from the descriptors) AND the reconstruction launches of all dependency levels.
     # untimed pre-roll: the measurement that runs first otherwise reads ~3 % low (the same launches measured a second time come out
     # faster: clocks still ramping after the host-bound parity check), then the W warm-up steps the contract asks for
-    PREROLL = 20
+    PREROLL = int(os.environ.get("HVQM4_BENCH_PREROLL", "20"))
     ctx.replay_stage(PREROLL, 1)
     for _ in range(args.warmup):
         ctx.replay_stage(1, 1)

@@ -1378,7 +1378,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const u32 nplane_tiles = p == 0 ? n0 : p == 1 ? n1 : n2;
     const u32 pairw = wg - (p == 0 ? 0u : p == 1 ? pf1 : pf2);
     const u32 tile0 = tile_first + (u32)TPW * pairw;
-    const int ntl = (int)min((u32)TPW, nplane_tiles - (u32)TPW * pairw);
+    /* wg < pend: the workgroup has at least one tile; with one tile per workgroup that is all there is to know (a constant frees the
+     * scalar registers the 64-bit `h < ntl` masks held from here to phase C: the kernel sits at its cap of 80) */
+    const int ntl = TPW == 1 ? 1 : (int)min((u32)TPW, nplane_tiles - (u32)TPW * pairw);
     const uint64_t map_a = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
     const uint64_t dst_a = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
     const u32 plane_off = w[4];
@@ -1423,7 +1425,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 #pragma unroll
     for (int h = 0; h < TPW; ++h) wbase[h] = h < ntl ? wave_base[(tile0 + (u32)h) * HVQ_NW + wave] : 0u;
     bool valid[TPW];
-    u32 bx[TPW], by[TPW], wby0[TPW], wbx0[TPW];
+    u32 bx[TPW], by[TPW];
     uint64_t row8[TPW];
     u32 nt[TPW], nbt[TPW], mvw[TPW];
 #pragma unroll
@@ -1446,7 +1448,6 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         if (hb >= 64u) q = t >= hb ? 1u : 0u;
         else q = __umul24(t, magic16) >> 16;
         bx[h] = t - __umul24(q, hb); by[h] = by0 + q;
-        wby0[h] = by0; wbx0[h] = bx0;
         /* entry (by, bx) of the bordered map = b + 2 by + hb + 3 */
         const GLB uint8_t *mw = map + 2u * (size_t)(bws + 2u * by0 + hb + 3u);
         const u32 vo2 = 2u * (l + 2u * q);
@@ -1484,11 +1485,13 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
         for (u32 r0 = 0; r0 < nch; r0 += HVQ_WG)
             if (r0 + (u32)tid < nch) __builtin_amdgcn_global_load_lds((const GLB u32 *)(pool_lo + 16u * (r0 + (u32)tid)), (lds_u32 *)(s_pool + 4u * (r0 + wave * 64u)), 16, 0, 0);
     }
-    const bool all_staged = phi - plo4 <= pool_cap;                            /* uniform, and true unless a tile's payload exceeds the launch's LDS share */
+    /* staged dwords as the lanes compare against: everything (every index the descriptors produce lies inside the tile's range) unless the
+     * tile's payload exceeds the launch's LDS share.  One scalar, not a uniform condition: as a 64-bit mask that condition lived in two
+     * scalar registers from here to the item phase, was spilled to vector-register lanes and read back at every call (two tiles). */
+    const u32 nst_lim = phi - plo4 <= pool_cap ? 0xFFFFFFFFu : nst;
     auto pool_at = [&](u32 idx) -> u32 {                                       /* a dword of the payload pool: staged, or (beyond the staging cap) from HBM */
         const u32 j = idx - plo4;
-        if (all_staged) return s_pool[j];                                       /* every index the descriptors produce lies inside the tile's range */
-        return j < nst ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
+        return j < nst_lim ? s_pool[j] : pool[min(idx, pool_dwords ? pool_dwords - 1u : 0u)];
     };
 
 #if HVQ_PRIO == 1
@@ -1807,21 +1810,32 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 
     /* ---- phase C: tiles -> HBM ---- */
     if ((HVQ_ABL == 35 || HVQ_ABL == 37) && s_out[0][0][tid] != 0x12345678u) return;
+    /* The wave's first block is split into (row, column) AGAIN here, on the scalar unit (six instructions), from copies of b0, hb and
+     * nblocks the compiler cannot connect with the head's: what trip 2 derived -- per tile the two coordinates and three 64-bit lane
+     * masks -- would otherwise stay in scalar registers from the head to this point, the kernel sits at its cap of 80 (above it a CU
+     * takes seven workgroups, not eight), and the surplus went to vector-register lanes: 7 (one tile) / 59 (two tiles) v_writelane and
+     * as many and more v_readlane per wave, each a vector instruction in a kernel bound by those. */
+    u32 b0c = b0, hbc = hb, nbc = nblocks;
+    asm volatile("" : "+s"(b0c), "+s"(hbc), "+s"(nbc));
 #pragma unroll
     for (int h = 0; h < TPW; ++h) {
         if (h >= ntl) continue;
-        const u32 bw = b0 + (u32)(h * HVQ_TILE_BLOCKS) + wave * 64u;
-        if ((hb & 3u) == 0) {
+        const u32 bw = b0c + (u32)(h * HVQ_TILE_BLOCKS) + wave * 64u;
+        if ((hbc & 3u) == 0) {
             /* lane (g, r): sample row r of blocks 4g .. 4g + 3 = 16 contiguous bytes of the plane (rows are multiples of 4 blocks) */
             const u32 g4 = 4u * (lane & 15u), rr = lane >> 4;
             const u32 gb = bw + g4;
-            if (gb < nblocks) {
+            if (gb < nbc) {
                 /* the row's four blocks lie in one map row (rows are multiples of 4 blocks, the wave's first block is one of 64) */
-                const u32 t = wbx0[h] + g4;
+                const u32 bws = bw < nbc ? bw : 0u;
+                u32 cy0 = __umulhi(bws, magic);
+                if ((i32)(bws - cy0 * hbc) < 0) cy0 -= 1u;
+                const u32 cx0 = bws - cy0 * hbc;
+                const u32 t = cx0 + g4;
                 u32 q;
-                if (hb >= 64u) q = t >= hb ? 1u : 0u;
+                if (hbc >= 64u) q = t >= hbc ? 1u : 0u;
                 else q = __umul24(t, magic16) >> 16;
-                const u32 gx = t - __umul24(q, hb), gy = wby0[h] + q;
+                const u32 gx = t - __umul24(q, hbc), gy = cy0 + q;
                 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 v = *(const u32x4 *)&s_out[h][rr][wave * 64u + g4];
                 const u32 doff = (gy * 4u + rr) * pw + gx * 4u;
@@ -1834,9 +1848,9 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 #endif
                     *(GLB u32x4 *)(plane + (size_t)doff) = v;
             }
-        } else if (bw + lane < nblocks) {
+        } else if (bw + lane < nbc) {
             i32 sx, sy;
-            block_coords(bw + lane, (i32)hb, __builtin_amdgcn_rcpf((float)hb), sx, sy);
+            block_coords(bw + lane, (i32)hbc, __builtin_amdgcn_rcpf((float)hbc), sx, sy);
             GLB uint8_t *dst = plane + (size_t)(sy * 4) * pw + sx * 4;
 #pragma unroll
             for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[h][y][tid];
