@@ -1864,10 +1864,13 @@ template <int ITEMS_CAP, int TPW>
 static void launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_t max_wgs, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream)
 {
     const dim3 grid = nslots >= 8 ? dim3(8, max_wgs, nslots / 8) : dim3(nslots, max_wgs, 1);
+    /* HVQM4_AMD_LDS_PAD (measurements only): unused dynamic LDS behind the pair list and the staged pool, to run a launch at a lower
+     * residency than its own footprint allows (what does the step cost with 7, 6, 5 workgroups per CU?) */
+    static const size_t lds_pad = getenv("HVQM4_AMD_LDS_PAD") ? (size_t)atoi(getenv("HVQM4_AMD_LDS_PAD")) : 0;
 #ifdef HVQ_STAMPS
-    hipLaunchKernelGGL((hvq_recon_inline_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), (size_t)(pair_cap + pool_cap) * 4u, stream, jobs_dev, pair_cap, pool_cap, g_stamps);
+    hipLaunchKernelGGL((hvq_recon_inline_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), (size_t)(pair_cap + pool_cap) * 4u + lds_pad, stream, jobs_dev, pair_cap, pool_cap, g_stamps);
 #else
-    hipLaunchKernelGGL((hvq_recon_inline_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), (size_t)(pair_cap + pool_cap) * 4u, stream, jobs_dev, pair_cap, pool_cap);
+    hipLaunchKernelGGL((hvq_recon_inline_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), (size_t)(pair_cap + pool_cap) * 4u + lds_pad, stream, jobs_dev, pair_cap, pool_cap);
 #endif
 }
 
