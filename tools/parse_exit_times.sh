@@ -8,7 +8,7 @@ tag=${1:-pet}; shift
 out=gpurun_out/$tag; mkdir -p $out
 words=${@:-1 13 269 1549 1805 12 3 4 9 10 6}
 for e in $words; do
-  HVQM4_AMD_PARSE_EXIT=$e HVQM4_AMD_LIB=$PWD/hvqm4_amd/abl/libhvq_probe.so timeout -k 10 120 python tools/overlap_probe.py 8 1 128 > $out/e$e.txt 2>&1 || { tail -3 $out/e$e.txt; exit 1; }
+  HVQM4_AMD_PARSE_EXIT=$e HVQM4_AMD_LIB=$PWD/hvqm4_amd/abl/libhvq_${PROBE_LIB:-probe}.so timeout -k 10 120 python tools/overlap_probe.py 8 1 128 > $out/e$e.txt 2>&1 || { tail -3 $out/e$e.txt; exit 1; }
   python3 - $out/e$e.txt $e <<'PY'
 import re, sys
 t = sorted(float(m.group(1)) for m in re.finditer(r"exit at stamp \d+: ([0-9.]+) ms", open(sys.argv[1]).read()))
