@@ -410,6 +410,64 @@ def main():
         # (c) the plain pair hvq_flush_end / hvq_flush_begin (rounds 2-4's loop): the GPU idles between a batch's parse kernel and its
         # first reconstruction launch while the host reads the results and builds the tables
         pp_pipe, pp_median, pp_calls, _pp = stream_loop(lambda: ctx2.submit_many_device(a_sid2, a_ft, a_raw, defer=True), plain_pair=True)
+        # (d) the same 128 streams over TWO contexts of this process (even / odd streams), each fed by its own thread: their parse kernels
+        # are half the size and out of phase -- one context's pictures sit in the scalar chains while the other's are in the all-thread
+        # passes or being reconstructed -- which is what a single launch of 2048 pictures cannot arrange (profiles/r05_flush_next.txt)
+        two_ctx = None
+        nctx = int(os.environ.get("HVQM4_BENCH_STREAM_CONTEXTS", "2"))
+        if len(sids) >= nctx >= 2:
+            import threading
+            halves = []
+            for hh in range(nctx):
+                cx = batch.Context(device)
+                sid_of = {s: cx.open_stream(clips[stream_clip[s]].width, clips[stream_clip[s]].height, 2, 2, clips[stream_clip[s]].version == "1.5", args.nslots)
+                          for s in range(len(sids)) if s % nctx == hh}
+                idx = [i for i, s in enumerate(a_stream) if s % nctx == hh]
+                halves.append((cx, sid_of, [sid_of[a_stream[i]] for i in idx], [a_ft[i] for i in idx], [a_raw[i] for i in idx]))
+
+            def half_loop(cx, _sid_of, hs, ht, hp, n, marks):
+                cx.submit_many_device(hs, ht, hp, defer=True)
+                cx.flush_begin()
+                for _ in range(n):
+                    cx.submit_many_device(hs, ht, hp, defer=True)
+                    cx.flush_next()
+                    marks.append(time.perf_counter())
+                cx.flush_end()
+                cx.sync()
+
+            for hv in halves:                                   # buffers sized, both arenas and parse-buffer sets in use
+                half_loop(*hv, 3, [])
+            barrier()
+            marks = [[] for _ in halves]
+            th = [threading.Thread(target=half_loop, args=(*halves[i], nwarm + nbatch, marks[i])) for i in range(nctx)]
+            for t in th: t.start()
+            for t in th: t.join()
+            n_batches_half = 4 + 1 + nwarm + nbatch               # batches each context has seen
+            per = [(m[-1] - m[nwarm]) / (len(m) - 1 - nwarm) for m in marks]
+            px_half = [sum(clips[stream_clip[s]].width * clips[stream_clip[s]].height * len(pics[stream_clip[s]]) for s in hv[1]) for hv in halves]
+            rate2 = sum(p_ / t_ for p_, t_ in zip(px_half, per)) / 1e6
+            ok2 = 0
+            n_seq = [len(pics[stream_clip[s]]) for s in range(len(sids))]
+            for hv in halves:                                    # the last batch of either context against the host-parsed pictures
+                for s in sorted(hv[1])[:2]:
+                    for k in range(n_seq[s]):
+                        try:
+                            a = ctx.read_picture(sids[s], k); b = hv[0].read_picture(hv[1][s], k + (n_batches_half - 1) * n_seq[s])
+                        except HvqError as e:
+                            if e.code != HVQ_E_STATE:
+                                raise
+                            continue
+                        if not np.array_equal(a, b):
+                            raise SystemExit(f"PARITY FAILURE: two-context streaming, stream {s} picture {k} differs from the host-parsed one")
+                        ok2 += 1
+            if ok2 < 1:
+                raise SystemExit("PARITY CHECK INCOMPLETE on the two-context streaming leg")
+            two_ctx = {"value": round(grp.sum(rate2), 1), "unit": "Mpixels/s", "contexts": nctx,
+                       "ms_per_batch_of_each_context": [round(t_ * 1e3, 2) for t_ in per], "pictures_checked_against_host_parsed": ok2,
+                       "what": "the same streams dealt to %d contexts of the process (stream s to context s mod %d, one thread each, hvq_flush_next): "
+                               "smaller parse kernels out of phase with each other and with the other contexts' reconstruction" % (nctx, nctx)}
+            for hv in halves:
+                hv[0].close()
         n_done = 3 + 3 * (nwarm + nbatch)
         ok = 0
         ok_per_stream = []
@@ -509,6 +567,7 @@ def main():
                                             "submit_end_begin_ms": pp_calls,
                                             "what": "the same loop with hvq_flush_end + hvq_flush_begin in place of hvq_flush_next (the loop of "
                                                     "rounds 2-4): the host's part of a batch is not hidden behind the next batch's parse kernel"},
+                   "streaming_two_contexts": two_ctx,
                    "affinity": {"cores_of_rank0": len(my_cores), "first": my_cores[0], "last": my_cores[-1], "ranks_on_host": local_world,
                                 "pinned": local_world > 1, "numa_node_of_gpu": my_node, "core_choice": pin_how},
                    "pictures_checked_against_host_parsed": ok,

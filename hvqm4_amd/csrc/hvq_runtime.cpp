@@ -450,7 +450,17 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     c->tile_queues = env_tile_queues();
     struct Guard { HvqContext *c; ~Guard() { if (c) hvq_context_destroy(c); } } guard{ c };     /* a failing step below frees what exists */
     HIPCHK(hvq_upload_tables());
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {   /* The launch stream at the highest stream priority: the runtime deals a process's streams to four hardware queues in the order of
+         * their creation, per priority level -- with a copy and a read-back stream per context, the launch streams of two contexts (two
+         * players of one process, bench.py's two-context streaming leg) landed on ONE hardware queue and their kernels ran one after the
+         * other (4.6 ms per half batch each instead of 3.6: profiles/r05_flush_next.txt 6).  At a level of their own the launch streams of
+         * up to four contexts get a queue each.  HVQM4_AMD_STREAM_PRIORITY=0: plain streams as before. */
+        int lo = 0, hi = 0;
+        static const bool prio = !(getenv("HVQM4_AMD_STREAM_PRIORITY") && atoi(getenv("HVQM4_AMD_STREAM_PRIORITY")) == 0);
+        if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+            HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+        else HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->read_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));

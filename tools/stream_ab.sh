@@ -11,9 +11,9 @@ for r in $(seq 1 $reps); do
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 e = d["end_to_end_gpu_parse"]
-print("%-24s streaming %8.1f (%.2f ms, median %.2f) | zero copy %8.1f | plain pair %8.1f (%.2f ms) | parse kernel %.3f ms | recon frac %.4f" % (
+print("%-24s streaming %8.1f (%.2f ms, median %.2f) | zero copy %8.1f | plain pair %8.1f (%.2f ms) | two contexts %8.1f | parse kernel %.3f ms | recon frac %.4f" % (
     sys.argv[2], e["streaming_value"], e["streaming_ms_per_batch"], e["streaming_ms_per_batch_median"], e["streaming_zero_copy"]["value"],
-    e["streaming_plain_pair"]["value"], e["streaming_plain_pair"]["ms_per_batch"], e["streaming_parse_kernel_ms"], d["roofline"]["frac"]))
+    e["streaming_plain_pair"]["value"], e["streaming_plain_pair"]["ms_per_batch"], (e.get("streaming_two_contexts") or {}).get("value", 0.0), e["streaming_parse_kernel_ms"], d["roofline"]["frac"]))
 PY
   done
 done
