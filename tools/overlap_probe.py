@@ -58,11 +58,24 @@ if __name__ == "__main__":
     px = per * 16 * 640 * 480
     print("one context of %d streams: %d batches in %.1f ms = %.3f ms per batch = %.1f Gpixel/s" % (per, nb + 1, t1 * 1e3, t1 * 1e3 / (nb + 1), px * (nb + 1) / t1 / 1e9))
     outs = [[] for _ in range(nctx)]
-    th = [threading.Thread(target=stream_loop, args=(*ctxs[i], nb, outs[i])) for i in range(nctx)]
-    t0 = time.perf_counter()
-    for t in th: t.start()
-    for t in th: t.join()
-    t2 = time.perf_counter() - t0
+    if os.environ.get("PROBE_ONE_THREAD", "0") == "1":      # ONE thread drives all contexts in turn (submit / flush_next of A, then of B, ...)
+        t0 = time.perf_counter()
+        for c, a_s, a_t, a_p in ctxs:
+            c.submit_many_device(a_s, a_t, a_p, defer=True); c.flush_begin()
+        for _ in range(nb):
+            for c, a_s, a_t, a_p in ctxs:
+                c.submit_many_device(a_s, a_t, a_p, defer=True); c.flush_next()
+        for c, *_ in ctxs:
+            c.flush_end()
+        for c, *_ in ctxs:
+            c.sync()
+        t2 = time.perf_counter() - t0
+    else:
+        th = [threading.Thread(target=stream_loop, args=(*ctxs[i], nb, outs[i])) for i in range(nctx)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        t2 = time.perf_counter() - t0
     print("%d contexts of %d streams side by side: %d x %d batches in %.1f ms = %.1f Gpixel/s (one context alone: %.1f)" % (
         nctx, per, nctx, nb + 1, t2 * 1e3, nctx * px * (nb + 1) / t2 / 1e9, px * (nb + 1) / t1 / 1e9))
     for ctx, *_ in ctxs:
