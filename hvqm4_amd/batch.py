@@ -198,3 +198,66 @@ def decode_clip(ctx: Context, data: bytes, nslots: Optional[int] = None, gpu_par
     out = np.stack([ctx.read_picture(sid, i) for i in range(len(pics))])
     ctx.close_stream(sid)
     return out
+
+
+class PairedContexts:
+    """The streaming subset of Context over TWO contexts of one GPU, driven by one thread: streams are dealt to the contexts in turn, a
+    submit splits its pictures by their stream's context, flush_next() advances context A, then context B.  While the call waits for
+    one context's parse results the other context's kernels run, and the two half-size parse kernels stay out of phase (one context's
+    pictures in the scalar chains while the other's are in the all-thread passes or being reconstructed): 169-173 Gpixel/s against
+    158-160 for the same 128 dense streams in one context (profiles/r05_flush_next.txt 6; INTEGRATION.md "Two contexts per GPU" is the
+    same recipe in C).  Stream ids are the pair's own."""
+
+    def __init__(self, device: int = 0):
+        self._ctx = [Context(device), Context(device)]
+        self._where = []                                   # pair stream id -> (context index, stream id inside it)
+
+    def open_stream(self, width: int, height: int, h_samp: int = 2, v_samp: int = 2, is15: bool = True, nslots: int = 4) -> int:
+        k = len(self._where) & 1
+        self._where.append((k, self._ctx[k].open_stream(width, height, h_samp, v_samp, is15, nslots)))
+        return len(self._where) - 1
+
+    def submit_many_device(self, sids, frame_types, pictures, defer: bool = False):
+        """as Context.submit_many_device; the returned ordinals are per stream, as there"""
+        part = ([], [], [], []), ([], [], [], [])
+        for i, sid in enumerate(sids):
+            k, inner = self._where[sid]
+            part[k][0].append(inner); part[k][1].append(frame_types[i]); part[k][2].append(pictures[i]); part[k][3].append(i)
+        ords = [0] * len(sids)
+        for k in (0, 1):
+            if part[k][0]:
+                for i, o in zip(part[k][3], self._ctx[k].submit_many_device(part[k][0], part[k][1], part[k][2], defer=defer)):
+                    ords[i] = o
+        return ords
+
+    def flush_begin(self) -> None:
+        for c in self._ctx:
+            c.flush_begin()
+
+    def flush_next(self) -> None:
+        for c in self._ctx:
+            c.flush_next()
+
+    def flush_end(self) -> None:
+        for c in self._ctx:
+            c.flush_end()
+
+    def flush(self) -> None:
+        self.flush_begin()
+        self.flush_end()
+
+    def sync(self) -> None:
+        for c in self._ctx:
+            c.sync()
+
+    def read_picture(self, sid: int, ordinal: int) -> np.ndarray:
+        k, inner = self._where[sid]
+        return self._ctx[k].read_picture(inner, ordinal)
+
+    def stats(self):
+        return [c.stats() for c in self._ctx]
+
+    def close(self) -> None:
+        for c in self._ctx:
+            c.close()
+

@@ -233,6 +233,47 @@ def test_flush_next_streams_like_the_plain_pair(gpu_ctx, submit_form):
         gpu_ctx.close_stream(sid)
 
 
+def test_paired_contexts_stream_like_one(gpu_ctx):
+    """batch.PairedContexts: the streams dealt to two contexts of the GPU, one thread advancing them in turn with hvq_flush_next; every
+    picture of every stream against the oracle, ordinals per stream as with one context"""
+    from hvqm4_amd import batch
+    from hvqm4_amd.container import parse_header, video_pictures
+    from oracle import bridge
+    cases = [clips.get(c) for c in (clips.SMALL[14], clips.SMALL[3], clips.SMALL[15], clips.SMALL[4], clips.SMALL[3])]
+    hdrs = [parse_header(cl.data) for cl in cases]
+    pics = [list(video_pictures(cl.data)) for cl in cases]
+    pair = batch.PairedContexts(0)
+    sids = [pair.open_stream(h.width, h.height, h.h_samp, h.v_samp, h.is15, len(p) + 3) for h, p in zip(hdrs, pics)]
+    step = 2
+    nb = max((len(p) + step - 1) // step for p in pics)
+    keep, ords = [], [[] for _ in sids]
+
+    def submit(b):
+        a_s, a_t, a_p, a_i = [], [], [], []
+        for i, (sid, p) in enumerate(zip(sids, pics)):
+            for ft, _d, pic in p[b * step:(b + 1) * step]:
+                a_s.append(sid); a_t.append(ft); a_p.append(bytes(pic)); a_i.append(i)
+        if a_p:
+            keep.append(a_p)
+            for i, o in zip(a_i, pair.submit_many_device(a_s, a_t, a_p, defer=True)):
+                ords[i].append(o)
+
+    submit(0)
+    pair.flush_begin()
+    for b in range(1, nb):
+        submit(b)
+        pair.flush_next()
+    pair.flush_end()
+    pair.sync()
+    for i, (sid, cl) in enumerate(zip(sids, cases)):
+        assert ords[i] == list(range(cl.n_pictures))
+        want = bridge.oracle_decode(cl.data, cl.n_pictures)
+        for k in range(cl.n_pictures):
+            assert np.array_equal(pair.read_picture(sid, k), want[k]), (i, k)
+    assert sum(st.gpu_parsed for st in pair.stats()) > 0
+    pair.close()
+
+
 def test_flush_next_and_the_plain_pair_mix(gpu_ctx):
     """a caller may change between the two forms batch by batch (the parse-buffer set in use follows the batch in flight), and a
     replay of the last ended batch still reads that batch's blobs"""
