@@ -61,7 +61,7 @@ class HvqStats(C.Structure):
                 ("descriptor_bytes", C.c_uint64), ("launches", C.c_uint32), ("workgroups", C.c_uint32),
                 ("parse_seconds", C.c_double), ("flags_or", C.c_uint32), ("gpu_parsed", C.c_uint32),
                 ("gpu_parse_ms", C.c_double), ("gpu_parse_retried", C.c_uint32), ("dropped", C.c_uint32),
-                ("pad0", C.c_uint32), ("queue_bytes", C.c_uint64), ("copy_bytes", C.c_uint64), ("copy_seconds", C.c_double)]
+                ("launch_queues", C.c_uint32), ("queue_bytes", C.c_uint64), ("copy_bytes", C.c_uint64), ("copy_seconds", C.c_double)]
 
 
 # every symbol include/hvqm4.h and include/hvqm4_amd.h declare: (restype, argtypes)

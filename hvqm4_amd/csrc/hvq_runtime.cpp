@@ -179,6 +179,7 @@ struct Pending {
 
 struct Launch {
     int level;
+    int queue;                         /* launch queue (0: the main stream, 1: stream2) */
     uint32_t first_tile, ntiles;       /* its picture slots in the launch table: first entry, count */
     uint32_t max_tiles, workgroups;    /* grid = (8, max_tiles, slots / 8) at the chosen tiles per workgroup; workgroups that do work */
     uint32_t max_wg[2], wgs[2];        /* the same for one / two tiles per workgroup (chosen at flush_end, when the queues are known) */
@@ -202,6 +203,7 @@ static bool env_tile_queues()
  * (unless it is there already), then the raster-order walk (hvq_selfref_kernel) from the side buffer */
 struct SelfRef {
     int level;
+    int queue;                         /* the launch queue of its picture's level launch */
     uint32_t job;                      /* launch slot */
     const uint8_t *old_dev;            /* device source of the previous content, nullptr: in place already */
     const void *old_host;              /* SDK path: host source */
@@ -214,6 +216,8 @@ struct HvqContext {
     int device = 0;
     bool tile_queues = false;          /* two-pass reconstruction over tile queues in HBM (HVQM4_AMD_TILE_QUEUES=1) */
     hipStream_t stream = nullptr;      /* every launch of a batch: its dependency levels in order */
+    hipStream_t stream2 = nullptr;     /* second launch queue (created on first use): the levels of the odd streams, see build_tiles */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<Stream> streams;
     /* staging: pinned host arena mirrored by a device arena */
@@ -513,6 +517,9 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     for (auto e : c->ev_arena_free) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->read_stream) { (void)hipStreamSynchronize(c->read_stream); (void)hipStreamDestroy(c->read_stream); }
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_read) (void)hipEventDestroy(c->ev_read);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tq_dev) (void)hipFree(c->tq_dev);
@@ -1322,14 +1329,45 @@ static int run_queue_build(HvqContext *c, bool count_bytes)
 /* enqueue all launches of the resident batch once, dependency level by dependency level, on the context's one launch stream.  (Rounds
  * 1-4 could deal the levels of even and odd streams to two HIP streams, HVQM4_AMD_QUEUES=2: it lost 7-9 % in every evidence line of
  * round 4 -- two grids of this kernel get in each other's way -- and was removed in round 5.) */
+/* the second launch queue forks from the main stream (everything queued there so far is done before its first launch) ... */
+static int queues_fork(HvqContext *c, bool *two)
+{
+    *two = false;
+    for (auto &L : c->launches) *two |= L.queue == 1;
+    if (!*two) return HVQ_OK;
+    if (!c->stream2) {
+        /* at the launch streams' priority level (hvq_context_create): a hardware queue of its own */
+        int lo = 0, hi = 0;
+        static const bool prio = !(getenv("HVQM4_AMD_STREAM_PRIORITY") && atoi(getenv("HVQM4_AMD_STREAM_PRIORITY")) == 0);
+        if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+            HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
+        else HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    return HVQ_OK;
+}
+
+/* ... and joins it again: whatever is queued on the main stream next runs behind both queues */
+static int queues_join(HvqContext *c, bool two)
+{
+    if (!two) return HVQ_OK;
+    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return HVQ_OK;
+}
+
+/* one pass over the launches of the resident batch, every launch on its queue (between queues_fork and queues_join) */
 static int run_launches(HvqContext *c)
 {
-    hipStream_t st = c->stream;
     for (auto &L : c->launches) {
+        hipStream_t st = L.queue ? c->stream2 : c->stream;
         if (L.inline_queues) HIPCHK(hvq_launch_recon_inline(c->jobs_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, L.pool_cap, st));
         else HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, st));
         for (const SelfRef &sr : c->selfrefs) {
-            if (sr.level != L.level) continue;
+            if (sr.level != L.level || sr.queue != L.queue) continue;
             if (sr.old_host) HIPCHK(hipMemcpyAsync(sr.dst, sr.old_host, sr.pic_bytes, hipMemcpyHostToDevice, st));
             else if (sr.old_dev) HIPCHK(hipMemcpyAsync(sr.dst, sr.old_dev, sr.pic_bytes, hipMemcpyDeviceToDevice, st));
             HIPCHK(hvq_launch_selfref(c->jobs_dev + sr.job, c->selfref_dev + sr.side_off, sr.dst, st));
@@ -1348,15 +1386,33 @@ static int build_tiles(HvqContext *c)
     c->fl_launches.clear();
     int max_level = 0;
     for (auto &p : c->fl_pending) max_level = std::max(max_level, p.level);
-    for (int lvl = 0; lvl <= max_level; ++lvl) {
+    /* Two launch queues: clips are independent, so the dependency levels of the even and of the odd streams form two chains of launches
+     * that run on two HIP streams with a hardware queue each -- while one chain drains a level or waits at the head of the next, the
+     * other keeps the CUs busy (a launch is some twenty generations of workgroups; the first and the last of them leave CUs idle).
+     * Rounds 1-4 had this behind HVQM4_AMD_QUEUES and dropped it (-7 ... -9 %): the second stream was a plain one, and the runtime deals
+     * plain streams to four hardware queues in creation order -- with the context's copy and read-back streams in between, the two
+     * launch streams could share one.  At the launch streams' own priority level: dense 965 -> 900 us per step (tools/replay_pair_probe.py,
+     * profiles/r05_flush_next.txt 7).  Batches of fewer than 16 streams keep one queue (their launches are a single generation of
+     * workgroups: nothing to fill); HVQM4_AMD_QUEUES=1 / 2 forces either. */
+    int nq = 1;
+    {
+        static const int qenv = getenv("HVQM4_AMD_QUEUES") ? atoi(getenv("HVQM4_AMD_QUEUES")) : 0;
+        std::vector<char> seen(c->streams.size(), 0);
+        size_t nstreams = 0;
+        for (auto &p : c->fl_pending) if (!seen[(size_t)p.stream]) { seen[(size_t)p.stream] = 1; ++nstreams; }
+        nq = qenv >= 2 ? 2 : (qenv == 1 ? 1 : (nstreams >= 16 && !c->tile_queues ? 2 : 1));
+    }
+    for (int lvl = 0; lvl <= max_level; ++lvl)
+      for (int qi = 0; qi < nq; ++qi) {
         Launch L{};
+        L.queue = qi;
         L.level = lvl; L.first_tile = (uint32_t)tiles.size();
         /* submission order (sorting same-stream pictures into one grid column of consecutive groups was tried: +1 % dense, -3 % flat, dropped) */
         /* (walking odd levels in reverse order, so that a level reads first the anchors its predecessor wrote last, was measured in
          * round 5: dense -1.5 %, flat -3 %, profiles/r05_recon_steps.txt) */
         for (size_t i = 0; i < c->fl_pending.size(); ++i) {
             const Pending &p = c->fl_pending[i];
-            if (p.level != lvl) continue;
+            if (p.level != lvl || (nq == 2 && (p.stream & 1) != qi)) continue;
             tiles.push_back(HvqTileRef{ (uint32_t)i, p.ntiles });
             L.max_wg[0] = std::max(L.max_wg[0], p.ntiles); L.wgs[0] += p.ntiles;
             L.max_wg[1] = std::max(L.max_wg[1], p.nwg); L.wgs[1] += p.nwg;
@@ -1706,12 +1762,15 @@ static int flush_end(HvqContext *c)
      * rows padded to 32 entries (LDS banks); pairs above the cap take the kernel's serial fallback */
     /* fullest tile per launch: one pass over the pictures (this runs between the parse results and the first launch: the GPU waits) */
     std::vector<uint32_t> lmi(c->fl_launches.size(), 0), lmp(c->fl_launches.size(), 0);
+    bool twoq = false;
+    for (auto &L : c->fl_launches) twoq |= L.queue == 1;
+    for (auto &sr : c->selfrefs) sr.queue = twoq ? (c->fl_pending[slots[sr.job].job].stream & 1) : 0;
     for (size_t i = 0; i < c->fl_pending.size(); ++i) {
         const Pending &p = c->fl_pending[i];
         if (p.dropped) continue;
         for (size_t l = 0; l < c->fl_launches.size(); ++l) {
             const Launch &L = c->fl_launches[l];
-            if (p.level != L.level) continue;
+            if (p.level != L.level || (twoq && (p.stream & 1) != L.queue)) continue;
             lmi[l] = std::max(lmi[l], p.max_items); lmp[l] = std::max(lmp[l], p.max_pairs);
             break;
         }
@@ -1763,6 +1822,7 @@ static int flush_end(HvqContext *c)
     }
     c->launches = c->fl_launches;
     st.launches = (uint32_t)c->launches.size();
+    st.launch_queues = twoq ? 2u : 1u;
     st.parse_seconds = c->parse_seconds;
     st.gpu_parse_ms = st.gpu_parsed ? c->gpu_parse_ms : 0.0;
     st.gpu_parse_retried = st.gpu_parsed ? c->gpu_parse_retried : 0u;
@@ -1796,7 +1856,13 @@ static int flush_end(HvqContext *c)
     c->tq_njobs = (uint32_t)jobs.size(); c->tq_max_tiles = max_tiles;
     { int rcq = run_queue_build(c, true); if (rcq) return flush_abandon(c, rcq); }
     /* 3. one launch per level */
-    { int rc = run_launches(c); if (rc) return flush_abandon(c, rc); }
+    {
+        bool two = false;
+        int rc = queues_fork(c, &two);
+        if (!rc) rc = run_launches(c);
+        if (!rc) rc = queues_join(c, two);
+        if (rc) return flush_abandon(c, rc);
+    }
     if (!c->fl_nest_pairs.empty()) {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
         { int rcu = staged_upload(c, c->fl_arena_id, 3, PS(c).np_dev, c->fl_nest_pairs.data(), c->fl_nest_pairs.size() * sizeof(uint64_t)); if (rcu) return flush_abandon(c, rcu); }
         HIPCHK_FL(hvq_launch_nest_commit(PS(c).np_dev, (uint32_t)(c->fl_nest_pairs.size() / 2), c->stream));
@@ -1840,11 +1906,15 @@ HVQ_EXPORT int hvq_sync(HvqContext *c)
  * a dependency chain, each as long as a workgroup's lifetime; there is no launch overhead for a graph to remove.  Not kept.) */
 static int replay_passes(HvqContext *c, int what, int reps)
 {
+    /* the two launch queues fork once and join once: inside a queue pass r + 1 follows pass r in stream order, and the queues hold
+     * different streams' pictures */
+    bool two = false;
+    { int rc = queues_fork(c, &two); if (rc) return rc; }
     for (int r = 0; r < reps; ++r) {
         if (what != 0) { int rc = run_queue_build(c, false); if (rc) return rc; }
         if (what != 2) { int rc = run_launches(c); if (rc) return rc; }
     }
-    return HVQ_OK;
+    return queues_join(c, two);
 }
 
 HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)

@@ -48,7 +48,7 @@ typedef struct HvqStats {
     uint64_t luma_pixels;       /* sum of w*h over them */
     uint64_t algorithmic_bytes; /* 1.5 B/px written + 1.5 B/px read for P/B */
     uint64_t descriptor_bytes;  /* blob bytes uploaded (not credited in the roofline) */
-    uint32_t launches;          /* kernel launches (= dependency levels) per pass */
+    uint32_t launches;          /* kernel launches per pass: dependency levels x launch queues */
     uint32_t workgroups;        /* total workgroups per pass */
     double   parse_seconds;     /* host entropy-parse time accumulated by hvq_stream_submit */
     uint32_t flags_or;          /* OR of all blob header flags (HVQ_F_*) */
@@ -57,7 +57,8 @@ typedef struct HvqStats {
     uint32_t gpu_parse_retried; /* of those, pictures the flat parse path handed to the chain decoder (unusual section layout,
                                    capacities, overflow groups at the caps) -- same result, slower */
     uint32_t dropped;           /* pictures of the batch that were not reconstructed: rejected, or behind a rejected picture of their stream */
-    uint32_t pad0;
+    uint32_t launch_queues;     /* 1, or 2: a batch of 16 streams or more deals the levels of its even and of its odd streams to two HIP
+                                   streams (a hardware queue each) whose launches run side by side; HVQM4_AMD_QUEUES=1 / 2 forces either */
     uint64_t queue_bytes;       /* tile-queue bytes (block records, literal / item / pair lists actually filled) one reconstruction pass
                                    reads beside the blobs' payload pools: descriptor traffic, not credited in the roofline */
     uint64_t copy_bytes;        /* hvq_submit_many_device / _async: bitstream bytes the library copied into its pinned arena, summed since

@@ -1,5 +1,6 @@
 """GPU: the batched device-resident path beyond single clips -- mixed sizes and versions in one launch
 sequence (BASELINE config 4 in miniature), replay, slot reuse, malformed input."""
+import os
 import numpy as np
 import pytest
 
@@ -14,6 +15,9 @@ def _submit_all(ctx, cl, nslots=None):
     pics = list(video_pictures(cl.data))
     sid = ctx.open_stream(hdr.width, hdr.height, hdr.h_samp, hdr.v_samp, hdr.is15, nslots or len(pics) + 3)
     return sid, pics
+
+
+NQ = 2 if os.environ.get("HVQM4_AMD_QUEUES", "") == "2" else 1      # launch queues forced by the mode test (tests/test_gpu_modes.py)
 
 
 def test_mixed_batch_interleaved_streams(gpu_ctx):
@@ -35,7 +39,7 @@ def test_mixed_batch_interleaved_streams(gpu_ctx):
     gpu_ctx.flush()
     st = gpu_ctx.stats()
     assert st.pictures == sum(len(p) for _c, _s, p in streams)
-    assert st.launches <= max(len(p) for _c, _s, p in streams)     # pictures of many streams share launches
+    assert st.launches <= NQ * max(len(p) for _c, _s, p in streams)     # pictures of many streams share launches (per launch queue)
     for cl, sid, pics in streams:
         want = bridge.oracle_decode(cl.data, cl.n_pictures)
         for i in range(len(pics)):
@@ -72,7 +76,7 @@ def test_full_gop_in_few_launches_with_small_ring(gpu_ctx):
         gpu_ctx.submit(sid, ft, pic)
     gpu_ctx.flush()
     st = gpu_ctx.stats()
-    assert st.launches < len(pics)
+    assert st.launches < NQ * len(pics)
     checked = 0
     for i in range(len(pics)):
         try:

@@ -50,7 +50,8 @@ def test_c4_share_mixed_sizes_and_versions_share_launches(gpu_ctx, c4_share, gpu
         gpu_ctx.submit_many(sids, fts, data, 8)
     gpu_ctx.flush()
     st = gpu_ctx.stats()
-    assert st.pictures == 8 * 16 and st.launches <= 8           # dependency levels, shared by the eight clips
+    nq = 2 if os.environ.get("HVQM4_AMD_QUEUES", "") == "2" else 1
+    assert st.pictures == 8 * 16 and st.launches <= 8 * nq      # dependency levels (per launch queue), shared by the eight clips
     assert not st.flags_or & 0x28
     for name, cl, pics, sid in streams:
         want = bridge.oracle_decode(cl.data, cl.n_pictures)
