@@ -265,6 +265,7 @@ struct HvqContext {
     std::vector<SelfRef> selfrefs;
     std::vector<Launch> launches;
     std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
+    std::vector<uint8_t> fl_qof;       /* launch queue of every stream in the batch in flight (two queues: dealt by work, build_tiles) */
     HvqStats stats{};
     double parse_seconds = 0;
     std::atomic<uint64_t> copy_bytes{ 0 };     /* bitstream bytes copied into the pinned arena (copy threads), and their wall time in ns */
@@ -1386,21 +1387,40 @@ static int build_tiles(HvqContext *c)
     c->fl_launches.clear();
     int max_level = 0;
     for (auto &p : c->fl_pending) max_level = std::max(max_level, p.level);
-    /* Two launch queues: clips are independent, so the dependency levels of the even and of the odd streams form two chains of launches
+    /* Two launch queues: clips are independent, so the dependency levels of two halves of the streams form two chains of launches
      * that run on two HIP streams with a hardware queue each -- while one chain drains a level or waits at the head of the next, the
      * other keeps the CUs busy (a launch is some twenty generations of workgroups; the first and the last of them leave CUs idle).
      * Rounds 1-4 had this behind HVQM4_AMD_QUEUES and dropped it (-7 ... -9 %): the second stream was a plain one, and the runtime deals
      * plain streams to four hardware queues in creation order -- with the context's copy and read-back streams in between, the two
      * launch streams could share one.  At the launch streams' own priority level: dense 965 -> 900 us per step (tools/replay_pair_probe.py,
-     * profiles/r05_flush_next.txt 7).  Batches of fewer than 16 streams keep one queue (their launches are a single generation of
-     * workgroups: nothing to fill); HVQM4_AMD_QUEUES=1 / 2 forces either. */
+     * profiles/r05_flush_next.txt 7); 64 / 32 / 16 streams gain 7 / 14 / 19 %.  Batches of fewer than 16 streams keep one queue (each queue's
+     * launches should hold the 8 picture slots that spread a launch over the XCDs); HVQM4_AMD_QUEUES=1 / 2 forces either. */
     int nq = 1;
     {
         static const int qenv = getenv("HVQM4_AMD_QUEUES") ? atoi(getenv("HVQM4_AMD_QUEUES")) : 0;
         std::vector<char> seen(c->streams.size(), 0);
         size_t nstreams = 0;
-        for (auto &p : c->fl_pending) if (!seen[(size_t)p.stream]) { seen[(size_t)p.stream] = 1; ++nstreams; }
-        nq = qenv >= 2 ? 2 : (qenv == 1 ? 1 : (nstreams >= 16 && !c->tile_queues ? 2 : 1));
+        bool uniform = true;                               /* every picture of the batch has the same number of tiles */
+        for (auto &p : c->fl_pending) {
+            if (!seen[(size_t)p.stream]) { seen[(size_t)p.stream] = 1; ++nstreams; }
+            uniform &= p.ntiles == c->fl_pending[0].ntiles;
+        }
+        /* mixed picture sizes keep one queue: BASELINE config 4 (320x240 and 640x480 clips alternating, 25 levels) took 1762 us per step
+         * with two queues against 1303 with one, however the streams were dealt (a launch's grid is as tall as its largest picture) */
+        nq = qenv >= 2 ? 2 : (qenv == 1 ? 1 : (nstreams >= 16 && uniform && !c->tile_queues ? 2 : 1));
+        /* streams to queues by WORK (tiles of their pictures in this batch), heaviest first to the lighter queue: clips of mixed sizes
+         * (BASELINE config 4 alternates 320x240 and 640x480) dealt by parity put every large clip on one queue, and that chain then ran
+         * alone for most of the step (1766 against 1295 us) */
+        c->fl_qof.assign(c->streams.size(), 0);
+        if (nq == 2) {
+            std::vector<uint64_t> work(c->streams.size(), 0);
+            for (auto &p : c->fl_pending) work[(size_t)p.stream] += p.ntiles;
+            std::vector<uint32_t> order;
+            for (size_t sidx = 0; sidx < work.size(); ++sidx) if (seen[sidx]) order.push_back((uint32_t)sidx);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
+            uint64_t load[2] = { 0, 0 };
+            for (uint32_t sidx : order) { const int q = load[1] < load[0] ? 1 : 0; c->fl_qof[sidx] = (uint8_t)q; load[q] += work[sidx]; }
+        }
     }
     for (int lvl = 0; lvl <= max_level; ++lvl)
       for (int qi = 0; qi < nq; ++qi) {
@@ -1412,7 +1432,7 @@ static int build_tiles(HvqContext *c)
          * round 5: dense -1.5 %, flat -3 %, profiles/r05_recon_steps.txt) */
         for (size_t i = 0; i < c->fl_pending.size(); ++i) {
             const Pending &p = c->fl_pending[i];
-            if (p.level != lvl || (nq == 2 && (p.stream & 1) != qi)) continue;
+            if (p.level != lvl || (nq == 2 && c->fl_qof[(size_t)p.stream] != qi)) continue;
             tiles.push_back(HvqTileRef{ (uint32_t)i, p.ntiles });
             L.max_wg[0] = std::max(L.max_wg[0], p.ntiles); L.wgs[0] += p.ntiles;
             L.max_wg[1] = std::max(L.max_wg[1], p.nwg); L.wgs[1] += p.nwg;
@@ -1764,13 +1784,13 @@ static int flush_end(HvqContext *c)
     std::vector<uint32_t> lmi(c->fl_launches.size(), 0), lmp(c->fl_launches.size(), 0);
     bool twoq = false;
     for (auto &L : c->fl_launches) twoq |= L.queue == 1;
-    for (auto &sr : c->selfrefs) sr.queue = twoq ? (c->fl_pending[slots[sr.job].job].stream & 1) : 0;
+    for (auto &sr : c->selfrefs) sr.queue = twoq ? (int)c->fl_qof[(size_t)c->fl_pending[slots[sr.job].job].stream] : 0;
     for (size_t i = 0; i < c->fl_pending.size(); ++i) {
         const Pending &p = c->fl_pending[i];
         if (p.dropped) continue;
         for (size_t l = 0; l < c->fl_launches.size(); ++l) {
             const Launch &L = c->fl_launches[l];
-            if (p.level != L.level || (twoq && (p.stream & 1) != L.queue)) continue;
+            if (p.level != L.level || (twoq && (int)c->fl_qof[(size_t)p.stream] != L.queue)) continue;
             lmi[l] = std::max(lmi[l], p.max_items); lmp[l] = std::max(lmp[l], p.max_pairs);
             break;
         }
