@@ -420,6 +420,7 @@ def main():
             halves = []
             for hh in range(nctx):
                 cx = batch.Context(device)
+                cx.set_launch_queues(1)                         # the contexts are each other's second launch queue
                 sid_of = {s: cx.open_stream(clips[stream_clip[s]].width, clips[stream_clip[s]].height, 2, 2, clips[stream_clip[s]].version == "1.5", args.nslots)
                           for s in range(len(sids)) if s % nctx == hh}
                 idx = [i for i, s in enumerate(a_stream) if s % nctx == hh]

@@ -80,6 +80,7 @@ SYMBOLS = {
     "HVQM4SetMaxFrameSize": (None, [C.POINTER(SeqObj), C.c_uint32]),
     "hvq_context_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "hvq_context_destroy": (None, [C.c_void_p]),
+    "hvq_context_set_launch_queues": (C.c_int, [C.c_void_p, C.c_int]),
     "hvq_stream_open": (C.c_int, [C.c_void_p] + [C.c_int] * 6),
     "hvq_stream_close": (C.c_int, [C.c_void_p, C.c_int]),
     "hvq_stream_ring_bytes": (C.c_uint64, [C.c_int] * 5),

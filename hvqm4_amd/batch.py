@@ -15,6 +15,10 @@ class Context:
         self._h = C.c_void_p()
         check(lib().hvq_context_create(device, C.byref(self._h)))
 
+    def set_launch_queues(self, n: int) -> None:
+        """1 or 2 launch queues for this context's batches (hvq_context_set_launch_queues); 1 when two contexts share the GPU"""
+        check(lib().hvq_context_set_launch_queues(self._h, n))
+
     def open_stream(self, width: int, height: int, h_samp: int = 2, v_samp: int = 2, is15: bool = True,
                     nslots: int = 4) -> int:
         return check(lib().hvq_stream_open(self._h, width, height, h_samp, v_samp, int(is15), nslots))
@@ -210,6 +214,8 @@ class PairedContexts:
 
     def __init__(self, device: int = 0):
         self._ctx = [Context(device), Context(device)]
+        for c in self._ctx:
+            c.set_launch_queues(1)                         # the two contexts are each other's second queue
         self._where = []                                   # pair stream id -> (context index, stream id inside it)
 
     def open_stream(self, width: int, height: int, h_samp: int = 2, v_samp: int = 2, is15: bool = True, nslots: int = 4) -> int:

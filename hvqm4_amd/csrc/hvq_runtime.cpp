@@ -265,6 +265,7 @@ struct HvqContext {
     std::vector<SelfRef> selfrefs;
     std::vector<Launch> launches;
     std::vector<Launch> fl_launches;   /* of the batch in flight: tile ranges known at begin, LDS sizes at end */
+    int max_queues = 2;                /* hvq_context_set_launch_queues */
     std::vector<uint8_t> fl_qof;       /* launch queue of every stream in the batch in flight (two queues: dealt by work, build_tiles) */
     HvqStats stats{};
     double parse_seconds = 0;
@@ -481,6 +482,13 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     HIPCHK(hipEventCreate(&c->ev1));
     guard.c = nullptr;
     *out = c;
+    return HVQ_OK;
+}
+
+HVQ_EXPORT int hvq_context_set_launch_queues(HvqContext *c, int n)
+{
+    if (!c || n < 1 || n > 2) return fail(HVQ_E_ARG, "launch queues: 1 or 2");
+    c->max_queues = n;
     return HVQ_OK;
 }
 
@@ -1407,7 +1415,7 @@ static int build_tiles(HvqContext *c)
         }
         /* mixed picture sizes keep one queue: BASELINE config 4 (320x240 and 640x480 clips alternating, 25 levels) took 1762 us per step
          * with two queues against 1303 with one, however the streams were dealt (a launch's grid is as tall as its largest picture) */
-        nq = qenv >= 2 ? 2 : (qenv == 1 ? 1 : (nstreams >= 16 && uniform && !c->tile_queues ? 2 : 1));
+        nq = qenv >= 2 ? 2 : (qenv == 1 ? 1 : (c->max_queues >= 2 && nstreams >= 16 && uniform && !c->tile_queues ? 2 : 1));
         /* streams to queues by WORK (tiles of their pictures in this batch), heaviest first to the lighter queue: clips of mixed sizes
          * (BASELINE config 4 alternates 320x240 and 640x480) dealt by parity put every large clip on one queue, and that chain then ran
          * alone for most of the step (1766 against 1295 us) */

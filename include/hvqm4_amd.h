@@ -67,6 +67,10 @@ typedef struct HvqStats {
 } HvqStats;
 
 int  hvq_context_create(int device, HvqContext **out);
+/* Launch queues a batch of this context may use: 2 (default: a batch of 16 streams or more of one picture size deals its dependency levels
+ * to two HIP streams, HvqStats.launch_queues) or 1.  A process that runs TWO contexts on a GPU side by side (INTEGRATION.md "Two contexts per
+ * GPU") sets 1 on both: the contexts are each other's second queue, four queues get in each other's way (157 against 171 Gpixel/s). */
+int  hvq_context_set_launch_queues(HvqContext *ctx, int n);
 void hvq_context_destroy(HvqContext *ctx);
 
 /* A stream = one clip.  `nslots` >= 3 picture buffers stay resident in HBM per stream (the
