@@ -216,8 +216,8 @@ struct HvqContext {
     int device = 0;
     bool tile_queues = false;          /* two-pass reconstruction over tile queues in HBM (HVQM4_AMD_TILE_QUEUES=1) */
     hipStream_t stream = nullptr;      /* every launch of a batch: its dependency levels in order */
-    hipStream_t stream2 = nullptr;     /* second launch queue (created on first use): the levels of the odd streams, see build_tiles */
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t qstream[4] = { nullptr, nullptr, nullptr, nullptr };   /* launch queues 1..3 (created on first use; queue 0 is `stream`), see build_tiles */
+    hipEvent_t ev_fork = nullptr, ev_join[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<Stream> streams;
     /* staging: pinned host arena mirrored by a device arena */
@@ -526,9 +526,11 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     for (auto e : c->ev_arena_free) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->read_stream) { (void)hipStreamSynchronize(c->read_stream); (void)hipStreamDestroy(c->read_stream); }
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    for (int q = 1; q < 4; ++q) {
+        if (c->qstream[q]) { (void)hipStreamSynchronize(c->qstream[q]); (void)hipStreamDestroy(c->qstream[q]); }
+        if (c->ev_join[q]) (void)hipEventDestroy(c->ev_join[q]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_read) (void)hipEventDestroy(c->ev_read);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tq_dev) (void)hipFree(c->tq_dev);
@@ -1341,21 +1343,24 @@ static int run_queue_build(HvqContext *c, bool count_bytes)
 /* the second launch queue forks from the main stream (everything queued there so far is done before its first launch) ... */
 static int queues_fork(HvqContext *c, bool *two)
 {
-    *two = false;
-    for (auto &L : c->launches) *two |= L.queue == 1;
+    int nq = 1;
+    for (auto &L : c->launches) nq = std::max(nq, L.queue + 1);
+    *two = nq > 1;
     if (!*two) return HVQ_OK;
-    if (!c->stream2) {
-        /* at the launch streams' priority level (hvq_context_create): a hardware queue of its own */
-        int lo = 0, hi = 0;
-        static const bool prio = !(getenv("HVQM4_AMD_STREAM_PRIORITY") && atoi(getenv("HVQM4_AMD_STREAM_PRIORITY")) == 0);
-        if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
-            HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
-        else HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
+    if (!c->ev_fork) HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    for (int q = 1; q < nq; ++q) {
+        if (!c->qstream[q]) {
+            /* at the launch streams' priority level (hvq_context_create): a hardware queue of its own */
+            int lo = 0, hi = 0;
+            static const bool prio = !(getenv("HVQM4_AMD_STREAM_PRIORITY") && atoi(getenv("HVQM4_AMD_STREAM_PRIORITY")) == 0);
+            if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+                HIPCHK(hipStreamCreateWithPriority(&c->qstream[q], hipStreamNonBlocking, hi));
+            else HIPCHK(hipStreamCreateWithFlags(&c->qstream[q], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_join[q], hipEventDisableTiming));
+        }
+        HIPCHK(hipStreamWaitEvent(c->qstream[q], c->ev_fork, 0));
+    }
     return HVQ_OK;
 }
 
@@ -1363,8 +1368,12 @@ static int queues_fork(HvqContext *c, bool *two)
 static int queues_join(HvqContext *c, bool two)
 {
     if (!two) return HVQ_OK;
-    HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    int nq = 1;
+    for (auto &L : c->launches) nq = std::max(nq, L.queue + 1);
+    for (int q = 1; q < nq; ++q) {
+        HIPCHK(hipEventRecord(c->ev_join[q], c->qstream[q]));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join[q], 0));
+    }
     return HVQ_OK;
 }
 
@@ -1372,7 +1381,7 @@ static int queues_join(HvqContext *c, bool two)
 static int run_launches(HvqContext *c)
 {
     for (auto &L : c->launches) {
-        hipStream_t st = L.queue ? c->stream2 : c->stream;
+        hipStream_t st = L.queue ? c->qstream[L.queue] : c->stream;
         if (L.inline_queues) HIPCHK(hvq_launch_recon_inline(c->jobs_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, L.pool_cap, st));
         else HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, st));
         for (const SelfRef &sr : c->selfrefs) {
@@ -1415,19 +1424,23 @@ static int build_tiles(HvqContext *c)
         }
         /* mixed picture sizes keep one queue: BASELINE config 4 (320x240 and 640x480 clips alternating, 25 levels) took 1762 us per step
          * with two queues against 1303 with one, however the streams were dealt (a launch's grid is as tall as its largest picture) */
-        nq = qenv >= 2 ? 2 : (qenv == 1 ? 1 : (c->max_queues >= 2 && nstreams >= 16 && uniform && !c->tile_queues ? 2 : 1));
+        nq = qenv >= 2 ? std::min(qenv, 4) : (qenv == 1 ? 1 : (c->max_queues >= 2 && nstreams >= 16 && uniform && !c->tile_queues ? 2 : 1));
         /* streams to queues by WORK (tiles of their pictures in this batch), heaviest first to the lighter queue: clips of mixed sizes
          * (BASELINE config 4 alternates 320x240 and 640x480) dealt by parity put every large clip on one queue, and that chain then ran
          * alone for most of the step (1766 against 1295 us) */
         c->fl_qof.assign(c->streams.size(), 0);
-        if (nq == 2) {
+        if (nq >= 2) {
             std::vector<uint64_t> work(c->streams.size(), 0);
             for (auto &p : c->fl_pending) work[(size_t)p.stream] += p.ntiles;
             std::vector<uint32_t> order;
             for (size_t sidx = 0; sidx < work.size(); ++sidx) if (seen[sidx]) order.push_back((uint32_t)sidx);
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
-            uint64_t load[2] = { 0, 0 };
-            for (uint32_t sidx : order) { const int q = load[1] < load[0] ? 1 : 0; c->fl_qof[sidx] = (uint8_t)q; load[q] += work[sidx]; }
+            uint64_t load[4] = { 0, 0, 0, 0 };
+            for (uint32_t sidx : order) {
+                int q = 0;
+                for (int k = 1; k < nq; ++k) if (load[k] < load[q]) q = k;
+                c->fl_qof[sidx] = (uint8_t)q; load[q] += work[sidx];
+            }
         }
     }
     for (int lvl = 0; lvl <= max_level; ++lvl)
@@ -1440,7 +1453,7 @@ static int build_tiles(HvqContext *c)
          * round 5: dense -1.5 %, flat -3 %, profiles/r05_recon_steps.txt) */
         for (size_t i = 0; i < c->fl_pending.size(); ++i) {
             const Pending &p = c->fl_pending[i];
-            if (p.level != lvl || (nq == 2 && c->fl_qof[(size_t)p.stream] != qi)) continue;
+            if (p.level != lvl || (nq >= 2 && c->fl_qof[(size_t)p.stream] != qi)) continue;
             tiles.push_back(HvqTileRef{ (uint32_t)i, p.ntiles });
             L.max_wg[0] = std::max(L.max_wg[0], p.ntiles); L.wgs[0] += p.ntiles;
             L.max_wg[1] = std::max(L.max_wg[1], p.nwg); L.wgs[1] += p.nwg;
@@ -1791,7 +1804,8 @@ static int flush_end(HvqContext *c)
     /* fullest tile per launch: one pass over the pictures (this runs between the parse results and the first launch: the GPU waits) */
     std::vector<uint32_t> lmi(c->fl_launches.size(), 0), lmp(c->fl_launches.size(), 0);
     bool twoq = false;
-    for (auto &L : c->fl_launches) twoq |= L.queue == 1;
+    int nqs = 1;
+    for (auto &L : c->fl_launches) { twoq |= L.queue >= 1; nqs = std::max(nqs, L.queue + 1); }
     for (auto &sr : c->selfrefs) sr.queue = twoq ? (int)c->fl_qof[(size_t)c->fl_pending[slots[sr.job].job].stream] : 0;
     for (size_t i = 0; i < c->fl_pending.size(); ++i) {
         const Pending &p = c->fl_pending[i];
@@ -1850,7 +1864,7 @@ static int flush_end(HvqContext *c)
     }
     c->launches = c->fl_launches;
     st.launches = (uint32_t)c->launches.size();
-    st.launch_queues = twoq ? 2u : 1u;
+    st.launch_queues = (uint32_t)nqs;
     st.parse_seconds = c->parse_seconds;
     st.gpu_parse_ms = st.gpu_parsed ? c->gpu_parse_ms : 0.0;
     st.gpu_parse_retried = st.gpu_parsed ? c->gpu_parse_retried : 0u;
