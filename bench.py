@@ -6,9 +6,10 @@ Metric (BASELINE.json): decoded Mpixels/s (bit-exact YUV) and % of the HBM roofl
 Workloads, weak scaling, one rank per GPU, no collective on the data path:
   c5 (default)  the per-GPU share of config C5: 128 concurrent 640x480 HVQM4 1.5 streams, GOP I P B B P B B ...
                 (16 pictures), descriptors pre-parsed and resident in HBM.  One step = every stream decodes one GOP
-                (128 * 16 = 2048 pictures) through the batched path (hvq_replay_stage): EVERYTHING a batch of new
-                pictures costs behind its parse -- the launches of the dependency levels, whose workgroups derive their
-                queues from the parser's descriptors themselves; no per-picture pass outside the step (round 3 had one).
+                (128 * 16 = 2048 pictures) through the batched path (hvq_replay_stage, what = 1): EVERYTHING a batch of
+                new pictures costs behind its parse -- the launches of the dependency levels on the launch queues, forked
+                and joined per step exactly as a flush forks and joins them (round 6; rounds 1-5 let the queues run free
+                over all timed steps, which is reported beside the headline as `free_running`).
   c4            config C4: 64 clips = 32 x 320x240 + 32 x 640x480, HVQM4 1.3 and 1.5 alternating, seeds 0..63,
                 four 16-picture GOPs each, clip i -> rank i mod N.  One step = every clip of the rank decoded once.
 `value` = luma pixels decoded by all ranks / max-over-ranks time.
@@ -20,8 +21,7 @@ Extra objects on the JSON line:
   roofline      algorithmic bytes (1.5 B/px written + 1.5 B/px read for P/B) of a step / HIP-event
                 time of the step on the launch stream (= bytes per launch / average launch duration: the step is its 7
                 launches), vs 8 TB/s; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
-                (profiles/*_pmc_traffic.json), calibrated as MI355X_MICROARCH.md prescribes; `two_pass_tile_queues`
-                (extra object) = the same step with round 3's queue-build kernel + reconstruction over its queues
+                (profiles/*_pmc_traffic.json), calibrated as MI355X_MICROARCH.md prescribes
   cpu_baseline  the reference decoder (oracle/_ref, kind "reference") or this repo's scalar restatement (kind "port")
                 on the host cores: one core on C1, C2, C3 and one process per clip over all cores on a C4 sample
 """
@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--mv-bits", default="0,1,2", help="vector residual-bit choices of the synthetic P/B pictures (reach = 16 << bits samples)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that generate the synthetic clips (0 = cores / ranks)")
     ap.add_argument("--clip-cache", default="", help="directory that keeps generated clips between runs (profiling passes of one workload)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing rehearsal, no GPU: start the ranks, rendezvous, bind cores (sysfs tree from HVQM4_AMD_SYSFS), deal the "
+                         "clips / streams to the ranks, reduce -- and print what every rank would decode")
     return ap.parse_args(argv)
 
 
@@ -182,14 +185,15 @@ def pin_rank(local_rank: int, local_world: int):
     /sys/class/kfd) the ranks take even linear slices of the allowed cores, as before round 5.  Reads sysfs only: no GPU call.
     Returns (copy threads, cores of the slice, numa node or None, "numa" | "linear")."""
     from hvqm4_amd import topology
+    sysfs = os.environ.get("HVQM4_AMD_SYSFS", "/sys")                   # tests: a fake tree (tests/test_topology.py)
     cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     shared = bool(os.environ.get("HVQM4_BENCH_SHARE_GPU"))             # rehearsal: every rank drives device 0
     devices = [0] * local_world if shared else None
     if shared:                                                        # ... so the node of device 0 is everybody's: split linearly
         mine, node, how = topology.rank_cores(local_rank, local_world, cores, sysfs=os.devnull)
-        node = topology.gpu_numa_node(0)
+        node = topology.gpu_numa_node(0, sysfs)
     else:
-        mine, node, how = topology.rank_cores(local_rank, local_world, cores, devices=devices)
+        mine, node, how = topology.rank_cores(local_rank, local_world, cores, sysfs=sysfs, devices=devices)
     if local_world > 1 and hasattr(os, "sched_setaffinity"):
         os.sched_setaffinity(0, mine)
     threads = int(os.environ.get("HVQM4_AMD_COPY_THREADS", "0")) or max(1, min(8, len(mine)))
@@ -209,6 +213,9 @@ def main():
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     if world != args.gpus:
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; running {world} rank(s)", file=sys.stderr)
+
+    if args.dry_run:
+        return dry_run(args, grp)
 
     import numpy as np
     from hvqm4_amd import batch
@@ -307,8 +314,8 @@ def main():
         ctx.sync()
         grp.barrier()
 
-    # One step = what a batch of NEW pictures costs behind its parse: the per-picture queue build (hvq_tileq_kernel: block
-    # records, literal / item / pair lists from the descriptors) AND the reconstruction launches of all dependency levels.
+    # One step = what a batch of NEW pictures costs behind its parse: the reconstruction launches of all dependency levels, the
+    # launch queues forked and joined around every step as hvq_flush_end does (hvq_replay_stage what = 1).
     # untimed pre-roll: the measurement that runs first otherwise reads ~3 % low (the same launches measured a second time come out
     # faster: clocks still ramping after the host-bound parity check), then the W warm-up steps the contract asks for
     PREROLL = int(os.environ.get("HVQM4_BENCH_PREROLL", "20"))
@@ -320,10 +327,9 @@ def main():
     gpu_ms = ctx.replay_stage(args.steps, 1)  # K steps, timed by HIP events on the launch stream
     barrier()
     wall = grp.max(time.perf_counter() - t0)
-    # beside the headline: the reconstruction launches alone (queues resident, what rocprofv3's per-kernel average is compared
-    # with) and the queue build alone
+    # beside the headline: the same launches with the launch queues running free over all steps (forked once, joined once: rounds
+    # 1-5's timed region -- a queue that is ahead runs into the next step)
     recon_ms = ctx.replay(args.steps)
-    qb_ms = ctx.replay_stage(args.steps, 2)
     st = ctx.stats()
 
     # ---- end to end with the entropy parse ON THE GPU, on EVERY rank at once: raw bitstreams in
@@ -492,6 +498,13 @@ def main():
         px = int(st.luma_pixels)
         one = px / min(t_pass[1:]) / 1e6
         stream_v = px / t_pipe / 1e6
+        # what PCIe allows: the batch's bitstreams cross it once per batch -- the rate the streaming loop moves them at, the rate a
+        # plain pinned-host -> device copy of the same size reaches on this box, and the Mpixel/s that rate is worth at this stream density
+        batch_bytes = int(sum(z_len))
+        try:
+            h2d_peak = ctx2.h2d_probe(batch_bytes, 8)
+        except HvqError:
+            h2d_peak = None
         # the same streaming loop with EVERY picture brought back to (pinned) host memory: hvq_read_pictures of batch k runs
         # beside the parse of batch k + 1 (one synchronisation per batch).  PCIe-bound; never `value`.
         rb = None
@@ -557,6 +570,13 @@ def main():
                    "host_copy_threads": copy_threads,
                    "host_copy_GBs": round(copy_gbs, 2), "host_copy_GBs_all_ranks": round(grp.sum(copy_gbs), 2),
                    "host_copy_bytes_per_batch": int(sum(z_len)),
+                   "h2d_GBs": round(batch_bytes / t_pipe / 1e9, 2),
+                   "h2d_GBs_what": "bitstream bytes of a batch / streaming period: what the streaming loop moves over PCIe per GPU",
+                   "h2d_probe_GBs": round(h2d_peak, 2) if h2d_peak else None,
+                   "pcie_bound_Mpixels": round(px / (batch_bytes / (h2d_peak * 1e9)) / 1e6, 1) if h2d_peak else None,
+                   "pcie_bound_what": "pixels of a batch / (its bitstream bytes / h2d_probe_GBs): the streaming rate at which the upload alone "
+                                      "fills the period at this stream density (%.1f bitstream bytes per kilopixel), whatever the kernels do"
+                                      % (batch_bytes / (px / 1e3)),
                    "streaming_zero_copy": {"value": round(grp.sum(px / z_pipe / 1e6), 1), "unit": "Mpixels/s",
                                            "ms_per_batch": round(z_pipe * 1e3, 2), "ms_per_batch_median": round(z_median * 1e3, 2),
                                            "submit_end_begin_ms": z_calls, "parse_kernel_ms": round(z_parse, 3),
@@ -578,7 +598,7 @@ def main():
                            "per-rank min and max of the streaming rate; the per-rank detail fields are rank 0's).  value: one "
                            "batch start to finish; streaming_value: steady-state period of submit next / hvq_flush_next "
                            "(next batch copied and uploaded while this one is parsed; its parse kernel queued before the host takes this "
-                           "batch's results, this batch's reconstruction on a second HIP stream beside it), mean over `streaming_batches` "
+                           "batch's results; everything on the one launch stream, the reconstruction's two launch queues forked from it), mean over `streaming_batches` "
                            "batches after 2 warm-up batches"}
         ctx2.close()
 
@@ -587,15 +607,16 @@ def main():
     value = total_px * args.steps / wall / 1e6
     launches = int(st.launches)
     queues = max(1, int(st.launch_queues))          # launch queues whose launches run side by side (2 for a batch of 16 streams or more)
-    two_pass = bool(os.environ.get("HVQM4_AMD_TILE_QUEUES", "0") not in ("", "0"))
-    # average duration of ONE launch: a queue runs its launches back to back, so a step lasts as long as a queue's launches/queues
-    # launches -- the figure rocprofv3's per-kernel average is compared with; the queues run side by side, hence `queues x`
-    avg_launch_s = recon_ms * 1e-3 / (args.steps * launches / queues)
-    recon_achieved = queues * (st.algorithmic_bytes / launches) / avg_launch_s / 1e9
+    # average duration of ONE launch, derived: a queue runs its launches back to back, so a step lasts as long as a queue's
+    # launches / queues launches; the queues run side by side, hence `queues x`.  `avg_launch_us_measured` beside it is rocprofv3's
+    # per-kernel average from the committed kernel trace of this same command (profiles/*_kernel_stats.csv).
     stage_s = gpu_ms * 1e-3 / args.steps
+    avg_launch_s = stage_s / (launches / queues)
+    free_s = recon_ms * 1e-3 / args.steps
+    free_achieved = st.algorithmic_bytes / free_s / 1e9
     achieved = st.algorithmic_bytes / stage_s / 1e9
     traffic = pmc_traffic(args)
-    qb_s = qb_ms * 1e-3 / args.steps
+    trace = kernel_trace_avg(args)
 
     out = {
         "metric": "decoded Mpixels/s (bit-exact YUV)",
@@ -612,11 +633,11 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": what,
-            "step": ("queue build (hvq_tileq_kernel, once per picture) + reconstruction launches of all dependency levels" if two_pass else
-                     "reconstruction launches of all dependency levels; the workgroups derive block records, item queues and pair lists "
-                     "from the parser's descriptors themselves (hvq_recon_inline_kernel): no per-picture pass outside the step"),
+            "step": ("reconstruction launches of all dependency levels, the launch queues forked and joined per step as in a flush; the "
+                     "workgroups derive block records, item queues and pair lists from the parser's descriptors themselves "
+                     "(hvq_recon_inline_kernel): no per-picture pass outside the step"),
             "streams_per_gpu": len(sids), "pictures_per_step": int(st.pictures),
-            "distinct_clips_per_gpu": len(clips), "launches_per_step": launches + (1 if two_pass else 0),
+            "distinct_clips_per_gpu": len(clips), "launches_per_step": launches,
             "reconstruction_launches_per_step": launches, "launch_queues": queues,
             "workgroups_per_step": int(st.workgroups), "nslots": args.nslots,
             "sharding": "one clip per stream, streams split across GPUs, no collective",
@@ -625,38 +646,35 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "what": "algorithmic bytes of one step / HIP-event time of one step (everything a new batch costs behind its parse)",
+            "what": ("algorithmic bytes of one step / HIP-event time of one step (everything a new batch costs behind its parse), the launch "
+                     "queues forked and joined around EVERY step exactly as hvq_flush_end does (stage_us_per_step_joined)"),
             "stage_us_per_step": round(stage_s * 1e6, 2),
+            "stage_us_per_step_joined": round(stage_s * 1e6, 2),
             "algorithmic_bytes_per_step": int(st.algorithmic_bytes),
             "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_over_algorithmic": traffic["over_algorithmic"] if traffic else None,
             "traffic_source": traffic["source"] if traffic else None,
-            "traffic_what": f"HBM bytes per launch of the dominant kernel ({'hvq_recon_kernel' if two_pass else 'hvq_recon_inline_kernel'}), PMC passes",
+            "traffic_what": "HBM bytes per launch of the dominant kernel (hvq_recon_inline_kernel), PMC passes",
             "valu": pmc_valu(args),
-            "kernel": "hvq_recon_kernel" if two_pass else "hvq_recon_inline_kernel", "algorithmic_bytes_per_launch": int(st.algorithmic_bytes // launches),
-            "recon_only": {"achieved": round(recon_achieved, 1), "frac": round(recon_achieved / HBM_PEAK_GBS, 4),
-                           "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches_per_step": launches, "launch_queues": queues,
-                           "us_per_step": round(recon_ms * 1e3 / args.steps, 2),
-                           "what": ("the reconstruction launches alone over resident tile queues (hvq_replay)" if two_pass else
-                                    "the same launches once more (hvq_replay): there is nothing else in the step")},
-            "queue_build": ({"kernel": "hvq_tileq_kernel", "us_per_step": round(qb_s * 1e6, 2), "bytes": int(st.queue_bytes),
-                             "GB/s": round(st.queue_bytes / qb_s / 1e9, 1) if qb_s > 0 else None,
-                             "what": "bytes = the block records and list entries it leaves (what every reconstruction pass reads back)"}
-                            if two_pass else
-                            {"kernel": None, "us_per_step": 0.0, "bytes": 0, "GB/s": None,
-                             "what": "no queue-build pass: queues are derived in LDS by the reconstruction workgroups; the two-pass "
-                                     "variant (HVQM4_AMD_TILE_QUEUES=1) is measured beside the headline as `two_pass_tile_queues`"}),
+            "kernel": "hvq_recon_inline_kernel", "algorithmic_bytes_per_launch": int(st.algorithmic_bytes // launches),
+            "free_running": {"achieved": round(free_achieved, 1), "frac": round(free_achieved / HBM_PEAK_GBS, 4),
+                             "us_per_step": round(free_s * 1e6, 2),
+                             "what": "the same launches with the launch queues forked once and joined once around all timed steps (hvq_replay; "
+                                     "the timed region of rounds 1-5): a queue that is ahead runs into the next step.  Never the headline"},
             "avg_launch_us": round(avg_launch_s * 1e6, 2),
+            "avg_launch_us_what": "derived: joined step time / (launches / queues) -- a queue's launches run back to back",
+            "avg_launch_us_measured": trace["avg_us"] if trace else None,
+            "avg_launch_us_measured_source": trace["source"] if trace else None,
             "launch_queues": queues,
-            "launch_queues_what": ("the dependency levels of the even and of the odd streams are two chains of launches on two HIP streams "
+            "launch_queues_what": ("a batch's streams are dealt -- by work -- to two chains of launches on two HIP streams "
                                    "(a hardware queue each); a step = launches / queues launches per queue, back to back, the queues side by "
                                    "side: achieved = queues x algorithmic_bytes_per_launch / avg_launch_us = algorithmic bytes of a step / its time"
                                    if queues > 1 else "one launch queue"),
-            "descriptor_bytes_per_launch": int((st.descriptor_bytes + st.queue_bytes) // launches),
-            "descriptor_bytes_what": "blobs (maps, vectors, payload pools, nests) + tile queues, per reconstruction launch; not credited",
+            "descriptor_bytes_per_launch": int(st.descriptor_bytes // launches),
+            "descriptor_bytes_what": "blobs (maps, vectors, payload pools, nests) per reconstruction launch; not credited",
         },
         "gpu_event_ms_per_step": round(gpu_ms / args.steps, 4),
-        "gpu_event_ms_per_step_recon_only": round(recon_ms / args.steps, 4),
+        "gpu_event_ms_per_step_free_running": round(recon_ms / args.steps, 4),
         "end_to_end_gpu_parse": gpu_e2e,
         "end_to_end": {"value": round(px_step / t_e2e / 1e6, 1), "unit": "Mpixels/s", "parse_threads": threads,
                        "parse_only_mpix_s": round(px_step / t_parse / 1e6, 1),
@@ -740,32 +758,6 @@ def main():
         except Exception as e:
             out["c5_staggered"] = {"error": str(e)}
 
-    # round 3's two-pass variant beside the headline: hvq_tileq_kernel builds tile queues in HBM once per picture, hvq_recon_kernel
-    # reads them.  Its reconstruction launches alone are faster (nothing is derived in them), the step as a whole is not.
-    if rank == 0 and world == 1 and not args.no_sdk and not two_pass:
-        try:
-            os.environ["HVQM4_AMD_TILE_QUEUES"] = "1"
-            ctxt = batch.Context(device)
-            sidst = [ctxt.open_stream(clips[ci].width, clips[ci].height, 2, 2, clips[ci].version == "1.5", args.nslots) for ci in stream_clip]
-            ctxt.submit_many([sidst[s] for s in a_stream], a_ft, a_pic, threads)
-            ctxt.flush(); ctxt.sync()
-            ctxt.replay_stage(args.warmup or 1, 1)
-            t_stage = ctxt.replay_stage(args.steps, 1); t_recon = ctxt.replay(args.steps); t_q = ctxt.replay_stage(args.steps, 2)
-            stt = ctxt.stats()
-            okt = all(np.array_equal(ctxt.read_picture(sidst[s], len(pics[stream_clip[s]]) - 1), last_single[s]) for s in range(len(last_single)))
-            ctxt.close()
-            fr = lambda ms: round(st.algorithmic_bytes * args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            out["two_pass_tile_queues"] = {"stage_frac": fr(t_stage), "stage_us_per_step": round(t_stage * 1e3 / args.steps, 2),
-                                           "recon_only_frac": fr(t_recon), "recon_only_us_per_step": round(t_recon * 1e3 / args.steps, 2),
-                                           "queue_build_us_per_step": round(t_q * 1e3 / args.steps, 2), "queue_bytes": int(stt.queue_bytes),
-                                           "descriptor_bytes_per_launch": int((stt.descriptor_bytes + stt.queue_bytes) // launches),
-                                           "pictures_equal_headline": bool(okt),
-                                           "what": "HVQM4_AMD_TILE_QUEUES=1: hvq_tileq_kernel (once per picture) + hvq_recon_kernel over its queues"}
-        except Exception as e:
-            out["two_pass_tile_queues"] = {"error": str(e)}
-        finally:
-            os.environ.pop("HVQM4_AMD_TILE_QUEUES", None)
-
     # BASELINE config 4 at the shape one GPU of eight sees it: clips 0, 8, ..., 56 of the 64 (4 x 320x240 + 4 x 640x480, HVQM4 1.3
     # and 1.5 alternating), every picture checked against the SHA-256 the REFERENCE decoder produced (tests/golden/manifest.json)
     if rank == 0 and world == 1 and not args.no_sdk:
@@ -773,6 +765,48 @@ def main():
 
     if rank == 0:
         grp.emit(json.dumps(out))
+    grp.close()
+
+
+def dry_run(args, grp):
+    """`bench.py --gpus N --dry-run`: everything a multi-GPU run does around the GPU work and nothing of the GPU work -- the ranks
+    are started (launch_ranks or torchrun), meet (gloo), bind themselves to the cores of their GPU's NUMA node (pin_rank; sysfs tree
+    from HVQM4_AMD_SYSFS), deal the workload (c4: clip i -> rank i mod N; c5: `--streams` streams per rank, their clips' seeds), pass the
+    barriers of the timed region and reduce.  No clip is generated, neither the HIP library nor a GPU is touched.  Rank 0 prints one
+    JSON line with every rank's share, so that the first real 8-GPU run cannot die in plumbing (tests/test_bench_launcher.py)."""
+    from hvqm4_amd.distrib import shard
+    rank, world = grp.rank, grp.world
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    copy_threads, my_cores, my_node, pin_how = pin_rank(grp.local_rank % max(1, local_world), local_world)
+    if args.workload == "c4":
+        ids = shard(64, rank, world)
+        cfgs = [c4_clip_config(i, args.preset, 4) for i in ids]
+        units = [{"clip": i, "w": c.width, "h": c.height, "version": c.version, "seed": c.seed} for i, c in zip(ids, cfgs)]
+        pictures = sum(16 * c.repeat_gops for c in cfgs)
+        pixels = sum(16 * c.repeat_gops * c.width * c.height for c in cfgs)
+    else:
+        seeds = [1000 + rank * args.distinct + i for i in range(args.distinct)]
+        units = {"streams": args.streams, "first_global_stream": rank * args.streams, "clip_seeds": seeds, "w": args.width, "h": args.height}
+        pictures = args.streams * len(args.gop)
+        pixels = pictures * args.width * args.height
+    mine = {"rank": rank, "local_rank": grp.local_rank, "device": 0 if os.environ.get("HVQM4_BENCH_SHARE_GPU") else grp.local_rank,
+            "cores": my_cores, "numa_node": my_node, "core_choice": pin_how, "copy_threads": copy_threads,
+            "units": units, "pictures_per_step": pictures, "pixels_per_step": pixels}
+    grp.barrier()
+    t0 = time.perf_counter()
+    grp.barrier()
+    wall = grp.max(time.perf_counter() - t0)
+    total_px = grp.sum(float(pixels))
+    total_pics = grp.sum(float(pictures))
+    if grp.dist is not None:
+        everyone = [None] * world
+        grp.dist.all_gather_object(everyone, mine)
+    else:
+        everyone = [mine]
+    if rank == 0:
+        grp.emit(json.dumps({"dry_run": True, "workload": args.workload, "n_gpus": world, "scaling": "weak" if args.workload == "c5" else "strong",
+                             "pictures_per_step": int(total_pics), "pixels_per_step": int(total_px), "barrier_s": round(wall, 4),
+                             "ranks": everyone}))
     grp.close()
 
 
@@ -877,6 +911,27 @@ def pmc_traffic(args):
     hbm = j.get("hbm_bytes_per_launch_calibrated", j.get("hbm_bytes_per_launch"))
     return {"hbm_bytes_per_launch": int(hbm), "over_algorithmic": j.get("over_algorithmic"),
             "source": "profiles/" + os.path.basename(files[-1]) + (" (calibrated)" if "hbm_bytes_per_launch_calibrated" in j else " (raw counters)")}
+
+
+def kernel_trace_avg(args):
+    """rocprofv3's average duration of hvq_recon_inline_kernel over the committed kernel trace of this default workload
+    (profiles/r*_kernel_stats.csv, newest round); None for any other workload"""
+    if pmc_traffic(args) is None:
+        return None
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats.csv")))
+    for f in reversed(files):
+        try:
+            tot_ns = calls = 0
+            for row in csv.DictReader(open(f)):
+                if "hvq_recon_inline_kernel" in row.get("Name", ""):
+                    tot_ns += float(row["TotalDurationNs"]); calls += int(row["Calls"])
+            if calls:
+                return {"avg_us": round(tot_ns / calls / 1e3, 2), "source": "profiles/" + os.path.basename(f) + f" ({calls} launches)"}
+        except Exception:
+            continue
+    return None
 
 
 def pmc_valu(args):

@@ -164,6 +164,12 @@ class Context:
         check(lib().hvq_rgb_bench(self._h, reps, C.byref(ms), C.byref(by), C.byref(n)))
         return float(ms.value), int(by.value), int(n.value)
 
+    def h2d_probe(self, nbytes: int, reps: int = 8) -> float:
+        """GB/s of pinned-host -> device copies of `nbytes` on the copy stream (the PCIe bound of streaming from host memory)"""
+        g = C.c_double(0)
+        check(lib().hvq_h2d_probe(self._h, int(nbytes), int(reps), C.byref(g)))
+        return float(g.value)
+
     def stats(self) -> HvqStats:
         st = HvqStats()
         check(lib().hvq_get_stats(self._h, C.byref(st)))

@@ -139,7 +139,7 @@ typedef struct HvqJob {                /* 232 bytes */
     uint32_t ref1_off;             /* "future" (macroblock type 2) */
     uint64_t pool;                 /* device addresses of the blob sections */
     uint64_t mv;
-    uint64_t tq;                   /* tile queues of the picture (HvqTileQ[total_tiles]), built by hvq_tileq_kernel */
+    uint64_t tq;                   /* HVQ_F_SELF_REF pictures: side section the level's launch leaves the blocks' pool offsets in (q_offs_off), else 0 */
     uint64_t nest;                 /* nibble-packed nest (HVQ_NESTP_BYTES), 0 when absent */
     uint32_t slot_bytes;           /* readable bytes of a slot (>= pic_bytes + 8) */
     uint32_t flags;                /* HVQ_F_* | picture kind << 16 | unk_shift << 20 */
@@ -147,13 +147,11 @@ typedef struct HvqJob {                /* 232 bytes */
     uint32_t mcb_w;
     uint32_t pool_dwords;          /* payload pool size */
     uint32_t total_tiles;          /* 0: picture dropped by the flush, its workgroups exit */
-    uint32_t q_lits_off;           /* byte offsets from `tq` of the picture's literal, item and pair lists */
-    uint32_t q_items_off;
+    uint32_t rsv0[2];              /* (rounds 3-5: list offsets of the two-pass variant; the kernel addresses this record by dword index, the layout stays) */
     HvqPlaneRec plane[3];
-    uint32_t q_pairs_off;
-    uint32_t q_caps;               /* list entries reserved per tile: items | pairs << 16 (literals: HVQ_TILE_BLOCKS) */
-    uint64_t wave_base;            /* blob section: pool offset of every run of 64 blocks (read by hvq_tileq_kernel only) */
-    uint32_t q_recs_off;           /* byte offset from `tq` of the picture's block records */
+    uint32_t rsv1[2];
+    uint64_t wave_base;            /* blob section: pool offset of every run of 64 blocks (scalar loads of hvq_recon_inline_kernel) */
+    uint32_t rsv2;
     uint32_t q_offs_off;           /* HVQ_F_SELF_REF pictures: byte offset from `tq` of the blocks' pool offsets (u32 per block), else 0 */
     uint32_t pad2[2];
     uint32_t hb_magic[3];          /* per plane, hb = blocks per row: floor(2^32 / hb) + 1 (0 for hb = 1: the quotient is the index itself)
@@ -171,71 +169,7 @@ _Static_assert(sizeof(HvqPlaneRec) == 32, "HvqPlaneRec must be 32 bytes");
 _Static_assert(sizeof(HvqJob) == 232, "HvqJob must be 232 bytes");
 #endif
 
-/*
- * Tile queues (round 3).  Which blocks of a tile need the AOT machinery, in which order, with which bases -- all of it
- * follows from the type bytes alone, so it is worked out ONCE per picture when its descriptors arrive (hvq_tileq_kernel,
- * part of the parse stage) instead of by every reconstruction launch: the reconstruction kernel no longer classifies,
- * ballots, scans or builds lists, and its AOT phase does not wait for its per-block phase.
- *   HvqTileQ   per tile: counts
- *   records    8 bytes per block, HVQ_TILE_BLOCKS per tile: what the owning lane does with the block, with its operands
- *              resolved -- the reconstruction kernel reads neither the map nor the vectors:
- *              w1 = DC value | HVQ_BR_* action << 8 | half-sample flags (hx << 10, hy << 11)
- *              w0 = motion compensated (also the MC part of an MC-residual block): ring offset of the top-left source
- *                   sample (h4m:1327-1355, clamped into the slot); weighted DC: the four neighbour values the predictor
- *                   sees, top | bottom << 8 | left << 16 | right << 24 (h4m:1437-1454, 1811-1814)
- *   literals   u32 per literal block: owner (lane of the tile) | pool offset << 8
- *   items      8 bytes per queued block (intra AOT first, then MC residual): owner | map entry << 8 | HVQ_IQ_WIDE, and the two
- *              scalars of an MC-residual block (h4m:1405-1406) as 16-bit values, the first before its shift by unk_shift;
- *              HVQ_IQ_WIDE (scalars beyond 16 bits, and every item of a serial tile): the pool offset of the payload instead
- *   pairs      8 bytes per (item, basis), items in order, fully decoded (h4m:683-731 / 738-772):
- *              w0 = [17:0] coefficient sum + offset, [18] negate, [19] sample stride 2, [20] row stride 2, [21] MC residual,
- *                   [31:23] item of the tile
- *              w1 = intra: nest index of sample (0,0) (nibble units); MC residual: ring offset of sample (0,0) of the
- *                   70x38 window (origin of h4m:1865-1868 + basis offset, clamped into the slot)
- */
-typedef struct HvqTileQ {
-    uint32_t w0;                   /* pairs | items << 16 | HVQ_TQ_* */
-    uint32_t w1;                   /* literal blocks */
-} HvqTileQ;
-#define HVQ_TQ_INTRA   (1u << 26)  /* the tile has intra AOT items: the nest is staged */
-#define HVQ_TQ_SERIAL  (1u << 27)  /* more pairs than the picture's list reserves: no pair list, items loop over their bases */
-#define HVQ_PAIR_CAP_MAX 1024u     /* pairs per tile a list may reserve (the queue build keeps two tiles' lists in LDS) */
-#define HVQ_BR_LIST    0u          /* literal or AOT block: the lists do it */
-#define HVQ_BR_FLAT    1u          /* flat DC (h4m:281-286) */
-#define HVQ_BR_WDC     2u          /* weighted DC (h4m:299-383) */
-#define HVQ_BR_MC      3u          /* motion compensated */
-#define HVQ_PQ_NEG     (1u << 18)
-#define HVQ_PQ_X2      (1u << 19)
-#define HVQ_PQ_Y2      (1u << 20)
-#define HVQ_PQ_MC      (1u << 21)
-#define HVQ_PQ_ITEM_SHIFT 23
-#define HVQ_IQ_WIDE    (1u << 24)
-
-/* Block classification by map type byte, one dword per (context, type): context 0 = I-picture luma (kind = whole byte,
- * h4m:1093), 1 = I-picture chroma, 2 = P/B picture.  Filled by hvq_type_class() on the host, read by the kernel. */
-#define HVQ_TC_NPAY(c)   ((c) & 0xFFu)           /* payload dwords (hvq_payload_dwords) */
-#define HVQ_TC_NB(c)     (((c) >> 8) & 0xFFu)    /* AOT bases */
-#define HVQ_TC_CLS(c)    (((c) >> 16) & 3u)      /* 0 done by the owning lane, 1 intra AOT, 2 motion compensation + AOT residual */
-#define HVQ_TC_MC        (1u << 18)              /* motion compensated (plain, or the MC part of class 2) */
-#define HVQ_TC_WDC       (1u << 19)              /* weighted-DC intra predictor (intra kind 0) */
-#define HVQ_TC_LIT       (1u << 20)              /* literal block */
-HVQ_HD static inline uint32_t hvq_type_class(uint32_t type, int ctx)
-{
-    const int is_pb = ctx == 2, il = ctx == 0;
-    const uint32_t kind = il ? type : (type & 0xFu);
-    const int inter = is_pb && (type & 0x60u);
-    const int proc = (type & 0x10u) != 0;
-    const uint32_t npay = hvq_payload_dwords(type, is_pb, il);
-    const int aot = kind != 0u && kind != 6u;
-    const int c1 = !inter && aot && kind != 8u;
-    const int c2 = inter && !proc && aot;
-    const uint32_t nb = c1 ? kind : c2 ? kind - 1u : 0u;
-    uint32_t c = (npay & 0xFFu) | ((nb & 0xFFu) << 8) | ((uint32_t)(c1 ? 1 : c2 ? 2 : 0) << 16);
-    if (inter && (c2 || proc || kind == 0u)) c |= HVQ_TC_MC;
-    if (!inter && kind == 0u) c |= HVQ_TC_WDC;
-    if (kind == 6u && npay) c |= HVQ_TC_LIT;
-    return c;
-}
+#define HVQ_PQ_NEG     (1u << 18)   /* a basis' gain word inside the kernel: coefficient sum + offset [17:0], negate */
 
 /* launch table: one entry per picture of a launch.  The grid is (picture slots, tiles): consecutive workgroup ids differ in
  * the picture, and with the slot count a multiple of 8 all tiles of a picture run on one XCD (workgroups are dealt round-robin

@@ -13,20 +13,17 @@
  *                      lane, pairs -> nest or window gather, gain, 16 products -> LDS accumulators (ds_add), items -> samples;
  *                      the tile is assembled in LDS and leaves as 16-byte row segments (every store instruction of a wave
  *                      writes four complete 256-byte runs, every output line reaches HBM once and whole)
- *   hvq_tileq_kernel + hvq_recon_kernel   the two-pass variant (HVQM4_AMD_TILE_QUEUES=1): the queues built once per picture
- *                      into HBM (a record per block, literal list, AOT items, decoded pairs), then read by the reconstruction
  *   hvq_selfref_kernel P pictures with future-referencing macroblocks: the reference's raster-order walk
  *   hvq_yuv420_rgb_kernel, hvq_gather_kernel   display epilogue, bulk readback
  *   - sample arithmetic is SIMD-within-register: v_lerp_u8 for the 2-tap and 4-tap half-sample filters, 16-bit packed math for
  *     the weighted-DC predictor, v_sad_u8 for block sums; the AOT products in the reference's own uint32 wrap arithmetic
- *     (v_mul_lo_u32); the reference's divTable / mcdivTable lookups are a v_rcp_f32 estimate with an exact integer fix-up;
+ *     (v_mul_lo_u32); the reference's divTable / mcdivTable lookups are one v_rcp_f32 and a biased multiply (udiv_table, no fix-up);
  *   - reference pictures are addressed LINEARLY inside the Y|U|V buffer exactly like the reference's pointer arithmetic
  *      as ring base + 32-bit offset; every address is clamped to the picture slot so malformed vectors cannot
  *     fault the GPU.
- * What bounds the reconstruction: round 3's two-pass kernel, the number of gather requests -- four row segments
- * per 4x4 block in four cache lines, a window per AOT basis at its own place -- beside a half-busy VALU; round 4's one-pass
- * kernel, vector-instruction issue (VALU 0.67-0.79 busy on every dependency level, profiles/r04f_levels.txt): it executes the
- * queue derivation the two-pass variant pays a whole extra kernel for.
+ * What bounds the reconstruction: vector-instruction issue (VALU 0.67-0.8 busy on every dependency level).  Round 3's
+ * two-pass variant (queues built once per picture into HBM by a kernel of their own) lost as a stage for three rounds and was
+ * deleted in round 6; its measurements are in profiles/HISTORY.md.
  *
  * Reference behaviour restated per device function (h4m: = h4m_audio_decode.c).
  */
@@ -124,22 +121,6 @@ __device__ __forceinline__ Blk mc_filter(const McRows &rows, int hx, int hy)
     return o;
 }
 
-/* `a` is already clamped so that every row read stays inside the picture slot */
-__device__ __forceinline__ Blk mc_block(const GLB uint8_t *ref, i32 a, i32 stride, int hx, int hy)
-{
-    return mc_filter(mc_load(ref, a, stride, hy), hx, hy);
-}
-
-/* exact floor(num / den) for num <= 4096, den <= 511 (0 -> 0): v_rcp_f32 estimate, integer fix-up.
- * Replaces the reference's divTable / mcdivTable lookups (h4m:265-273) -- no memory access. */
-__device__ __forceinline__ u32 udiv_small(u32 num, u32 den)
-{
-    u32 q = (u32)((float)num * __builtin_amdgcn_rcpf((float)den));
-    i32 r = (i32)(num - __umul24(q, den));
-    if (r < 0) q -= 1;
-    else if ((u32)r >= den) q += 1;
-    return den ? q : 0u;
-}
 
 /* floor(N / den) for the two numerators the tables use (N = 256 with den <= 15, N = 4096 with den <= 255), 0 for den = 0, without the
  * integer fix-up: where N / den is an integer den is a power of two and its reciprocal exact; everywhere else the quotient lies at
@@ -162,12 +143,6 @@ __device__ __forceinline__ i32 sar(u32 v, i32 s)
     i32 r = (i32)v >> s;
     __asm__ volatile("" : "+v"(r));
     return r;
-}
-
-__device__ __forceinline__ u32 pack4(i32 a, i32 b, i32 c, i32 d)
-{
-    a = clampi(a, 0, 255); b = clampi(b, 0, 255); c = clampi(c, 0, 255); d = clampi(d, 0, 255);
-    return (u32)a | ((u32)b << 8) | ((u32)c << 16) | ((u32)d << 24);
 }
 
 /*
@@ -199,72 +174,6 @@ __device__ __forceinline__ void basis_scatter(u32 g, const u32 e[16], u32 *acc_l
     for (int i = 0; i < 16; ++i)
         __hip_atomic_fetch_add(acc_lds + i * STRIDE, g * e[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-}
-
-/* nest gather for one basis, intra (h4m:713-725).  The LDS nest holds two 4-bit values per byte at the
- * reference's linear index (nibble n of the array = nest_data[n]); a basis row spans at most 7 values,
- * so one unaligned 8-byte LDS read per row replaces four byte reads. */
-__device__ __forceinline__ void gather_nest(u32 d, bool landscape, const uint8_t *s_nest, u32 e[16], u32 &lo, u32 &hi)
-{
-    const i32 stride = landscape ? 70 : 38;
-    i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
-    u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
-    i32 o, ys; u32 x2;
-    if (landscape) { o = stride * os + ol; x2 = sl; ys = stride << ss; }
-    else           { o = stride * ol + os; x2 = ss; ys = stride << sl; }
-    const u32 sh = x2 ? 8u : 4u;                                     /* bits between consecutive samples */
-    lo = 255; hi = 0;
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-        const i32 n = o + y * ys;
-        uint64_t q = *(const u64u *)(s_nest + (n >> 1));
-        q >>= 4 * (n & 1);
-        const u32 w0 = (u32)q;
-        /* samples at bits 0, sh, 2sh, 3sh (sh = 4 or 8): all inside the low dword */
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            u32 v = (w0 >> (sh * x)) & 15u;
-            e[4 * y + x] = v;
-            lo = min(lo, v);
-            hi = max(hi, v);
-        }
-    }
-}
-
-/* nest gather for one basis, MC residual: the nest is a 70x38 window of the reference LUMA plane
- * (h4m:1865-1868, 734-765); each basis row (4 samples at stride 1 or 2) is one unaligned 8-byte load */
-__device__ __forceinline__ void gather_window(u32 d, bool landscape, const GLB uint8_t *ref, i32 origin, i32 lw, i32 slot,
-                                              u32 e[16], u32 &lo, u32 &hi)
-{
-    i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;
-    u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
-    i32 o, ys; u32 x2;
-    if (landscape) { o = lw * os + ol; x2 = sl; ys = lw << ss; }
-    else           { o = lw * ol + os; x2 = ss; ys = lw << sl; }
-    const u32 sel = x2 ? 0x06040200u : 0x03020100u;                 /* stride 2: bytes 0,2,4,6 */
-    uint64_t q[4];
-    const i32 base = clampi(origin + o, 0, slot - 8 - 3 * ys);      /* one clamp: legal windows lie inside the slot */
-#if defined(HVQ_ABL) && (HVQ_ABL == 6 || HVQ_ABL == 7)   /* ablation: 6 = two of the four window rows fetched, 7 = one (prices the gathers) */
-    q[0] = *(const GLB u64u *)(ref + base);
-    q[1] = HVQ_ABL == 6 ? *(const GLB u64u *)(ref + base + ys) : q[0] * 3u;
-    q[2] = q[0] ^ 0x5555555555555555ull; q[3] = q[1] + 0x0101010101010101ull;
-#else
-#pragma unroll
-    for (int y = 0; y < 4; ++y) q[y] = *(const GLB u64u *)(ref + base + y * ys);
-#endif
-    lo = 255; hi = 0;
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-        u32 w = __builtin_amdgcn_perm((u32)(q[y] >> 32), (u32)q[y], sel);
-        w = (w >> 4) & 0x0F0F0F0Fu;                                  /* upper nibble of each sample */
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            u32 v = (w >> (8 * x)) & 0xFFu;
-            e[4 * y + x] = v;
-            lo = min(lo, v);
-            hi = max(hi, v);
-        }
-    }
 }
 
 /* four samples: arithmetic shift right, clamp to [0, 255], pack -- gfx950's v_ashr_pk_u8_i32 does two samples per instruction (it
@@ -390,283 +299,9 @@ extern "C" __attribute__((visibility("default"))) void hvq_set_stamps(unsigned l
 #define STAMP(i, VM) do { } while (0)
 #endif
 
-/* block classes by type byte (hvq_type_class), read by hvq_tileq_kernel */
-__device__ u32 g_type_class[3 * 256];
-
-extern "C" hipError_t hvq_upload_tables(void)
-{
-    u32 t[3 * 256];
-    for (int ctx = 0; ctx < 3; ++ctx)
-        for (u32 ty = 0; ty < 256; ++ty) t[ctx * 256 + ty] = hvq_type_class(ty, ctx);
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_type_class), t, sizeof t);
-}
-
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 /* not `volatile`: a volatile asm counts as a store to anything, and every scalar load after it would become a vector load */
 #define HVQ_PIN(x) do { x = (u32)__builtin_amdgcn_readfirstlane((int)(x)); asm("" : "+s"(x)); } while (0)
-
-/* What the owning lane of a block does, with its operands resolved, from the block's descriptors (hvq_desc.h "records"): shared by
- * the queue build (hvq_tileq_kernel) and the reconstruction kernel that derives its queues itself (hvq_recon_inline_kernel). */
-struct BlkSrc { u32 e16, nt, nbt, nlf, nr, mvw; };          /* map entry {value, type << 8}, the four neighbours' entries, the macroblock vector */
-__device__ __forceinline__ u32x2 block_record_b(bool mc, bool wdc, bool flat, bool is_pb, bool is15, const BlkSrc &s, i32 bx, i32 by, i32 ws, i32 hs,
-                                                i32 pw, i32 plane_off, i32 slot, u32 ref0_off, u32 ref1_off)
-{
-    const u32 T = s.e16 >> 8;
-    const i32 V = s.e16 & 0xFF;
-    u32 w0 = 0, w1 = (u32)V;
-    if (mc) {
-        /* plain MC and the MC part of MC-residual blocks (h4m:1327-1355): half-sample rule per version (h4m:1337-1343) */
-        const i32 rx = (i32)(int16_t)(s.mvw & 0xFFFF), ry = (i32)(int16_t)(s.mvw >> 16);
-        const u32 roff = (((T >> 5) & 3u) == 1u) ? ref0_off : ref1_off;
-        const i32 pdx = rx >> ws, pdy = ry >> hs;
-        const int hx = is15 ? (pdx & 1) : (rx & 1), hy = is15 ? (pdy & 1) : (ry & 1);
-        i32 a = plane_off + (pdy >> 1) * pw + (pdx >> 1) + (by & (1 - hs)) * 4 * pw + (bx & (1 - ws)) * 4;
-        /* one clamp for the block: legal vectors keep all rows inside the slot, malformed ones cannot fault */
-        a = clampi(a, 0, slot - 8 - (hy ? 4 : 3) * pw);
-        w0 = roff + (u32)a;
-        w1 |= (HVQ_BR_MC << 8) | ((u32)hx << 10) | ((u32)hy << 11);
-    } else if (wdc) {
-        /* neighbour DCs via the map; the border {0x7F,0xFF} never exposes (h4m:1437-1442, 1811-1814).
-         * I pictures track the left value separately: only kinds 0 and 8 expose it (h4m:1443-1454). */
-        const u32 Tt = (s.nt & 0x7700u) ? (u32)V : (s.nt & 0xFF);
-        const u32 Bb = (s.nbt & 0x7700u) ? (u32)V : (s.nbt & 0xFF);
-        const u32 Rr = (s.nr & 0x7700u) ? (u32)V : (s.nr & 0xFF);
-        const bool lexp = is_pb ? !(s.nlf & 0x7700u) : ((s.nlf >> 8) == 0 || (s.nlf >> 8) == 8);
-        const u32 Ll = lexp ? (s.nlf & 0xFF) : (u32)V;
-        w0 = Tt | (Bb << 8) | (Ll << 16) | (Rr << 24);
-        w1 |= HVQ_BR_WDC << 8;
-    } else if (flat) {
-        w1 |= HVQ_BR_FLAT << 8;
-    }
-    const u32x2 br = { w0, w1 };
-    return br;
-}
-__device__ __forceinline__ u32x2 block_record(u32 tc, bool flat, bool is_pb, bool is15, const BlkSrc &s, i32 bx, i32 by, i32 ws, i32 hs,
-                                              i32 pw, i32 plane_off, i32 slot, u32 ref0_off, u32 ref1_off)
-{
-    return block_record_b(tc & HVQ_TC_MC, tc & HVQ_TC_WDC, flat, is_pb, is15, s, bx, by, ws, hs, pw, plane_off, slot, ref0_off, ref1_off);
-}
-
-/* ------------------------------------------------------------------------------------------------------
- * Tile queues (hvq_desc.h): once per picture, when its descriptors arrive -- part of the parse stage, not of the
- * reconstruction launches.  One workgroup = one tile; lane = block.  Everything the reconstruction kernel used to derive
- * from the type bytes on every launch (class, payload offset by prefix scan, queue slot by ballot, pair slot by a second
- * scan, the basis word's decode, the window origin of an MC-residual block) is done here and left in three lists.
- */
-#define HVQ_TQ_TILES 2           /* tiles per workgroup of the queue build: the second tile's map and vector loads travel while the
-                                    first tile is worked on (the kernel is one chain of round trips per tile, like the reconstruction) */
-struct TqLoad {                  /* what a lane requests first for its block of one tile */
-    int p;
-    bool live, valid;
-    i32 bx, by, hb;
-    u32 e16, nt, nbt, nlf, nr, mvw, wbase, hbvb, pw_sub;
-};
-
-/* LOOP = false: grid (tile pairs, pictures), one pair of tiles per workgroup.  LOOP = true: grid (pictures, splits): workgroup
- * (p, s) walks the tile pairs s, s + splits, ... of picture p -- the picture's job record, map and vectors stay in the scalar
- * cache / the L2 of the one XCD all its workgroups run on, and a batch is a single generation of workgroups instead of dozens.
- * `qbytes` (may be null): bytes of queue data a reconstruction pass reads, summed over the tiles (HvqStats.queue_bytes). */
-template <bool LOOP>
-__global__ __launch_bounds__(HVQ_WG)
-void hvq_tileq_kernel(const HvqJob *__restrict__ jobs, u32 first_job, unsigned long long *__restrict__ qbytes)
-{
-    __shared__ u32 s_cnt[HVQ_TQ_TILES][HVQ_NW][5];
-    __shared__ u32 s_meta[HVQ_TQ_TILES][HVQ_TILE_BLOCKS][3];          /* per item: pool index of its first basis | MC flag, window origin, ring offset of its reference */
-    __shared__ u32 s_pref[HVQ_TQ_TILES][HVQ_PAIR_CAP_MAX];            /* per pair: item | basis number << 9 */
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const HvqJob *__restrict__ J = jobs + first_job + (LOOP ? blockIdx.x : blockIdx.y);
-    const u32 total_tiles = J->total_tiles;
-    const u32 wg_step = LOOP ? gridDim.y : 0x40000000u;
-    u32 qb_sum = 0;
-  for (u32 wgx = LOOP ? blockIdx.y : blockIdx.x; wgx * HVQ_TQ_TILES < total_tiles; wgx += wg_step) {
-    const u32 flags = J->flags;
-    const bool is_pb = ((flags >> HVQ_JOB_KIND_SHIFT) & 3u) != HVQ_PIC_I;
-    const bool landscape = flags & HVQ_F_LANDSCAPE;
-    const i32 lw = (i32)J->width, slot = (i32)J->slot_bytes;
-    const i32 unk = (i32)((flags >> HVQ_JOB_UNK_SHIFT) & 31u);
-    const GLB u32 *__restrict__ pool = (const GLB u32 *)J->pool;
-    GLB uint8_t *q = (GLB uint8_t *)J->tq;
-    const u32 cap_items = J->q_caps & 0xFFFFu, cap_pairs = J->q_caps >> 16;
-
-    TqLoad L[HVQ_TQ_TILES];
-#pragma unroll
-    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
-        const u32 tile = wgx * HVQ_TQ_TILES + (u32)h;
-        TqLoad &l = L[h];
-        l.live = tile < total_tiles;
-        const u32 t = l.live ? tile : total_tiles - 1u;
-        l.p = (t >= J->plane[1].tile_first) + (t >= J->plane[2].tile_first);
-        l.hbvb = J->plane[l.p].hbvb; l.pw_sub = J->plane[l.p].pw_sub;
-        l.hb = (i32)(l.hbvb & 0xFFFFu);
-        const u32 b = (t - J->plane[l.p].tile_first) * HVQ_TILE_BLOCKS + (u32)tid;
-        l.valid = l.live && b < (u32)l.hb * (l.hbvb >> 16);
-        block_coords(l.valid ? b : 0u, l.hb, 1.0f / (float)l.hb, l.bx, l.by);
-        const i32 ws = (i32)((l.pw_sub >> 16) & 0xFFu), hs = (i32)(l.pw_sub >> 24);
-        const i32 mstride = l.hb + 2;
-        const GLB uint8_t *ent = (const GLB uint8_t *)J->plane[l.p].map + 2 * ((l.by + 1) * mstride + l.bx + 1);
-        l.e16 = *(const GLB uint16_t *)ent;
-        l.nt = *(const GLB uint16_t *)(ent - 2 * mstride); l.nbt = *(const GLB uint16_t *)(ent + 2 * mstride);
-        l.nlf = *(const GLB uint16_t *)(ent - 2); l.nr = *(const GLB uint16_t *)(ent + 2);
-        l.mvw = 0;
-        if (is_pb) l.mvw = ((const GLB u32 *)J->mv)[(l.by >> (1 - hs)) * (i32)J->mcb_w + (l.bx >> (1 - ws))];
-        l.wbase = ((const GLB u32 *)J->wave_base)[t * HVQ_NW + (u32)wave];
-    }
-
-    /* ---- phase 1, both tiles: class, block record, scans, counts ---- */
-    u32 off[HVQ_TQ_TILES], cls[HVQ_TQ_TILES], nb[HVQ_TQ_TILES], sc1[HVQ_TQ_TILES], sc2[HVQ_TQ_TILES];
-    bool lit[HVQ_TQ_TILES];
-    unsigned long long m1[HVQ_TQ_TILES], m2[HVQ_TQ_TILES], ml[HVQ_TQ_TILES];
-#pragma unroll
-    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
-        const TqLoad &l = L[h];
-        const u32 tile = wgx * HVQ_TQ_TILES + (u32)h;
-        const int p = l.p;
-        const i32 bx = l.bx, by = l.by;
-        const i32 ws = (i32)((l.pw_sub >> 16) & 0xFFu), hs = (i32)(l.pw_sub >> 24);
-        const u32 e16 = l.e16, mvw = l.mvw, T = e16 >> 8;
-        const bool valid = l.valid;
-        /* the block's class, computed (a table in memory would be one more dependent access) */
-        const u32 tc = valid ? hvq_type_class(T, is_pb ? 2 : p == 0 ? 0 : 1) : 0u;
-        const u32 npay = HVQ_TC_NPAY(tc);
-        cls[h] = HVQ_TC_CLS(tc); nb[h] = HVQ_TC_NB(tc);
-        lit[h] = tc & HVQ_TC_LIT;
-        if (l.live) {   /* the block's record: what its owning lane does, operands resolved */
-            const BlkSrc src = { e16, l.nt, l.nbt, l.nlf, l.nr, mvw };
-            const u32x2 br = block_record(tc, valid && cls[h] == 0 && !lit[h], is_pb, (flags & HVQ_F_IS15) != 0, src, bx, by, ws, hs,
-                                          (i32)(l.pw_sub & 0xFFFFu), (i32)J->plane[p].plane_off, slot, J->ref0_off, J->ref1_off);
-            ((GLB u32x2 *)(q + J->q_recs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = br;
-        }
-        off[h] = l.wbase + wave_incl_scan(npay) - npay;
-        /* queue order: intra AOT items first, then MC-residual items, each in block order; pairs follow their items */
-        m1[h] = __ballot(cls[h] == 1); m2[h] = __ballot(cls[h] == 2); ml[h] = __ballot(lit[h]);
-        sc1[h] = wave_incl_scan(cls[h] == 1 ? nb[h] : 0u); sc2[h] = wave_incl_scan(cls[h] == 2 ? nb[h] : 0u);
-        if (lane == 63) {
-            s_cnt[h][wave][0] = (u32)__popcll(m1[h]); s_cnt[h][wave][1] = (u32)__popcll(m2[h]); s_cnt[h][wave][2] = sc1[h]; s_cnt[h][wave][3] = sc2[h];
-            s_cnt[h][wave][4] = (u32)__popcll(ml[h]);
-        }
-    }
-    __syncthreads();
-    /* ---- phase 2, both tiles: slots; literal list; what the pair lanes need, into LDS; the scalars of MC-residual items requested ---- */
-    u32 npairs[HVQ_TQ_TILES], it_of[HVQ_TQ_TILES], p0[HVQ_TQ_TILES], p1[HVQ_TQ_TILES];
-    bool serial[HVQ_TQ_TILES];
-#pragma unroll
-    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
-        const TqLoad &l = L[h];
-        const u32 tile = wgx * HVQ_TQ_TILES + (u32)h;
-        u32 tot[5] = { 0, 0, 0, 0, 0 }, mine[5] = { 0, 0, 0, 0, 0 };
-#pragma unroll
-        for (int v = 0; v < HVQ_NW; ++v)
-#pragma unroll
-            for (int k = 0; k < 5; ++k) { const u32 c = s_cnt[h][v][k]; tot[k] += c; if (v < wave) mine[k] += c; }
-        const u32 nI = tot[0], nitems = tot[0] + tot[1], nlit = tot[4];
-        npairs[h] = tot[2] + tot[3];
-        serial[h] = npairs[h] > cap_pairs;
-        it_of[h] = 0; p0[h] = 0; p1[h] = 0;
-        if (!l.live) continue;                                       /* uniform */
-        if (tid == 0) {
-            GLB HvqTileQ *t = (GLB HvqTileQ *)q + tile;
-            t->w0 = (serial[h] ? 0u : npairs[h]) | (nitems << 16) | (nI ? HVQ_TQ_INTRA : 0u) | (serial[h] ? HVQ_TQ_SERIAL : 0u);
-            t->w1 = nlit;
-            qb_sum += 8u + HVQ_TILE_BLOCKS * 8u + nlit * 20u + nitems * 8u + (serial[h] ? 0u : npairs[h] * 8u);
-        }
-        if (lit[h]) ((GLB u32 *)(q + J->q_lits_off))[(size_t)tile * HVQ_TILE_BLOCKS + mine[4] + lanes_below(ml[h])] = (u32)tid | (off[h] << 8);
-        if (J->q_offs_off) ((GLB u32 *)(q + J->q_offs_off))[(size_t)tile * HVQ_TILE_BLOCKS + (u32)tid] = off[h];     /* for hvq_selfref_kernel */
-        if (cls[h]) {
-            const u32 T = l.e16 >> 8;
-            const u32 it = cls[h] == 1 ? mine[0] + lanes_below(m1[h]) : nI + mine[1] + lanes_below(m2[h]);
-            it_of[h] = it;
-            if (cls[h] == 2) { p0[h] = pool[off[h]]; p1[h] = pool[off[h] + 1]; }        /* not used before phase 3: both tiles' travel together */
-            if (!serial[h] && it < cap_items) {
-                /* the pairs are written by one lane per PAIR (the basis dwords of a block are dependent loads when its owner walks
-                 * them one after the other): the owner leaves what a pair needs from its item, and the pair slots of its bases */
-                const u32 pstart = cls[h] == 1 ? mine[2] + sc1[h] - nb[h] : tot[2] + mine[3] + sc2[h] - nb[h];
-                i32 origin = 0;
-                u32 ref_off = 0;
-                if (cls[h] == 2) {
-                    const i32 rx = (i32)(int16_t)(l.mvw & 0xFFFF), ry = (i32)(int16_t)(l.mvw >> 16);
-                    origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;   /* h4m:1865-1868 */
-                    ref_off = ((T >> 5) & 3u) == 1u ? J->ref0_off : J->ref1_off;
-                }
-                s_meta[h][it][0] = (off[h] + (cls[h] == 2 ? 2u : 0u)) | (cls[h] == 2 ? 0x80000000u : 0u);
-                s_meta[h][it][1] = (u32)origin;
-                s_meta[h][it][2] = ref_off;
-#pragma clang loop unroll(disable) vectorize(disable)
-                for (u32 k = 0; k < nb[h]; ++k) s_pref[h][pstart + k] = it | (k << 9);
-            }
-        }
-    }
-    __syncthreads();
-    /* ---- phase 3, both tiles: one lane per pair (first round's basis dwords of both tiles requested together), item records ---- */
-    u32 d0[HVQ_TQ_TILES], pr0[HVQ_TQ_TILES];
-#pragma unroll
-    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
-        d0[h] = 0; pr0[h] = 0;
-        if (L[h].live && !serial[h] && (u32)tid < npairs[h]) {
-            pr0[h] = s_pref[h][tid];
-            d0[h] = pool[(s_meta[h][pr0[h] & 511u][0] & 0x7FFFFFFFu) + (pr0[h] >> 9)];
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < HVQ_TQ_TILES; ++h) {
-        const TqLoad &l = L[h];
-        if (!l.live) continue;
-        const u32 tile = wgx * HVQ_TQ_TILES + (u32)h;
-        if (cls[h] && it_of[h] < cap_items) {                        /* always: the cap is the picture's largest tile queue */
-            /* 8 bytes: owner | map entry, and the two scalars of an MC-residual block as 16-bit values (h4m:1405-1406: the first is
-             * (s >> dc_shift) << unk_shift, kept unshifted).  Scalars that do not fit, and every item of a serial tile (whose owner
-             * walks its bases), carry the payload offset instead: the reconstruction kernel then reads the pool itself. */
-            const i32 a = (i32)p0[h] >> unk, b = (i32)p1[h];
-            const bool fits = ((u32)a << unk) == p0[h] && a == (i32)(int16_t)a && b == (i32)(int16_t)b;
-            const bool wide = serial[h] || (cls[h] == 2 && !fits);
-            const u32x2 rec = { (u32)tid | (l.e16 << 8) | (wide ? HVQ_IQ_WIDE : 0u), wide ? off[h] : (((u32)a & 0xFFFFu) | ((u32)b << 16)) };
-            ((GLB u32x2 *)(q + J->q_items_off))[(size_t)tile * cap_items + it_of[h]] = rec;
-        }
-        if (serial[h]) continue;
-        GLB u32x2 *dst = (GLB u32x2 *)(q + J->q_pairs_off) + (size_t)tile * cap_pairs;
-        for (u32 pi = (u32)tid; pi < npairs[h]; pi += HVQ_WG) {
-            const u32 pr = pi == (u32)tid ? pr0[h] : s_pref[h][pi], it = pr & 511u;
-            const u32 m0 = s_meta[h][it][0];
-            const bool mc = m0 & 0x80000000u;
-            const u32 d = pi == (u32)tid ? d0[h] : pool[(m0 & 0x7FFFFFFFu) + (pr >> 9)];
-            const i32 ol = d & 0x3F, os = (d >> 6) & 0x1F;                       /* h4m:683-711 */
-            const u32 sl = (d >> 11) & 1, ss = (d >> 12) & 1;
-            const u32 x2 = landscape ? sl : ss, y2 = landscape ? ss : sl;
-            u32 w0 = (d >> 14) | ((d & 0x2000u) ? HVQ_PQ_NEG : 0u) | (x2 ? HVQ_PQ_X2 : 0u) | (y2 ? HVQ_PQ_Y2 : 0u) | (it << HVQ_PQ_ITEM_SHIFT);
-            u32 w1;
-            if (!mc) {
-                const i32 stride = landscape ? 70 : 38;
-                w1 = (u32)(landscape ? stride * os + ol : stride * ol + os);
-            } else {
-                const i32 o = landscape ? lw * os + ol : lw * ol + os;
-                const i32 ys = lw << y2;
-                w1 = s_meta[h][it][2] + (u32)clampi((i32)s_meta[h][it][1] + o, 0, slot - 8 - 3 * ys);     /* one clamp: legal windows lie inside the slot */
-                w0 |= HVQ_PQ_MC;
-            }
-            const u32x2 pw01 = { w0, w1 };
-            dst[pi] = pw01;
-        }
-    }
-  }     /* no barrier between pairs of tiles: the lists in LDS are rewritten behind the next pair's first barrier, which every thread reaches after its phase 3 */
-    if (qbytes && tid == 0 && qb_sum) atomicAdd(qbytes, (unsigned long long)qb_sum);
-}
-
-/* splits = 0: one workgroup per pair of tiles; otherwise `splits` workgroups per picture, each walking its share of the tile pairs */
-extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, uint32_t splits,
-                                       unsigned long long *qbytes_dev, hipStream_t stream)
-{
-    if (njobs == 0 || max_tiles == 0) return hipSuccess;
-    const uint32_t npairs = (max_tiles + HVQ_TQ_TILES - 1) / HVQ_TQ_TILES;
-    if (splits) {
-        if (splits > npairs) splits = npairs;
-        hipLaunchKernelGGL(hvq_tileq_kernel<true>, dim3(njobs, splits), dim3(HVQ_WG), 0, stream, jobs_dev, first_job, qbytes_dev);
-        return hipGetLastError();
-    }
-    for (uint32_t at = 0; at < njobs; at += 32768u) {
-        const uint32_t n = njobs - at < 32768u ? njobs - at : 32768u;
-        hipLaunchKernelGGL(hvq_tileq_kernel<false>, dim3(npairs, n), dim3(HVQ_WG), 0, stream, jobs_dev, first_job + at, qbytes_dev);
-    }
-    return hipGetLastError();
-}
 
 /* ------------------------------------------------------------------------------------------------------
  * P pictures with future-referencing (type 2) macroblocks.  HVQM4DecodePpic passes the picture being written as `future`
@@ -803,7 +438,7 @@ void hvq_selfref_kernel(const HvqJob *__restrict__ J, const uint8_t *__restrict_
                             for (int x = 0; x < 4; ++x) { const u32 v = sr_mc_sample(g, srco, pw, hx, hy, i, x); md[4 * i + x] = v; sum += v; lo = min(lo, v); hi = max(hi, v); }
                         const i32 mean = (i32)(sum >> 4);
                         const u32 addend = pool[off] - mean_aot;
-                        const u32 factor = pool[off + 1u] * udiv_small(0x1000u, hi - lo);            /* mcdivTable[max - min] */
+                        const u32 factor = pool[off + 1u] * udiv_table<4096>(hi - lo);            /* mcdivTable[max - min] */
                         for (int i = 0; i < 16; ++i) {
                             const u32 t = (u32)((i32)md[i] - mean) * factor;
                             const i32 v = sar(acc[i] + addend + t, unk) + (i32)md[i];
@@ -823,32 +458,6 @@ extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *s
     return hipGetLastError();
 }
 
-/* ------------------------------------------------------------------------------------------------------
- * Reconstruction over tile queues in HBM (round 3; since round 4 the opt-in two-pass variant, HVQM4_AMD_TILE_QUEUES=1 -- the
- * default is hvq_recon_inline_kernel further down, which derives the same queues inside the workgroup).
- *
- * With its queues resident this kernel is the fastest reconstruction (nothing is derived in it: 330 vector instructions per 64
- * blocks, VALU 0.45 busy); what bounds it is the request rate of its gathers beside a store path that holds a wave's slot until
- * its lines are acknowledged (profiles/r04_ta_calibration.txt).  But the queue build it needs costs 0.68 ms per
- * 2048 dense pictures against its own 1.0 ms (profiles/r04a_*): as a stage it is slower than deriving the queues in place.
- *
- * Grid = (picture slots of the launch, tiles); workgroup = TPW tiles of 256 consecutive blocks of one plane.
- *   prologue  the picture's job record and the tiles' queue records come through the scalar cache; every lane requests, at
- *             once, its block's map entry with both horizontal neighbours (ONE 8-byte load), the vertical neighbours, the
- *             macroblock vector, its (item, basis) pair, its literal entry and its share of the nest.
- *   phase A   every lane owns one block of each tile: flat, weighted-DC and motion-compensated blocks (and the MC part of
- *             MC-residual blocks) are reconstructed into the LDS tile; the action follows from the type byte with a few
- *             compares.  Literal blocks are copied by the lanes that hold the tile's literal list.
- *   phase B1  one lane per PAIR of the tiles' pair lists (fully decoded by hvq_tileq_kernel): nest or window gather,
- *             min/max, gain, 16 products -> ds_add into the item's accumulators.  Does not depend on phase A.
- *   phase B2  one lane per ITEM: accumulators -> samples (h4m:1367-1376 / 1385-1419).
- *   phase C   the finished tile leaves LDS as 16-byte row segments: one store instruction of a wave
- *             writes four complete 256-byte runs of the destination plane (full lines, written once).
- * ITEMS_CAP = accumulator rows (the most items of any workgroup of the launch, rounded up): a compile-time
- * stride puts every accumulator address into the instruction's offset field.
- * TPW = tiles per workgroup (1 or 2): two tiles double the memory-level parallelism of a wave -- what streams with few AOT
- * blocks are short of -- but also the pooled accumulators (profiles/r02o_ab_two_tiles.txt).
- */
 __device__ __forceinline__ u32 gain_q(u32 w0, u32 lo, u32 hi)
 {
     const u32 q = udiv_table<256>((hi - lo) & 15u);                 /* divTable[max - min] = 16 * (256 / r), h4m:265-271 */
@@ -906,374 +515,6 @@ __device__ __forceinline__ void window_finish(const uint64_t q[4], bool x2, u32 
     }
 }
 
-template <int ITEMS_CAP, int TPW>
-__global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
-void hvq_recon_kernel(const HvqJob *__restrict__ jobs, const HvqTileQ *__restrict__ tq_all HVQ_STAMP_ARG)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_nest[HVQ_NESTP_BYTES + 8];   /* nest packed two 4-bit values per byte */
-    __shared__ __attribute__((aligned(16))) u32 s_out[TPW][4][HVQ_WG];   /* [tile][sample row][block] packed dwords */
-    __shared__ __attribute__((aligned(16))) u32 s_acc[16 * ITEMS_CAP];   /* AOT accumulators, [sample][item]: lanes of
-                                              one ds_add hit consecutive banks (an [item][16] layout is a 32-way conflict) */
-    const int tid = threadIdx.x;
-    STAMP(0, 0);
-    /* grid = (8 pictures, workgroups, groups of 8): workgroup ids run over the 8 pictures of a group first (one per XCD), then
-     * over a picture's workgroups, then over groups -- eight pictures are in flight at a time, so their reference pictures stay in the L2s */
-    const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
-    const u32 wg = blockIdx.y;
-    /* the job table is in launch-slot order: no indirection between the grid position and the record (one scalar round trip
-     * less at the head of every wave's life) */
-    const HvqJob *__restrict__ J = jobs + slot_id;
-    /* The per-plane part of the record is read for ALL THREE planes at once and selected in registers: the empty asm pins
-     * every word in a scalar register here.  Written as `p = ...; x = J->plane[p].x` the compiler selects the ADDRESS and
-     * loads afterwards -- a chain of four dependent scalar loads instead of one. */
-    const u32 *__restrict__ PW = (const u32 *)&J->plane[0];
-    u32 w0[8], w1[8], w2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { w0[i] = PW[i]; w1[i] = PW[8 + i]; w2[i] = PW[16 + i]; }
-    /* the picture-wide part too (words 0..19 and 44, 45 of the record) */
-    const u32 *__restrict__ CW = (const u32 *)J;
-    u32 cw[20];
-#pragma unroll
-    for (int i = 0; i < 20; ++i) cw[i] = CW[i];
-    u32 q_pairs_off = CW[44], q_caps = CW[45], q_recs_off = CW[48];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { HVQ_PIN(w0[i]); HVQ_PIN(w1[i]); HVQ_PIN(w2[i]); }
-#pragma unroll
-    for (int i = 0; i < 20; ++i) HVQ_PIN(cw[i]);
-    HVQ_PIN(q_pairs_off); HVQ_PIN(q_caps); HVQ_PIN(q_recs_off);
-    const u32 total_tiles = cw[17];
-    /* words of HvqPlaneRec: 0,1 map; 2,3 dst; 4 plane_off; 5 tile_first; 6 hbvb; 7 pw_sub.
-     * Workgroup wg of the picture -> plane and the TPW consecutive tiles of that plane it owns (the last group may be short) */
-    const u32 n0 = w1[5] - w0[5], n1 = w2[5] - w1[5], n2 = total_tiles - w2[5];
-    const u32 pf1 = (n0 + TPW - 1) / TPW, pf2 = pf1 + (n1 + TPW - 1) / TPW, pend = pf2 + (n2 + TPW - 1) / TPW;
-    if (total_tiles == 0 || wg >= pend) return;                              /* picture dropped by the flush */
-    const int p = (wg >= pf1) + (wg >= pf2);
-    u32 w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = p == 0 ? w0[i] : p == 1 ? w1[i] : w2[i];
-    const u32 hbvb = w[6], pw_sub = w[7], tile_first = w[5];
-    const u32 nplane_tiles = p == 0 ? n0 : p == 1 ? n1 : n2;
-    const u32 pair = wg - (p == 0 ? 0u : p == 1 ? pf1 : pf2);
-    const u32 tile0 = tile_first + (u32)TPW * pair;
-    const int ntl = (int)min((u32)TPW, nplane_tiles - (u32)TPW * pair);      /* tiles of this workgroup */
-    const uint64_t map_a = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    const uint64_t dst_a = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-    const i32 plane_off = (i32)w[4];
-    const i32 hb = (i32)(hbvb & 0xFFFFu);
-    const u32 flags = cw[13];
-    const u32 pic_kind = (flags >> HVQ_JOB_KIND_SHIFT) & 3u;
-    const i32 unk = (i32)((flags >> HVQ_JOB_UNK_SHIFT) & 31u);
-    const bool is_pb = pic_kind != HVQ_PIC_I;
-    const bool landscape = flags & HVQ_F_LANDSCAPE;
-    const bool is15 = flags & HVQ_F_IS15;
-    const u32 nblocks = (u32)hb * (hbvb >> 16);
-    const u32 b0 = (u32)TPW * pair * HVQ_TILE_BLOCKS;
-    const i32 ws = (i32)((pw_sub >> 16) & 0xFFu), hs = (i32)(pw_sub >> 24);
-    const i32 pw = (i32)(pw_sub & 0xFFFFu);
-    const i32 mstride = hb + 2;
-    const float rhb = 1.0f / (float)hb;
-    const GLB uint8_t *map = (const GLB uint8_t *)map_a;
-#define HVQ_W64(i) ((uint64_t)cw[i] | ((uint64_t)cw[(i) + 1] << 32))
-    const GLB uint8_t *ring = (const GLB uint8_t *)HVQ_W64(0);
-    const u32 ref0_off = cw[2], ref1_off = cw[3];
-    const GLB u32 *__restrict__ pool = (const GLB u32 *)HVQ_W64(4);
-    const GLB u32 *__restrict__ mvs = (const GLB u32 *)HVQ_W64(6);
-    const GLB uint8_t *__restrict__ qb = (const GLB uint8_t *)HVQ_W64(8);
-    const GLB u32 *__restrict__ nestp = (const GLB u32 *)HVQ_W64(10);
-    GLB uint8_t *plane = (GLB uint8_t *)dst_a;
-    /* timing experiment 16: every row of the tile is stored into one 64 KB window (the stores are issued and acknowledged,
-     * HBM sees almost none of them) */
-    if (HVQ_ABL == 16) plane = (GLB uint8_t *)(HVQ_W64(0) + (uint64_t)((wg & 15u) * 4096u));
-    const i32 slot = (i32)cw[12];
-    const i32 lw = (i32)cw[14];
-    const i32 mcb_w = (i32)cw[15];
-    const u32 q_lits_off = cw[18], q_items_off = cw[19];
-    const u32 cap_items = q_caps & 0xFFFFu, cap_pairs = q_caps >> 16;
-    /* ---- the blocks' records go out first: they need the job record only ---- */
-    const GLB u32x2 *__restrict__ qrecs = (const GLB u32x2 *)(qb + q_recs_off);
-    u32x2 brec[TPW];
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        brec[h] = (u32x2)(0u);
-        if (h < ntl) brec[h] = qrecs[(size_t)(tile0 + (u32)h) * HVQ_TILE_BLOCKS + (u32)tid];
-    }
-    /* ---- the tiles' queue records.  Scalar loads: they are addressed through the kernel argument (the batch's queue buffer,
-     * which holds the job's `tq`), because only a load the compiler can prove read-only becomes s_load -- through an address
-     * taken from the job record it is a vector load with a full wait in front of everything else ---- */
-    const u32 tq_idx = (u32)((HVQ_W64(8) - (uint64_t)(uintptr_t)tq_all) >> 3) + tile0;
-    u32 np[TPW], ni[TPW], nl[TPW], qf = 0;
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        u32 a = 0, b = 0;
-        if (h < ntl) { a = tq_all[tq_idx + (u32)h].w0; b = tq_all[tq_idx + (u32)h].w1; }
-        HVQ_PIN(a); HVQ_PIN(b);
-        np[h] = a & 0xFFFFu; ni[h] = (a >> 16) & 0x3FFu; nl[h] = b; qf |= a;
-    }
-    const u32 npairs = TPW == 2 ? np[0] + np[TPW - 1] : np[0];
-    const u32 nitems = TPW == 2 ? ni[0] + ni[TPW - 1] : ni[0];
-    const u32 nlits = TPW == 2 ? nl[0] + nl[TPW - 1] : nl[0];
-    STAMP(1, 0);
-    /* first round of the pair list (pooled over the tiles: tile 0's pairs, then tile 1's) */
-    const GLB u32x2 *__restrict__ qpairs = (const GLB u32x2 *)(qb + q_pairs_off);
-    auto pair_at = [&](u32 pi) -> u32x2 {                                   /* nothing here may USE the loaded words: that would wait for them */
-        const bool second = TPW == 2 && pi >= np[0];
-        return qpairs[(size_t)(tile0 + (second ? 1u : 0u)) * cap_pairs + (pi - (second ? np[0] : 0u))];
-    };
-    u32x2 pr = { 0u, 0u };
-    if ((u32)tid < npairs) pr = pair_at((u32)tid);
-    /* the first round's item records with the prologue's requests: their first touch is an HBM miss that would otherwise sit
-     * between the pair phase and the item phase (r03q: +2 %) */
-    typedef u32x2 u32x4i;                                                   /* 8-byte item records (hvq_desc.h) */
-    const GLB u32x4i *__restrict__ qitems = (const GLB u32x4i *)(qb + q_items_off);
-    auto item_at = [&](u32 it) -> u32x4i {
-        const bool second = TPW == 2 && it >= ni[0];
-        return qitems[(size_t)(tile0 + (second ? 1u : 0u)) * cap_items + (it - (second ? ni[0] : 0u))];
-    };
-    u32x4i rec = { 0u, 0u };
-    if ((u32)tid < nitems) rec = item_at((u32)tid);
-    /* the literal list is held by the LAST lanes of the workgroup: the first waves already carry the pair and item lists */
-    u32 lit = 0;
-    const u32 li = (u32)(HVQ_WG - 1 - tid);
-    const bool has_lit = li < nlits;
-    const bool lit_second = TPW == 2 && li >= nl[0];
-    if (has_lit) lit = ((const GLB u32 *)(qb + q_lits_off))[(size_t)(tile0 + (lit_second ? 1u : 0u)) * HVQ_TILE_BLOCKS + (li - (lit_second ? nl[0] : 0u))];
-    const bool nest_second = tid + HVQ_WG < (HVQ_NESTP_BYTES + 3) / 4;
-    u32 nq0 = 0, nq1 = 0;
-    if (qf & HVQ_TQ_INTRA) { nq0 = nestp[tid]; if (nest_second) nq1 = nestp[tid + HVQ_WG]; }       /* already nibble-packed by the parser */
-    if (nitems) {
-        /* 16 * ITEMS_CAP dwords, ITEMS_CAP a multiple of 32: 16-byte stores */
-        typedef u32 u32x4z __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (u32 i = (u32)tid; i < 4u * ITEMS_CAP; i += HVQ_WG) ((u32x4z *)s_acc)[i] = (u32x4z)(0u);
-    }
-    /* literal blocks (h4m:543-549): second hop right behind the prologue's loads */
-    typedef u32 u32x4l __attribute__((ext_vector_type(4), aligned(4)));
-    u32x4l litv = { 0u, 0u, 0u, 0u };
-    if (has_lit) litv = *(const GLB u32x4l *)(pool + (lit >> 8));
-    if (qf & HVQ_TQ_INTRA) {
-        ((u32 *)s_nest)[tid] = nq0;
-        if (nest_second) ((u32 *)s_nest)[tid + HVQ_WG] = nq1;
-    }
-    STAMP(2, 1);
-#if HVQ_BARRIER1_EARLY
-    if (nitems) __syncthreads();
-#endif
-    STAMP(3, 0);
-
-    /* ---- second round trip: motion-compensation rows (lane = block) and window rows (lane = pair) ---- */
-    McRows rows[TPW];
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        if (((brec[h].y >> 8) & 3u) == HVQ_BR_MC) {
-            /* plain MC, and the MC part of MC-residual blocks (finished in phase B2 from the tile) */
-            u32 vo = brec[h].x;
-            /* timing experiments only (tools/variant.sh <name> -DHVQ_ABL=n; wrong pictures):
-             *   11 chroma lane pairs read the same address (what a U/V-interleaved reference copy would buy)
-             *   12 every quad reads ONE address (a quarter of the lines, same instructions)   13 no row loads at all
-             *   14 rows read from the workgroup's own output position (sequential, L2-friendly) instead of the vector's target */
-            if (HVQ_ABL == 11 && p != 0) vo = (u32)__builtin_amdgcn_mov_dpp((int)vo, 0xA0 /* quad_perm [0,0,2,2] */, 0xF, 0xF, true);
-            if (HVQ_ABL == 12) vo = (u32)__builtin_amdgcn_mov_dpp((int)vo, 0x00 /* quad_perm [0,0,0,0] */, 0xF, 0xF, true);
-            if (HVQ_ABL == 13) {
-#pragma unroll
-                for (int y = 0; y < 5; ++y) rows[h].q[y] = (uint64_t)vo * 0x0101010101ull + (uint64_t)y;
-                continue;
-            }
-#pragma unroll
-            for (int y = 0; y < 4; ++y) rows[h].q[y] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(y * pw)));
-            rows[h].q[4] = 0;
-            if (brec[h].y & 0x800u) rows[h].q[4] = *(const GLB u64u *)(ring + (size_t)(u32)(vo + (u32)(4 * pw)));   /* 5th row only for vertical half samples */
-        }
-    }
-    /* the first round's window rows are in flight beside the rows above (r03q: +2 %; with the item records below +5 %) */
-    constexpr bool EARLY = true;
-    uint64_t wq[4] = { 0, 0, 0, 0 };
-    if (EARLY && (u32)tid < npairs && (pr.x & HVQ_PQ_MC)) window_load(ring, pr.y, (u32)lw << ((pr.x >> 20) & 1u), wq);
-
-    /* ---- phase A: the blocks the owning lane reconstructs by itself ---- */
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        const u32 act = (brec[h].y >> 8) & 3u;
-        const i32 V = brec[h].y & 0xFF;
-        Blk o;
-        if (act == HVQ_BR_MC) {
-            o = mc_filter(rows[h], (brec[h].y >> 10) & 1, (brec[h].y >> 11) & 1);
-        } else if (act == HVQ_BR_WDC) {
-            const u32 nb4 = brec[h].x;                                        /* neighbour values as the predictor sees them */
-            o = weight_block(V, (i32)(nb4 & 0xFF), (i32)((nb4 >> 8) & 0xFF), (i32)((nb4 >> 16) & 0xFF), (i32)(nb4 >> 24));
-        } else if (act == HVQ_BR_FLAT) {
-            const u32 v = (u32)V * 0x01010101u;
-            o.r[0] = o.r[1] = o.r[2] = o.r[3] = v;
-        } else continue;                                                       /* literal or AOT: the lists do it */
-#pragma unroll
-        for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
-    }
-    if (has_lit) {                                                            /* the lanes that hold the literal list copy the blocks into the tile */
-        u32 *so = &s_out[lit_second ? TPW - 1 : 0][0][lit & 0xFFu];
-        so[0] = litv.x; so[HVQ_WG] = litv.y; so[2 * HVQ_WG] = litv.z; so[3 * HVQ_WG] = litv.w;
-    }
-    if (TPW == 2 && nlits > (u32)HVQ_WG) {                                     /* two tiles with more literal blocks than lanes: a second round (rare) */
-        const u32 l2 = li + (u32)HVQ_WG;
-        if (l2 < nlits) {
-            const bool sec = l2 >= nl[0];
-            const u32 e = ((const GLB u32 *)(qb + q_lits_off))[(size_t)(tile0 + (sec ? 1u : 0u)) * HVQ_TILE_BLOCKS + (l2 - (sec ? nl[0] : 0u))];
-            const u32x4l v = *(const GLB u32x4l *)(pool + (e >> 8));
-            u32 *so = &s_out[sec ? TPW - 1 : 0][0][e & 0xFFu];
-            so[0] = v.x; so[HVQ_WG] = v.y; so[2 * HVQ_WG] = v.z; so[3 * HVQ_WG] = v.w;
-        }
-    }
-    STAMP(4, 1);
-#if !HVQ_BARRIER1_EARLY
-    /* barrier 1 -- nest staged, accumulators zero: both happened before the second round trip was even requested; the rows
-     * and the window rows were requested WITHOUT waiting for the other waves, only their use in the pair phase is behind it */
-    if (nitems) __syncthreads();
-#endif
-
-    if (nitems) {
-        /* ---- phase B1: one lane per (item, basis) pair ---- */
-        const i32 nstride = landscape ? 70 : 38;
-        for (u32 pi = (u32)tid; pi < npairs; ) {
-            const u32 it = (pr.x >> HVQ_PQ_ITEM_SHIFT) + ((TPW == 2 && pi >= np[0]) ? ni[0] : 0u);   /* pooled accumulators */
-            const bool x2 = pr.x & HVQ_PQ_X2;
-            u32 e[16], lo, hi;
-            if (pr.x & HVQ_PQ_MC) {
-                if (!EARLY || pi != (u32)tid) window_load(ring, pr.y, (u32)lw << ((pr.x >> 20) & 1u), wq);
-                window_finish(wq, x2, e, lo, hi);
-            } else gather_nest_q((i32)pr.y, x2, nstride << ((pr.x >> 20) & 1u), s_nest, e, lo, hi);
-            basis_scatter<ITEMS_CAP>(gain_q(pr.x, lo, hi), e, s_acc + it);
-            pi += HVQ_WG;
-            if (pi < npairs) pr = pair_at(pi);
-        }
-        STAMP(7, 1);
-        /* ---- phase B2: one lane per item (two rounds when a pair of tiles queued more than 256) ---- */
-        __syncthreads();                                                       /* barrier 2: accumulators complete */
-        STAMP(8, 0);
-        for (u32 it = (u32)tid; it < nitems; it += HVQ_WG) {
-            const bool second = TPW == 2 && it >= ni[0];
-            if (it != (u32)tid) rec = item_at(it);
-            const u32 owner = rec.x & 0xFFu, q16 = (rec.x >> 8) & 0xFFFFu;
-            const bool item_mc = is_pb && (q16 & 0x6000u);
-            u32 r[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = s_acc[i * ITEMS_CAP + it];
-            if (qf & HVQ_TQ_SERIAL) {
-                /* a tile whose pair list exceeds what the picture reserves (pathological streams): the item walks its bases */
-                const bool ser = (second ? np[TPW - 1] : np[0]) == 0u;          /* a serial tile has no pair list */
-                const u32 kind = (q16 >> 8) & ((is_pb || p != 0) ? 0xFu : 0xFFu);   /* I-picture luma: the kind is the whole byte (h4m:1093) */
-                const u32 n = item_mc ? (kind & 0xFu) - 1u : kind;
-                if (ser) {
-                    const GLB u32 *bases = pool + rec.y + (item_mc ? 2u : 0u);
-                    i32 origin = 0;
-                    u32 roff = 0;
-                    if (item_mc) {
-                        i32 ox, oy;
-                        block_coords(b0 + (second ? HVQ_TILE_BLOCKS : 0u) + owner, hb, rhb, ox, oy);
-                        const u32 mv = mvs[(oy >> (1 - hs)) * mcb_w + (ox >> (1 - ws))];
-                        const i32 rx = (i32)(int16_t)(mv & 0xFFFF), ry = (i32)(int16_t)(mv >> 16);
-                        origin = landscape ? rx / 2 + (ry / 2 - 16) * lw - 32 : rx / 2 + (ry / 2 - 32) * lw - 16;
-                        roff = ((q16 >> 13) & 3u) == 1u ? ref0_off : ref1_off;
-                    }
-                    for (u32 k = 0; k < n; ++k) {
-                        const u32 d = bases[k];
-                        u32 e[16], lo, hi;
-                        if (!item_mc) gather_nest(d, landscape, s_nest, e, lo, hi);
-                        else gather_window(d, landscape, ring + roff, origin, lw, slot, e, lo, hi);
-                        const u32 g = basis_gain(d, lo, hi);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) r[i] += g * e[i];
-                    }
-                }
-            }
-            u32 *so = &s_out[second ? TPW - 1 : 0][0][owner];
-            Blk o;
-            if (item_mc) {
-                Blk m;                                       /* the owner left the MC block in the tile */
-#pragma unroll
-                for (int y = 0; y < 4; ++y) m.r[y] = so[y * HVQ_WG];
-                u32 p0 = (u32)(i32)(int16_t)(rec.y & 0xFFFFu) << unk, p1 = (u32)(i32)(int16_t)(rec.y >> 16);
-                if (rec.x & HVQ_IQ_WIDE) { p0 = pool[rec.y]; p1 = pool[rec.y + 1]; }              /* rare: scalars beyond 16 bits, serial tiles */
-                o = predi_finish(r, m, p0, p1, unk);
-            } else {
-                o = intra_finish(r, (i32)(q16 & 0xFF), unk);
-            }
-#pragma unroll
-            for (int y = 0; y < 4; ++y) so[y * HVQ_WG] = o.r[y];
-        }
-        STAMP(9, 1);
-    }
-    __syncthreads();                                                           /* barrier 3: tiles complete in LDS */
-    STAMP(10, 0);
-
-    /* ---- phase C: tiles -> HBM ---- */
-    if (HVQ_ABL == 15 && s_out[0][0][tid] != 0x12345678u) return;             /* timing experiment: no stores */
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int h = 0; h < TPW; ++h) {
-        if ((hb & 3) == 0) {
-            /* lane (g, r): sample row r of blocks 4g..4g+3 = 16 contiguous bytes of the plane */
-            const int g = wave * 16 + (lane & 15), rr = lane >> 4;
-            const u32 gb = b0 + (u32)(h * HVQ_TILE_BLOCKS) + 4u * (u32)g;
-            if (gb < nblocks) {
-                i32 gx, gy;
-                block_coords(gb, hb, rhb, gx, gy);
-                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 v = *(const u32x4 *)&s_out[h][rr][4 * g];
-                /* B pictures are never read again by a later picture: streaming stores keep them from displacing the anchors
-                 * in L2 (+1 % on MC-dominated streams, neutral on the dense one; profiles/r01j_ab_nontemporal.txt) */
-                if (HVQ_ABL == 16) *(GLB u32x4 *)(plane + (size_t)(tid * 16)) = v;
-                else if (HVQ_ABL == 17 ? true : HVQ_ABL == 18 ? false : pic_kind == HVQ_PIC_B) __builtin_nontemporal_store(v, (GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4));   /* 17 / 18: all / no stores non-temporal */
-                else *(GLB u32x4 *)(plane + (size_t)(gy * 4 + rr) * pw + gx * 4) = v;
-            }
-        } else if (b0 + (u32)(h * HVQ_TILE_BLOCKS + tid) < nblocks) {
-            i32 sx, sy;                                      /* recomputed: keeping bx, by alive through phase B costs registers */
-            block_coords(b0 + (u32)(h * HVQ_TILE_BLOCKS + tid), hb, rhb, sx, sy);
-            GLB uint8_t *dst = plane + (size_t)(sy * 4) * pw + sx * 4;
-#pragma unroll
-            for (int y = 0; y < 4; ++y) *(GLB u32 *)(dst + (size_t)y * pw) = s_out[h][y][tid];
-        }
-    }
-    STAMP(12, 0);
-    STAMP(13, 1);
-}
-
-template <int ITEMS_CAP, int TPW>
-static void launch_recon(const HvqJob *jobs_dev, const HvqTileQ *tq_all, uint32_t nslots, uint32_t max_wgs, hipStream_t stream)
-{
-    const dim3 grid = nslots >= 8 ? dim3(8, max_wgs, nslots / 8) : dim3(nslots, max_wgs, 1);     /* nslots is a multiple of 8 then */
-#ifdef HVQ_STAMPS
-    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, tq_all, g_stamps);
-#else
-    hipLaunchKernelGGL((hvq_recon_kernel<ITEMS_CAP, TPW>), grid, dim3(HVQ_WG), 0, stream, jobs_dev, tq_all);
-#endif
-}
-
-/* jobs_dev: the launch's picture slots, one job each (count a multiple of 8 when there are at least 8 pictures; padding: total_tiles 0);
- * tiles_per_wg: 1 or 2; max_wgs: the most workgroups of any picture of the launch at that setting;
- * items_cap: the most items of any workgroup of the launch (it selects the instantiation with the next larger accumulator array) */
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
-                                       uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream)
-{
-    if (nslots == 0 || max_wgs == 0) return hipSuccess;
-    const HvqTileQ *tq_all = (const HvqTileQ *)tq_buffer;       /* the buffer every job's `tq` points into (8-byte aligned offsets) */
-    if (tiles_per_wg >= 2) {
-        if (items_cap <= 32) launch_recon<32, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 64) launch_recon<64, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 96) launch_recon<96, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 128) launch_recon<128, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 192) launch_recon<192, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 256) launch_recon<256, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 384) launch_recon<384, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else launch_recon<512, 2>(jobs_dev, tq_all, nslots, max_wgs, stream);
-    } else {
-        if (items_cap <= 32) launch_recon<32, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 64) launch_recon<64, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 96) launch_recon<96, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 128) launch_recon<128, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else if (items_cap <= 192) launch_recon<192, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
-        else launch_recon<256, 1>(jobs_dev, tq_all, nslots, max_wgs, stream);
-    }
-    return hipGetLastError();
-}
-
 
 /* ------------------------------------------------------------------------------------------------------
  * Reconstruction WITHOUT a queue-build pass (round 4; front end rewritten in round 5): the workgroup derives its block records,
@@ -1322,6 +563,7 @@ __device__ __forceinline__ void inl_classify(u32 T, bool valid, u32 &cls, u32 &n
 }
 
 template <int N> struct InlCtx { static constexpr int value = N; };
+#define HVQ_W64(i) ((uint64_t)cw[i] | ((uint64_t)cw[(i) + 1] << 32))
 
 template <int ITEMS_CAP, int TPW>
 __global__ __launch_bounds__(HVQ_WG, HVQ_MIN_WAVES)
@@ -1680,6 +922,11 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
             for (int y = 0; y < 4; ++y) s_out[h][y][tid] = o.r[y];
         }
         STAMP(7, 0);                                                           /* phase A */
+        /* the nest and the pool range were staged by LDS-DMA (global_load_lds), which completes on the VECTOR-memory counter: s_barrier
+         * implies no vmcnt wait and __syncthreads() emits lgkmcnt(0) only, so the issuing waves wait explicitly before they signal the
+         * barrier after which every wave reads s_nest / s_pool.  Free: the wave's own loads (issued before the DMA, completed in order)
+         * were waited for long ago -- the ISA had an incidental vmcnt(0) behind trip 2; this one does not depend on the scheduler. */
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                    /* vmcnt(0), gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait */
         __syncthreads();                                                       /* barrier 1: queues, zeroed accumulators, staged pool and nest */
         STAMP(8, 0);
         /* literal blocks (h4m:543-549): the owner copies its 16 samples from the staged pool (complete only now: other waves staged parts of it) */

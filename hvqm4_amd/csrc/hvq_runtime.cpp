@@ -49,10 +49,6 @@ extern "C" hipError_t hvq_launch_nest_commit(const uint64_t *pairs_dev, uint32_t
 extern "C" uint32_t hvq_gparse_scratch_bytes(uint32_t total_blocks, uint32_t total_runs, uint32_t nmb);
 extern "C" int hvq_parse_occupancy(uint32_t rowbuf_stride);
 
-extern "C" hipError_t hvq_launch_recon(const HvqJob *jobs_dev, const void *tq_buffer, uint32_t nslots, uint32_t max_wgs,
-                                       uint32_t tiles_per_wg, uint32_t items_cap, hipStream_t stream);
-extern "C" hipError_t hvq_launch_tileq(const HvqJob *jobs_dev, uint32_t first_job, uint32_t njobs, uint32_t max_tiles, uint32_t splits,
-                                       unsigned long long *qbytes_dev, hipStream_t stream);
 extern "C" hipError_t hvq_launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_t max_wgs, uint32_t tiles_per_wg,
                                               uint32_t items_cap, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream);
 extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t items_cap);
@@ -60,7 +56,6 @@ extern "C" uint32_t hvq_recon_inline_dyn_lds(uint32_t pair_cap, uint32_t pool_ca
 extern "C" hipError_t hvq_launch_gather(const uint64_t *src_dev, uint8_t *dst_dev, uint32_t n, uint32_t pic_bytes, hipStream_t stream);
 extern "C" hipError_t hvq_launch_upload(const void *src_pinned, void *dst_dev, size_t bytes, hipStream_t stream);
 extern "C" hipError_t hvq_launch_selfref(const HvqJob *job_dev, const uint8_t *side, uint8_t *dst, hipStream_t stream);
-extern "C" hipError_t hvq_upload_tables(void);
 extern "C" hipError_t hvq_launch_table_div(uint32_t *out_dev, hipStream_t stream);
 
 #ifdef HVQ_STAMPS
@@ -185,19 +180,8 @@ struct Launch {
     uint32_t max_wg[2], wgs[2];        /* the same for one / two tiles per workgroup (chosen at flush_end, when the queues are known) */
     uint32_t tpw;
     uint32_t items_cap;                /* LDS sizing of the launch: max over its pictures */
-    bool inline_queues;                /* hvq_recon_inline_kernel: the workgroups derive their queues themselves (no hvq_tileq_kernel pass) */
     uint32_t pair_cap, pool_cap;       /* its dynamic LDS: pair list entries, staged pool dwords */
 };
-
-/* HVQM4_AMD_TILE_QUEUES=1 (read when a context is created): round 3's two-pass reconstruction -- hvq_tileq_kernel builds tile
- * queues in HBM once per picture, hvq_recon_kernel reads them.  Default: hvq_recon_inline_kernel derives the queues inside the
- * workgroup (round 4: the queue-build pass cost 0.70 ms per 2048 dense pictures beside 1.02 ms of reconstruction,
- * profiles/r04a_*). */
-static bool env_tile_queues()
-{
-    const char *e = getenv("HVQM4_AMD_TILE_QUEUES");
-    return e && atoi(e) > 0;
-}
 
 /* a P picture with future-referencing macroblocks, behind the launch of its level: previous content into the destination slot
  * (unless it is there already), then the raster-order walk (hvq_selfref_kernel) from the side buffer */
@@ -214,7 +198,6 @@ struct SelfRef {
 
 struct HvqContext {
     int device = 0;
-    bool tile_queues = false;          /* two-pass reconstruction over tile queues in HBM (HVQM4_AMD_TILE_QUEUES=1) */
     hipStream_t stream = nullptr;      /* every launch of a batch: its dependency levels in order */
     hipStream_t qstream[4] = { nullptr, nullptr, nullptr, nullptr };   /* launch queues 1..3 (created on first use; queue 0 is `stream`), see build_tiles */
     hipEvent_t ev_fork = nullptr, ev_join[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -252,10 +235,8 @@ struct HvqContext {
     /* last flushed batch (kept resident for hvq_replay) */
     HvqJob *jobs_dev = nullptr;        /* one job per launch slot, in launch order (padding slots: total_tiles = 0) */
     size_t jobs_cap = 0;
-    uint8_t *tq_dev = nullptr;         /* tile queues of the resident batch (hvq_tileq_kernel), read by every (re)play */
+    uint8_t *tq_dev = nullptr;         /* self-referencing P pictures: the pool offset of every block (written by the level's launch, read by hvq_selfref_kernel) */
     size_t tq_cap = 0;
-    uint32_t tq_njobs = 0, tq_max_tiles = 0;   /* the queue build of the resident batch: job table entries, most tiles of a picture */
-    unsigned long long *qbytes_dev = nullptr;  /* bytes of queue data one reconstruction pass reads (summed by the queue build) */
     uint8_t *rb_dev = nullptr;         /* bulk readback: pictures gathered into one buffer, then few large copies */
     size_t rb_cap = 0;
     uint64_t *rb_tab_dev = nullptr, *rb_tab_host = nullptr;   /* their slot addresses (device table, pinned staging) */
@@ -453,9 +434,7 @@ HVQ_EXPORT int hvq_context_create(int device, HvqContext **out)
     HIPCHK(hipSetDevice(device));
     HvqContext *c = new HvqContext();
     c->device = device;
-    c->tile_queues = env_tile_queues();
     struct Guard { HvqContext *c; ~Guard() { if (c) hvq_context_destroy(c); } } guard{ c };     /* a failing step below frees what exists */
-    HIPCHK(hvq_upload_tables());
     {   /* The launch stream at the highest stream priority: the runtime deals a process's streams to four hardware queues in the order of
          * their creation, per priority level -- with a copy and a read-back stream per context, the launch streams of two contexts (two
          * players of one process, bench.py's two-context streaming leg) landed on ONE hardware queue and their kernels ran one after the
@@ -534,7 +513,6 @@ HVQ_EXPORT void hvq_context_destroy(HvqContext *c)
     if (c->ev_read) (void)hipEventDestroy(c->ev_read);
     if (c->jobs_dev) (void)hipFree(c->jobs_dev);
     if (c->tq_dev) (void)hipFree(c->tq_dev);
-    if (c->qbytes_dev) (void)hipFree(c->qbytes_dev);
     if (c->selfref_dev) (void)hipFree(c->selfref_dev);
     if (c->rb_dev) (void)hipFree(c->rb_dev);
     if (c->rb_tab_dev) (void)hipFree(c->rb_tab_dev);
@@ -842,6 +820,8 @@ static int submit_device(HvqContext *c, int n, const int *streams, const int *fr
         arena_pics.resize((size_t)n);
         size_t prev_end = 0;
         for (int i = 0; i < n; ++i) {
+            if (lens[i] > c->resv_bytes)               /* before the span is computed: lens[i] + 32 must not wrap */
+                return fail(HVQ_E_ARG, "picture %d: %zu bytes exceed the reservation (%zu)", i, lens[i], c->resv_bytes);
             const size_t span = align_up(lens[i] + 32, 256);
             if ((arena_offs[i] & 255u) || arena_offs[i] < prev_end || arena_offs[i] > c->resv_bytes || span > c->resv_bytes - arena_offs[i])
                 return fail(HVQ_E_ARG, "picture %d: offset %zu (+ %zu bytes with its padding) is not a 256-byte aligned, ascending range of the reservation", i, arena_offs[i], span);
@@ -1002,10 +982,9 @@ static int submit_device(HvqContext *c, int n, const int *streams, const int *fr
         }
         return HVQ_OK;
     }
-    /* HVQM4_AMD_ASYNC_SUBMIT=1: the plain call defers its copy too, as round 4 did by default while a batch was in flight (its
-     * callers then had to keep their buffers until the next flush_begin: a silent change of the buffer contract, advisor finding) */
-    static const int async_env = getenv("HVQM4_AMD_ASYNC_SUBMIT") ? atoi(getenv("HVQM4_AMD_ASYNC_SUBMIT")) : 0;
-    if (mode == SUBMIT_COPY_ASYNC || (async_env > 0 && c->fl_active)) {
+    /* only the _async entry point defers its copy (rounds 4-5 had an environment switch that made the plain call defer too: a caller
+     * of the plain call may free its buffers on return, so the switch was a use-after-free waiting to happen; removed in round 6) */
+    if (mode == SUBMIT_COPY_ASYNC) {
         c->copy_rc = HVQ_OK;
         c->copy_err.clear();
         c->copy_active = true;
@@ -1266,7 +1245,13 @@ static int device_parse_finish(HvqContext *c)
      * reference sums for as long as the stream says (h4m:654-677), and so does the HOST parser since round 5 -- bounded by the bits
      * the picture has left.  Such a picture (nothing an encoder writes; rounds 3-4 refused it) is parsed once more, here, from its
      * bitstream in the pinned arena; its blob replaces the device parser's, an I picture's nest is put where the stream's later
-     * pictures look for it.  What even the host parser cannot end (a one-leaf tree outside the window) stays refused. */
+     * pictures look for it.  What even the host parser cannot end (a one-leaf tree outside the window) stays refused.
+     * Bounded per batch (HVQ_REDO_MAX pictures, HVQ_REDO_BYTES of blobs): the re-parse runs serially on the caller's thread between a
+     * batch's parse results and its first launch, and a crafted input whose pictures are ALL capped must not turn a 4 ms flush into
+     * seconds for every stream of the batch -- beyond the bound a capped picture is refused as rounds 3-4 refused all of them. */
+    constexpr uint32_t HVQ_REDO_MAX = 32;
+    constexpr size_t HVQ_REDO_BYTES = (size_t)32 << 20;
+    uint32_t n_reparsed = 0;
     c->rp_host.clear();
     for (size_t k = 0; k < idx.size(); ++k) {
         Pending &p = c->fl_pending[idx[k]];
@@ -1276,7 +1261,8 @@ static int device_parse_finish(HvqContext *c)
         p.flags = res[k].flags;
         p.pool_dwords = res[k].pool_dwords;
         p.redo = false;
-        if (!p.status && (p.flags & HVQ_F_CAPPED) && !p.dropped && raw_len) {
+        if (!p.status && (p.flags & HVQ_F_CAPPED) && !p.dropped && raw_len && n_reparsed < HVQ_REDO_MAX && c->rp_host.size() < HVQ_REDO_BYTES) {
+            ++n_reparsed;
             Stream &s = c->streams[(size_t)p.stream];
             const size_t bound = hvq_parser_blob_bound(s.parser), off = align_up(c->rp_host.size(), 256);
             c->rp_host.resize(off + bound + 2048);
@@ -1314,33 +1300,9 @@ static int device_parse_finish(HvqContext *c)
     return HVQ_OK;
 }
 
-/* The queue build of the resident batch (hvq_tileq_kernel).  HVQM4_AMD_TILEQ_SPLITS=n: n workgroups per picture, each walking
- * its share of the picture's tile pairs (0: one workgroup per pair of tiles); by default a batch of few pictures gets one
- * workgroup per tile pair (latency of a lone picture) and a large batch a few workgroups per picture. */
-static uint32_t tileq_splits(uint32_t njobs, uint32_t max_tiles)
-{
-    static const int forced = getenv("HVQM4_AMD_TILEQ_SPLITS") ? atoi(getenv("HVQM4_AMD_TILEQ_SPLITS")) : -1;
-    if (forced >= 0) return (uint32_t)forced;
-    (void)njobs; (void)max_tiles;
-    return 0u;
-}
-
-static int run_queue_build(HvqContext *c, bool count_bytes)
-{
-    if (!c->tq_njobs || !c->tile_queues) return HVQ_OK;
-    if (count_bytes) {
-        if (!c->qbytes_dev) HIPCHK(hipMalloc((void **)&c->qbytes_dev, sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(c->qbytes_dev, 0, sizeof(unsigned long long), c->stream));
-    }
-    HIPCHK(hvq_launch_tileq(c->jobs_dev, 0, c->tq_njobs, c->tq_max_tiles, tileq_splits(c->tq_njobs, c->tq_max_tiles),
-                            count_bytes ? c->qbytes_dev : nullptr, c->stream));
-    return HVQ_OK;
-}
-
-/* enqueue all launches of the resident batch once, dependency level by dependency level, on the context's one launch stream.  (Rounds
- * 1-4 could deal the levels of even and odd streams to two HIP streams, HVQM4_AMD_QUEUES=2: it lost 7-9 % in every evidence line of
- * round 4 -- two grids of this kernel get in each other's way -- and was removed in round 5.) */
-/* the second launch queue forks from the main stream (everything queued there so far is done before its first launch) ... */
+/* The launches of the resident batch go out dependency level by dependency level, every launch on the queue build_tiles dealt its
+ * streams to (one queue, or two for large uniform batches: see there).
+ * The second launch queue forks from the main stream (everything queued there so far is done before its first launch) ... */
 static int queues_fork(HvqContext *c, bool *two)
 {
     int nq = 1;
@@ -1382,8 +1344,7 @@ static int run_launches(HvqContext *c)
 {
     for (auto &L : c->launches) {
         hipStream_t st = L.queue ? c->qstream[L.queue] : c->stream;
-        if (L.inline_queues) HIPCHK(hvq_launch_recon_inline(c->jobs_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, L.pool_cap, st));
-        else HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, st));
+        HIPCHK(hvq_launch_recon_inline(c->jobs_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, L.pool_cap, st));
         for (const SelfRef &sr : c->selfrefs) {
             if (sr.level != L.level || sr.queue != L.queue) continue;
             if (sr.old_host) HIPCHK(hipMemcpyAsync(sr.dst, sr.old_host, sr.pic_bytes, hipMemcpyHostToDevice, st));
@@ -1424,7 +1385,7 @@ static int build_tiles(HvqContext *c)
         }
         /* mixed picture sizes keep one queue: BASELINE config 4 (320x240 and 640x480 clips alternating, 25 levels) took 1762 us per step
          * with two queues against 1303 with one, however the streams were dealt (a launch's grid is as tall as its largest picture) */
-        nq = qenv >= 2 ? std::min(qenv, 4) : (qenv == 1 ? 1 : (c->max_queues >= 2 && nstreams >= 16 && uniform && !c->tile_queues ? 2 : 1));
+        nq = qenv >= 2 ? std::min(qenv, 4) : (qenv == 1 ? 1 : (c->max_queues >= 2 && nstreams >= 16 && uniform ? 2 : 1));
         /* streams to queues by WORK (tiles of their pictures in this batch), heaviest first to the lighter queue: clips of mixed sizes
          * (BASELINE config 4 alternates 320x240 and 640x480) dealt by parity put every large clip on one queue, and that chain then ran
          * alone for most of the step (1766 against 1295 us) */
@@ -1558,7 +1519,7 @@ HVQ_EXPORT int hvq_flush_next(HvqContext *c)
     if (!c) return fail(HVQ_E_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
     static const bool allow = !(getenv("HVQM4_AMD_FLUSH_NEXT") && atoi(getenv("HVQM4_AMD_FLUSH_NEXT")) == 0);
-    bool ahead = allow && c->fl_active && !c->pending.empty() && !c->tile_queues && !PS(c).fl_idx.empty();
+    bool ahead = allow && c->fl_active && !c->pending.empty() && !PS(c).fl_idx.empty();
     if (ahead) {
         for (auto &p : c->fl_pending) if (!p.dev) { ahead = false; break; }
         for (auto &p : c->pending) if (!p.dev) { ahead = false; break; }
@@ -1703,7 +1664,6 @@ static int flush_end(HvqContext *c)
     std::vector<char> has_tq(slots.size(), 0);
     std::vector<uint32_t> slot_of(c->fl_pending.size(), 0);
     size_t tq_bytes = 0, side_bytes = 0;
-    uint32_t max_tiles = 0;
     c->selfrefs.clear();
     HvqStats st{};
     for (size_t k = 0; k < slots.size(); ++k) {
@@ -1739,46 +1699,25 @@ static int flush_end(HvqContext *c)
         j.pool_dwords = (p.dev && !p.redo) ? p.pool_dwords : hd->pool_dwords;
         j.total_tiles = p.dropped ? 0u : hd->tile_first[3];          /* 0: the tile records of this picture become padding entries */
         if (p.dropped) continue;
-        {   /* the picture's tile queues (HVQM4_AMD_TILE_QUEUES=1): per tile a record, a literal list, and item and pair lists sized
-             * for its fullest tile.  Without them only a self-referencing P picture needs a section: its blocks' pool offsets */
+        if (p.kind == HVQ_PIC_P && (hd->flags & HVQ_F_SELF_REF)) {
+            /* a self-referencing P picture: the data-parallel pass writes a side buffer and leaves every block's pool offset in a
+             * section of `tq_dev`; the walk behind this level's launch (hvq_selfref_kernel) merges the side buffer into the slot */
             const uint32_t nt = hd->tile_first[3];
-            const bool tqm = c->tile_queues;
-            /* at least one entry each: the reconstruction kernel requests the first round of every list before it knows the counts */
-            /* HVQM4_AMD_PAIR_CAP (tests): a smaller pair list, so that ordinary clips reach the tiles-with-too-many-pairs path
-             * (HVQ_TQ_SERIAL: no pair list, the items walk their bases) */
-            static const uint32_t pair_cap = getenv("HVQM4_AMD_PAIR_CAP") ? std::min(HVQ_PAIR_CAP_MAX, (uint32_t)std::max(1, atoi(getenv("HVQM4_AMD_PAIR_CAP")))) : HVQ_PAIR_CAP_MAX;
-            const uint32_t cap_items = std::max(1u, std::min(256u, (uint32_t)p.max_items)), cap_pairs = std::max(1u, std::min(pair_cap, p.max_pairs));
-            const bool selfref = p.kind == HVQ_PIC_P && (hd->flags & HVQ_F_SELF_REF);
-            const size_t recs = tqm ? align_up((size_t)nt * sizeof(HvqTileQ), 16) : 16, lits = recs + (tqm ? (size_t)nt * HVQ_TILE_BLOCKS * 8 : 0),
-                         items = lits + (tqm ? (size_t)nt * HVQ_TILE_BLOCKS * 4 : 0),
-                         pairs = items + (tqm ? (size_t)nt * cap_items * 8 : 0), offs = pairs + (tqm ? (size_t)nt * cap_pairs * 8 : 0),
-                         end = offs + (selfref ? (size_t)nt * HVQ_TILE_BLOCKS * 4 : 0);
-            if (tqm || selfref) {
-                tq_bytes = align_up(tq_bytes, 256);
-                tq_off[k] = tq_bytes;
-                has_tq[k] = 1;
-            }
-            if (selfref) {
-                /* the data-parallel pass writes a side buffer; the walk behind this level's launch merges it into the slot */
-                j.q_offs_off = (uint32_t)offs;
-                SelfRef sr{};
-                sr.level = p.level; sr.job = (uint32_t)k;
-                sr.old_host = p.host_old;
-                sr.old_dev = (p.host_old || p.old_slot == p.dst) ? nullptr : s.slot_ptr(p.old_slot);     /* -1: the zero slot */
-                sr.dst = s.slot_ptr(p.dst);
-                side_bytes = align_up(side_bytes, 256);
-                sr.side_off = side_bytes;
-                sr.pic_bytes = s.pic_bytes;
-                side_bytes += s.slot_bytes;
-                c->selfrefs.push_back(sr);
-            }
-            if (end >= ((size_t)1 << 32)) return flush_abandon(c, fail(HVQ_E_OVERFLOW, "stream %d picture %d: tile queues exceed 4 GiB", p.stream, p.ordinal));
-            if (tqm) {
-                j.q_recs_off = (uint32_t)recs; j.q_lits_off = (uint32_t)lits; j.q_items_off = (uint32_t)items; j.q_pairs_off = (uint32_t)pairs;
-                j.q_caps = cap_items | (cap_pairs << 16);
-            }
-            if (tqm || selfref) tq_bytes += end;
-            max_tiles = std::max(max_tiles, nt);
+            tq_bytes = align_up(tq_bytes, 256);
+            tq_off[k] = tq_bytes;
+            has_tq[k] = 1;
+            j.q_offs_off = 16;
+            tq_bytes += 16 + (size_t)nt * HVQ_TILE_BLOCKS * 4;
+            SelfRef sr{};
+            sr.level = p.level; sr.job = (uint32_t)k;
+            sr.old_host = p.host_old;
+            sr.old_dev = (p.host_old || p.old_slot == p.dst) ? nullptr : s.slot_ptr(p.old_slot);     /* -1: the zero slot */
+            sr.dst = s.slot_ptr(p.dst);
+            side_bytes = align_up(side_bytes, 256);
+            sr.side_off = side_bytes;
+            sr.pic_bytes = s.pic_bytes;
+            side_bytes += s.slot_bytes;
+            c->selfrefs.push_back(sr);
         }
         for (int k = 0; k < 3; ++k) {
             HvqPlaneRec &r = j.plane[k];
@@ -1820,16 +1759,8 @@ static int flush_end(HvqContext *c)
     for (size_t li = 0; li < c->fl_launches.size(); ++li) {
         Launch &L = c->fl_launches[li];
         const uint32_t mi = lmi[li], mp = lmp[li];
-        /* Two tiles per workgroup: twice the loads in flight per wave for the same chain of round trips -- what a latency-bound
-         * kernel is short of (profiles/r03_ablation.txt).  Since the tile queues left the kernel's LDS (11.6 KB per tile) the pooled
-         * accumulators of two tiles cost the AOT-dense stream no occupancy either (dense +3.7 %, flat +5 %); one tile only when the
-         * two tiles' items would need more than 192 accumulator rows (LDS: fewer than 7 workgroups per CU). */
         static const int force_tpw = getenv("HVQM4_AMD_TILES_PER_WG") ? atoi(getenv("HVQM4_AMD_TILES_PER_WG")) : 0;
-        L.inline_queues = !c->tile_queues;
-        if (!L.inline_queues) {
-            L.tpw = force_tpw ? (force_tpw >= 2 ? 2u : 1u) : (2u * mi <= 192u ? 2u : 1u);
-            L.items_cap = std::min(256u * L.tpw, std::max(32u, L.tpw * mi));
-        } else {
+        {
             /* hvq_recon_inline_kernel keeps its item queue, pair list and the tile range of the pool in LDS: accumulator rows
              * for the fullest tile (x tiles per workgroup), a pair list for its pairs, the staged pool for its bases, scalars and a
              * few literal blocks (what does not fit is read from HBM; more pairs than the list holds: the items walk their bases).
@@ -1894,15 +1825,13 @@ static int flush_end(HvqContext *c)
         }
     /* stream-ordered after whatever still reads the previous table */
     { int rcu = staged_upload(c, c->fl_arena_id, 2, c->jobs_dev, jobs.data(), jobs.size() * sizeof(HvqJob)); if (rcu) return flush_abandon(c, rcu); }
-    /* 2b. tile queues: once per picture, from the descriptors (type bytes, vectors, basis words) that are now all in HBM */
-    c->tq_njobs = (uint32_t)jobs.size(); c->tq_max_tiles = max_tiles;
-    { int rcq = run_queue_build(c, true); if (rcq) return flush_abandon(c, rcq); }
     /* 3. one launch per level */
     {
         bool two = false;
         int rc = queues_fork(c, &two);
         if (!rc) rc = run_launches(c);
-        if (!rc) rc = queues_join(c, two);
+        /* joined also when a launch failed: whatever the other queues hold is ordered in front of everything the main stream gets next */
+        { const int rcj = queues_join(c, two); if (!rc) rc = rcj; }
         if (rc) return flush_abandon(c, rc);
     }
     if (!c->fl_nest_pairs.empty()) {   /* the last I picture's nest of every GPU-parsed stream must outlive this batch's buffers */
@@ -1942,21 +1871,24 @@ HVQ_EXPORT int hvq_sync(HvqContext *c)
     return HVQ_OK;
 }
 
-/* `reps` passes over the resident batch: what = 0 the reconstruction launches, 1 queue build + launches, 2 queue build only.
+/* `reps` passes over the resident batch.  joined = true: every pass forks and joins the launch queues exactly as a flush does
+ * (flush_end: queues_fork, run_launches, queues_join) -- the product's step, pass r + 1 starts when BOTH queues have finished pass r.
+ * joined = false: the queues fork once and join once around all passes (inside a queue pass r + 1 follows pass r in stream order, and
+ * the queues hold different streams' pictures): a queue that is ahead runs into the next pass, which hides the queues' imbalance and
+ * one join per step -- measured beside the joined form, never the headline.
  * (Round 5 measured a HIP graph of the pass for small batches -- one GPU's share of BASELINE config 4, 128 pictures in 7 launches --
- * as the round-4 review had asked: 92.4 us per step against 87.2 with plain launches, profiles/r05_recon_steps.txt.  The launches are
- * a dependency chain, each as long as a workgroup's lifetime; there is no launch overhead for a graph to remove.  Not kept.) */
-static int replay_passes(HvqContext *c, int what, int reps)
+ * 92.4 us per step against 87.2 with plain launches, profiles/r05_recon_steps.txt.  The launches are a dependency chain, each as long as
+ * a workgroup's lifetime; there is no launch overhead for a graph to remove.  Not kept.) */
+static int replay_passes(HvqContext *c, bool joined, int reps)
 {
-    /* the two launch queues fork once and join once: inside a queue pass r + 1 follows pass r in stream order, and the queues hold
-     * different streams' pictures */
     bool two = false;
-    { int rc = queues_fork(c, &two); if (rc) return rc; }
+    if (!joined) { int rc = queues_fork(c, &two); if (rc) return rc; }
     for (int r = 0; r < reps; ++r) {
-        if (what != 0) { int rc = run_queue_build(c, false); if (rc) return rc; }
-        if (what != 2) { int rc = run_launches(c); if (rc) return rc; }
+        if (joined) { int rc = queues_fork(c, &two); if (rc) return rc; }
+        { int rc = run_launches(c); if (rc) return rc; }
+        if (joined) { int rc = queues_join(c, two); if (rc) return rc; }
     }
-    return queues_join(c, two);
+    return joined ? HVQ_OK : queues_join(c, two);
 }
 
 HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
@@ -1969,7 +1901,7 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
     if (!c->pending.empty()) return fail(HVQ_E_STATE, "pictures queued since the last flush");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    { int rc = replay_passes(c, 0, reps); if (rc) return rc; }
+    { int rc = replay_passes(c, false, reps); if (rc) return rc; }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0;
@@ -1978,23 +1910,19 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
 #ifdef HVQ_STAMPS
     if (getenv("HVQM4_AMD_STAMPS")) {
         /* diagnostic build: one more pass with phase stamps, per-launch mean segment lengths on stderr */
-        static const char *seg_q[10] = { "job + queue records", "prologue loads issue + land", "phase A (MC rows, cheap kinds, literals)", "barrier 1",
-                                         "B1 pairs", "barrier 2 (item record in flight)", "B2 items", "barrier 3", "store issue", "stores land" };
-        static const int from_q[10] = { 0, 1, 2, 3, 4, 7, 8, 9, 10, 12 }, to_q[10] = { 1, 2, 3, 4, 7, 8, 9, 10, 12, 13 };
         static const char *seg_i[14] = { "job record (+ early barrier)", "trip 2 issue", "trip 2 lands", "classes, rows requested, scans", "slots, lists",
                                          "rows land", "phase A", "barrier 1", "pair phase (B1)", "barrier 2", "item phase (B2)", "barrier 3", "store issue", "stores land" };
         static const int from_i[14] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13 }, to_i[14] = { 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14 };
         for (auto &L : c->launches) {
-            const char **seg = L.inline_queues ? seg_i : seg_q;
-            const int *from = L.inline_queues ? from_i : from_q, *to = L.inline_queues ? to_i : to_q;
-            const int NS = L.inline_queues ? 14 : 10, LAST = L.inline_queues ? 14 : 13;
+            const char **seg = seg_i;
+            const int *from = from_i, *to = to_i;
+            const int NS = 14, LAST = 14;
             unsigned long long *d = nullptr;
             const size_t n = (size_t)L.ntiles * L.max_tiles * 64;
             HIPCHK(hipMalloc((void **)&d, n * 8));
             HIPCHK(hipMemsetAsync(d, 0, n * 8, c->stream));
             hvq_set_stamps(d);
-            if (L.inline_queues) HIPCHK(hvq_launch_recon_inline(c->jobs_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, L.pool_cap, c->stream));
-            else HIPCHK(hvq_launch_recon(c->jobs_dev + L.first_tile, c->tq_dev, L.ntiles, L.max_tiles, L.tpw, L.items_cap, c->stream));
+            HIPCHK(hvq_launch_recon_inline(c->jobs_dev + L.first_tile, L.ntiles, L.max_tiles, L.tpw, L.items_cap, L.pair_cap, L.pool_cap, c->stream));
             hvq_set_stamps(nullptr);
             std::vector<unsigned long long> h(n);
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -2018,8 +1946,10 @@ HVQ_EXPORT int hvq_replay(HvqContext *c, int reps, float *gpu_ms)
     return HVQ_OK;
 }
 
-/* hvq_replay with the per-picture queue build inside the repeated region: what = 0 reconstruction launches only (hvq_replay),
- * 1 queue build + reconstruction launches per repetition (what a new batch costs behind its parse), 2 queue build only */
+/* what = 1: `reps` passes, each forking and joining the launch queues as a flush does -- the reconstruction stage of the product,
+ * everything a batch of new pictures costs behind its parse (bench.py's timed step).  what = 0: hvq_replay (the queues run free over
+ * all passes).  what = 2: nothing (it timed the queue build of the two-pass variant, deleted in round 6; kept so that callers of
+ * rounds 3-5 still link): 0 ms. */
 HVQ_EXPORT int hvq_replay_stage(HvqContext *c, int reps, int what, float *gpu_ms)
 {
     if (!c || reps < 0 || what < 0 || what > 2) return fail(HVQ_E_ARG, "bad arguments");
@@ -2029,9 +1959,10 @@ HVQ_EXPORT int hvq_replay_stage(HvqContext *c, int reps, int what, float *gpu_ms
     if (!c->selfrefs.empty())
         return fail(HVQ_E_STATE, "the resident batch holds self-referencing P pictures: their previous buffer content is gone after the first pass");
     if (!c->pending.empty()) return fail(HVQ_E_STATE, "pictures queued since the last flush");
+    if (what == 2) { if (gpu_ms) *gpu_ms = 0.f; return HVQ_OK; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    { int rc = replay_passes(c, what, reps); if (rc) return rc; }
+    { int rc = replay_passes(c, true, reps); if (rc) return rc; }
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipEventSynchronize(c->ev1));
     float ms = 0;
@@ -2252,6 +2183,34 @@ HVQ_EXPORT int hvq_rgb_bench(HvqContext *c, int reps, float *gpu_ms, uint64_t *b
     return HVQ_OK;
 }
 
+/* Measurement helper: `reps` pinned-host -> device copies of `bytes` on the context's copy stream, timed with HIP events: the PCIe
+ * rate a batch's bitstream upload can reach on this box (the bound of streaming from host memory, whatever the kernels do). */
+HVQ_EXPORT int hvq_h2d_probe(HvqContext *c, size_t bytes, int reps, double *gb_per_s)
+{
+    if (!c || !bytes || reps < 1 || !gb_per_s) return fail(HVQ_E_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    void *h = nullptr, *d = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&d, bytes);
+    if (e == hipSuccess) { memset(h, 0x5a, bytes); e = hipEventCreate(&e0); }
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->copy_stream);   /* warm-up: mappings, clocks */
+    if (e == hipSuccess) e = hipEventRecord(e0, c->copy_stream);
+    for (int r = 0; r < reps && e == hipSuccess; ++r) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->copy_stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d) (void)hipFree(d);
+    if (h) (void)hipHostFree(h);
+    HIPCHK(e);
+    *gb_per_s = ms > 0 ? (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
+    return HVQ_OK;
+}
+
 /* self-test: out[0..15] = the kernels' divTable quotients 256 / d, out[16..271] = their mcdivTable quotients 4096 / d (h4m:265-273) */
 HVQ_EXPORT int hvq_debug_table_divisions(HvqContext *c, uint32_t *out)
 {
@@ -2274,13 +2233,6 @@ HVQ_EXPORT int hvq_get_stats(HvqContext *c, HvqStats *out)
     *out = c->stats;
     out->parse_seconds = c->parse_seconds;
     out->copy_bytes = c->copy_bytes.load(); out->copy_seconds = (double)c->copy_ns.load() * 1e-9;
-    if (c->qbytes_dev && c->stats.pictures) {      /* summed on the device by the batch's queue build */
-        unsigned long long q = 0;
-        HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipMemcpyAsync(&q, c->qbytes_dev, sizeof q, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        out->queue_bytes = q;
-    }
     return HVQ_OK;
 }
 

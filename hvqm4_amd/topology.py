@@ -6,8 +6,9 @@ socket interconnect.  Everything here reads sysfs only -- no HIP call, so it run
 sysfs root as a parameter, so the mapping is unit-tested on a CPU box against a fake tree (tests/test_topology.py).
 
   GPU ordinal -> PCI address : KFD topology (/sys/class/kfd/kfd/topology/nodes/N/properties: simd_count > 0 = a GPU, `domain`,
-                               `location_id` = bus << 8 | device << 3 | function), in node order = HIP's device order; the
-                               ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES index lists are applied in that order.
+                               `location_id` = bus << 8 | device << 3 | function), in node order = HIP's device order;
+                               ROCR_VISIBLE_DEVICES filters first (the ROCr layer), then HIP_VISIBLE_DEVICES if it is set, otherwise
+                               CUDA_VISIBLE_DEVICES (the HIP runtime reads one of the two, never both).
                                Fallback: /sys/class/drm/card*/device of vendor 0x1002, by card number.
   PCI address -> NUMA node   : /sys/bus/pci/devices/<address>/numa_node (-1: unknown)
   NUMA node   -> cores       : /sys/devices/system/node/node<N>/cpulist
@@ -69,15 +70,25 @@ def gpu_pci_addresses(sysfs: str = "/sys") -> list[str]:
 def visible_indices(n_gpus: int, env=os.environ) -> list[int]:
     """device ordinals the process sees, as indices into the unfiltered list (integer index lists only; UUID forms are ignored)"""
     idx = list(range(n_gpus))
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+
+    def apply(var: str) -> bool:
+        """filter by one variable; False when it is unset / empty (the next candidate is looked at)"""
+        nonlocal idx
         v = env.get(var)
         if v is None or v.strip() == "":
-            continue
+            return False
         try:
             sel = [int(x) for x in v.split(",") if x.strip() != ""]
         except ValueError:
-            continue
+            return True                                 # a UUID list: set, but not ours to interpret
         idx = [idx[i] for i in sel if 0 <= i < len(idx)]
+        return True
+
+    apply("ROCR_VISIBLE_DEVICES")
+    # the HIP runtime uses HIP_VISIBLE_DEVICES when it is set and CUDA_VISIBLE_DEVICES only otherwise: launchers that export both
+    # with the same list must not be filtered twice
+    if not apply("HIP_VISIBLE_DEVICES"):
+        apply("CUDA_VISIBLE_DEVICES")
     return idx
 
 
@@ -109,14 +120,39 @@ def rank_cores(local_rank: int, local_world: int, allowed: list[int], sysfs: str
     allowed = sorted(allowed)
     devices = list(range(local_world)) if devices is None else list(devices)
     nodes = [gpu_numa_node(d, sysfs, env) for d in devices]
+    aset = set(allowed)
+
+    def numa_slice(r: int):
+        """rank r's share of its GPU's node, None when the node is unknown, has no allowed core, or fewer cores than ranks"""
+        node = nodes[r] if r < len(nodes) else None
+        if node is None:
+            return None
+        cpus = [c for c in node_cpus(node, sysfs) if c in aset]
+        peers = [q for q in range(local_world) if q < len(nodes) and nodes[q] == node]
+        per = len(cpus) // len(peers) if peers else 0
+        if per < 1:
+            return None
+        k = peers.index(r)
+        return cpus[k * per:(k + 1) * per]
+
     mine = nodes[local_rank] if local_rank < len(nodes) else None
-    if mine is not None:
-        cpus = [c for c in node_cpus(mine, sysfs) if c in set(allowed)]
-        peers = [r for r in range(local_world) if r < len(nodes) and nodes[r] == mine]
-        if cpus and local_rank in peers:
-            per = len(cpus) // len(peers)
-            if per >= 1:
-                k = peers.index(local_rank)
-                return cpus[k * per:(k + 1) * per], mine, "numa"
-    per = max(1, len(allowed) // max(1, local_world))
-    return (allowed[local_rank * per:(local_rank + 1) * per] or allowed), mine, "linear"
+    got = numa_slice(local_rank)
+    if got:
+        return got, mine, "numa"
+    # linear fallback: an even slice of the cores NO NUMA-placed rank of this host has claimed (a mixed host -- some GPUs with a known
+    # node, some without -- must not put two ranks on the same cores), in the order of the ranks that fall back
+    claimed = set()
+    fallers = []
+    for r in range(local_world):
+        sl = numa_slice(r)
+        if sl:
+            claimed.update(sl)
+        else:
+            fallers.append(r)
+    free = [c for c in allowed if c not in claimed]
+    if not free:                       # every allowed core is some NUMA-placed rank's: overlap is unavoidable, take the plain even slice
+        per = max(1, len(allowed) // max(1, local_world))
+        return (allowed[local_rank * per:(local_rank + 1) * per] or allowed), mine, "linear"
+    per = max(1, len(free) // max(1, len(fallers)))
+    k = fallers.index(local_rank) if local_rank in fallers else 0
+    return (free[k * per:(k + 1) * per] or free), mine, "linear"

@@ -57,10 +57,9 @@ typedef struct HvqStats {
     uint32_t gpu_parse_retried; /* of those, pictures the flat parse path handed to the chain decoder (unusual section layout,
                                    capacities, overflow groups at the caps) -- same result, slower */
     uint32_t dropped;           /* pictures of the batch that were not reconstructed: rejected, or behind a rejected picture of their stream */
-    uint32_t launch_queues;     /* 1, or 2: a batch of 16 streams or more deals the levels of its even and of its odd streams to two HIP
-                                   streams (a hardware queue each) whose launches run side by side; HVQM4_AMD_QUEUES=1 / 2 forces either */
-    uint64_t queue_bytes;       /* tile-queue bytes (block records, literal / item / pair lists actually filled) one reconstruction pass
-                                   reads beside the blobs' payload pools: descriptor traffic, not credited in the roofline */
+    uint32_t launch_queues;     /* 1, or 2: a batch of 16 streams or more of one picture size deals its streams -- by work -- to two chains of
+                                   launches on two HIP streams (a hardware queue each) that run side by side; HVQM4_AMD_QUEUES=1 / 2 forces either */
+    uint64_t queue_bytes;       /* always 0 since round 6 (rounds 3-5: bytes of the two-pass variant's tile queues); kept for the layout */
     uint64_t copy_bytes;        /* hvq_submit_many_device / _async: bitstream bytes the library copied into its pinned arena, summed since
                                    the context was created (hvq_submit_many_arena copies nothing) */
     double   copy_seconds;      /* ... and the wall time its copy threads took over them: host_copy GB/s = copy_bytes / copy_seconds */
@@ -139,13 +138,13 @@ int  hvq_flush_end(HvqContext *ctx);
 int  hvq_flush_next(HvqContext *ctx);
 int  hvq_sync(HvqContext *ctx);
 
-/* Re-run the launches of the last flush `reps` times (descriptors already resident in HBM).
+/* Re-run the launches of the last flush `reps` times (descriptors already resident in HBM), the launch queues running free.
  * *gpu_ms = elapsed time between HIP events recorded on the launch stream around all reps. */
 int  hvq_replay(HvqContext *ctx, int reps, float *gpu_ms);
-/* What a NEW batch costs behind its parse, repeated `reps` times.  Default (hvq_recon_inline_kernel): the reconstruction launches and
- * nothing else -- the workgroups derive their queues from the parser's descriptors themselves, so what = 1 equals hvq_replay and
- * what = 2 is empty.  With HVQM4_AMD_TILE_QUEUES=1 (round 3's two-pass variant) the per-picture queue build (hvq_tileq_kernel) runs
- * inside the repeated region: what = 0 reconstruction launches only, 1 queue build + launches, 2 queue build only. */
+/* What a NEW batch costs behind its parse, repeated `reps` times: what = 1 -- every repetition forks and joins the launch queues
+ * exactly as a flush does (the reconstruction stage of the product; bench.py's timed step); what = 0 -- hvq_replay: the launch queues
+ * fork once and join once around all repetitions (a queue that is ahead runs into the next pass); what = 2 -- nothing, 0 ms (it timed
+ * the queue build of the two-pass variant, deleted in round 6). */
 int  hvq_replay_stage(HvqContext *ctx, int reps, int what, float *gpu_ms);
 
 /* Copy a still-resident picture (Y|U|V, pic_bytes) to host memory; synchronises. */
@@ -170,6 +169,10 @@ int  hvq_convert_yuv420_rgb(HvqContext *ctx, const void *yuv, int width, int hei
 /* Measurement helper: converts the newest resident picture of every open 4:2:0 stream in ONE launch, `reps`
  * times, timed with HIP events on the launch stream.  bytes_per_rep = 1.5 B/px read + 3 B/px written. */
 int  hvq_rgb_bench(HvqContext *ctx, int reps, float *gpu_ms, uint64_t *bytes_per_rep, uint32_t *pictures);
+
+/* Measurement helper: `reps` copies of `bytes` from pinned host memory to the device on the context's copy stream, HIP-event timed:
+ * the PCIe rate the upload of a batch's bitstreams can reach on this box (GB/s, 1e9). */
+int  hvq_h2d_probe(HvqContext *ctx, size_t bytes, int reps, double *gb_per_s);
 
 int  hvq_get_stats(HvqContext *ctx, HvqStats *out);
 /* self-test of the kernels' replacement for the reference's division tables (h4m:265-273): out[0..15] = 256 / d, out[16..271] = 4096 / d

@@ -8,7 +8,7 @@
  *
  * Parity pin: the reference ships no golden vectors, so this
  * oracle is pinned against outputs of the reference itself run in the build
- * container (oracle/_ref, tests/test_oracle_vs_ref.py) and against the committed
+ * container (oracle/_ref, tests/test_oracle.py) and against the committed
  * fixtures under tests/golden/ that were generated from it (tests/golden/make_golden.py).
  */
 #ifndef HVQ_ORACLE_H

@@ -65,7 +65,7 @@ MEDIUM = [
     ("nest_border1_320x240", SynthConfig(width=320, height=240, gop="IPB", seed=24, nest_overhang=1)),
     ("nest_border2_296x160", SynthConfig(width=296, height=160, gop="IPB", seed=25, nest_overhang=2)),
     # up to 14 bases per MC-residual block, nearly every block coded: tiles with more (item, basis) pairs than a pair list holds
-    # (1024) -- their items walk their bases themselves (HVQ_TQ_SERIAL)
+    # (1024) -- their items walk their bases themselves
     ("manybases320x240", SynthConfig(width=320, height=240, gop="IPB", seed=41, max_predi_bases=14, p_zero=0.02, p_proc1=0.0, literal_weight=0.1)),
     ("pselfref320x240", SynthConfig(width=320, height=240, gop="IPBBPBBP", seed=39, p_future_refs=True)),
 ]

@@ -93,3 +93,60 @@ def test_c4_clip_set_is_balanced_over_i_mod_n_shards():
             combos = {(c.width, c.version) for c in mine}
             assert combos == {(320, "1.3"), (320, "1.5"), (640, "1.3"), (640, "1.5")}, (n, r)
             assert sum(c.width == 320 for c in mine) * 2 == len(mine)
+
+
+def _fake_eight_gpu_host(root, allowed):
+    """a two-socket host with eight GPUs (four per NUMA node) whose cpulists are the cores this process may really run on, so that the
+    ranks' sched_setaffinity calls succeed on the test box"""
+    from tests.test_topology import _write
+    half = len(allowed) // 2
+    lists = [allowed[:half], allowed[half:]]
+    for n in range(2):
+        _write(root, f"devices/system/node/node{n}/cpulist", ",".join(str(c) for c in lists[n]) + "\n")
+        _write(root, f"class/kfd/kfd/topology/nodes/{n}/properties", "cpu_cores_count 32\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for g in range(8):
+        bus = 0x10 + g
+        _write(root, f"bus/pci/devices/0000:{bus:02x}:00.0/numa_node", f"{g // 4}\n")
+        _write(root, f"class/kfd/kfd/topology/nodes/{2 + g}/properties", f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\n")
+    return lists
+
+
+def _dry(tmp_path, workload):
+    allowed = sorted(os.sched_getaffinity(0))
+    lists = _fake_eight_gpu_host(str(tmp_path), allowed)
+    env = dict(os.environ, HVQM4_AMD_SYSFS=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "HVQM4_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--workload", workload],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), lists
+
+
+def test_eight_rank_dry_run_of_config_4_from_a_cold_start(tmp_path):
+    """`python bench.py --gpus 8 --workload c4 --dry-run`: eight real processes, gloo rendezvous, barriers and reduces, core slices
+    from a fake 8-GPU sysfs tree, clip i -> rank i mod 8 -- everything but the GPU work, so the first real SCALE run cannot die in
+    plumbing"""
+    line, lists = _dry(tmp_path, "c4")
+    assert line["dry_run"] and line["n_gpus"] == 8 and line["scaling"] == "strong" and len(line["ranks"]) == 8
+    seen = []
+    for r, rec in enumerate(line["ranks"]):
+        assert rec["rank"] == r and rec["device"] == r
+        assert [u["clip"] for u in rec["units"]] == list(range(r, 64, 8))
+        assert {(u["w"], u["version"]) for u in rec["units"]} == {(320, "1.3"), (320, "1.5"), (640, "1.3"), (640, "1.5")}
+        assert rec["numa_node"] == r // 4
+        if len(lists[r // 4]) >= 4:
+            assert rec["core_choice"] == "numa" and set(rec["cores"]) <= set(lists[r // 4])
+        seen += [u["clip"] for u in rec["units"]]
+    assert sorted(seen) == list(range(64))
+    assert line["pictures_per_step"] == 64 * 64
+    assert line["pixels_per_step"] == 32 * 64 * (320 * 240 + 640 * 480)
+
+
+def test_eight_rank_dry_run_of_config_5(tmp_path):
+    line, _lists = _dry(tmp_path, "c5")
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert line["pictures_per_step"] == 1024 * 16 and line["pixels_per_step"] == 1024 * 16 * 640 * 480
+    seeds = [s for rec in line["ranks"] for s in rec["units"]["clip_seeds"]]
+    assert len(set(seeds)) == 64                               # every rank decodes its own clips
+    assert [rec["units"]["first_global_stream"] for rec in line["ranks"]] == [128 * r for r in range(8)]

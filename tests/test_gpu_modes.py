@@ -27,7 +27,7 @@ def test_parity_suites_with_forced_tiles_per_workgroup(tiles):
 @pytest.mark.parametrize("cap", ["24", "200"])
 def test_parity_suites_with_tiles_beyond_the_pair_list(cap):
     """A tile with more (item, basis) pairs than the picture's pair list reserves (1024 at most) gets no pair list: its items walk
-    their bases themselves (HVQ_TQ_SERIAL) and carry the payload offset instead of the packed MC-residual scalars (HVQ_IQ_WIDE).
+    their bases themselves (the kernel's serial pair phase).
     No encoder-like stream reaches 1024 pairs in 256 blocks; with the list capped at 24 nearly every tile of the parity clips
     takes that path, at 200 the two kinds of tile meet inside one workgroup."""
     env = dict(os.environ, HVQM4_AMD_PAIR_CAP=cap)
@@ -50,20 +50,8 @@ def test_parity_suites_with_tiles_beyond_the_staged_pool(cap):
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("extra", [{}, {"HVQM4_AMD_PAIR_CAP": "24"}, {"HVQM4_AMD_TILES_PER_WG": "1"}], ids=["default", "pair_cap_24", "one_tile"])
-def test_parity_suites_with_the_two_pass_reconstruction(extra):
-    """HVQM4_AMD_TILE_QUEUES=1 keeps round 3's two-pass reconstruction (hvq_tileq_kernel builds tile queues in HBM,
-    hvq_recon_kernel reads them) selectable beside the default hvq_recon_inline_kernel: same pictures."""
-    env = dict(os.environ, HVQM4_AMD_TILE_QUEUES="1", **extra)
-    suites = ["tests/test_gpu_parity.py", "tests/test_gpu_batch.py"] + (["tests/test_gpu_gparse.py", "tests/test_gpu_configs.py"] if not extra else [])
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + suites,
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
-    assert " passed" in r.stdout
-
-
 def test_parity_suites_with_two_launch_queues_forced():
-    """A batch of 16 streams or more deals its launches to two queues (even / odd streams, hvq_runtime.cpp build_tiles); the parity
+    """A batch of 16 streams or more deals its streams -- by work -- to two launch queues (hvq_runtime.cpp build_tiles); the parity
     clips are single streams, so the parity, batch and configuration suites run once more with HVQM4_AMD_QUEUES=2: every batch split,
     self-referencing P pictures included (the randomized sweep has a two-queue mode of its own in tools/sweep.sh)."""
     env = dict(os.environ, HVQM4_AMD_QUEUES="2")

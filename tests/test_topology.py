@@ -83,3 +83,30 @@ def test_drm_fallback_when_kfd_topology_is_absent(tmp_path):
     _fake_host(root, [1, 0], cpus_per_node=4, kfd=False)
     assert topology.gpu_pci_addresses(root) == ["0000:10:00.0", "0000:11:00.0"]
     assert topology.gpu_numa_node(0, root, {}) == 1
+
+
+def test_hip_visible_devices_wins_over_cuda_visible_devices(tmp_path):
+    """launchers export both with the same list: the HIP runtime reads HIP_VISIBLE_DEVICES when it is set and CUDA_VISIBLE_DEVICES only
+    otherwise -- applying one after the other would index the filtered list a second time and lose every device"""
+    assert topology.visible_indices(8, {"HIP_VISIBLE_DEVICES": "4,5,6,7", "CUDA_VISIBLE_DEVICES": "4,5,6,7"}) == [4, 5, 6, 7]
+    assert topology.visible_indices(8, {"CUDA_VISIBLE_DEVICES": "6,7"}) == [6, 7]
+    assert topology.visible_indices(8, {"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "1"}) == [1]
+    # ROCR filters first (the layer below), then HIP indexes what is left
+    assert topology.visible_indices(8, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "1,3", "CUDA_VISIBLE_DEVICES": "0"}) == [5, 7]
+    root = str(tmp_path)
+    _fake_host(root, [0, 0, 0, 0, 1, 1, 1, 1], cpus_per_node=8)
+    env = {"HIP_VISIBLE_DEVICES": "4,5,6,7", "CUDA_VISIBLE_DEVICES": "4,5,6,7"}
+    cores, node, how = topology.rank_cores(0, 4, list(range(16)), root, env)
+    assert (node, how) == (1, "numa") and cores == [8, 9]
+
+
+def test_linear_fallback_avoids_the_cores_of_numa_placed_ranks(tmp_path):
+    """a mixed host: GPUs 0 and 1 have a known node, GPU 2's numa_node says -1 -- its rank takes cores nobody was placed on"""
+    root = str(tmp_path)
+    _fake_host(root, [0, 1, 0], cpus_per_node=4)
+    _write(root, "bus/pci/devices/0000:12:00.0/numa_node", "-1\n")
+    _write(root, "devices/system/node/node2/cpulist", "8-11\n")          # cores of a node no GPU reports
+    allowed = list(range(12))
+    got = [topology.rank_cores(r, 3, allowed, root, env={}) for r in range(3)]
+    assert [g[2] for g in got] == ["numa", "numa", "linear"]
+    assert got[0][0] == [0, 1, 2, 3] and got[1][0] == [4, 5, 6, 7] and got[2][0] == [8, 9, 10, 11]

@@ -9,5 +9,4 @@ N=$N1; SEED=$((B+1)); run pair_cap20 HVQM4_AMD_PAIR_CAP=20
 SEED=$((B+2)); run pool_cap24 HVQM4_AMD_POOL_CAP=24
 SEED=$((B+3)); run tpw1 HVQM4_AMD_TILES_PER_WG=1
 SEED=$((B+4)); run tpw2 HVQM4_AMD_TILES_PER_WG=2
-SEED=$((B+5)); run two_pass HVQM4_AMD_TILE_QUEUES=1
 SEED=$((B+6)); run two_queues HVQM4_AMD_QUEUES=2
