@@ -124,6 +124,8 @@ SYMBOLS = {
     "hvq_parser_blob_bound": (C.c_size_t, [C.c_void_p]),
     "hvq_parser_pic_bytes": (C.c_uint32, [C.c_void_p]),
     "hvq_picture_length": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_size_t)]),
+    "hvq_parser_set_threads": (C.c_int, [C.c_void_p, C.c_int]),
+    "hvq_parser_last_flags": (C.c_uint32, [C.c_void_p]),
     "hvq_parse_picture": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                     C.POINTER(C.c_size_t)]),
 }

@@ -50,6 +50,14 @@ void hvq_parser_layout(const HvqParser *p, HvqPicHeader *out);
 int hvq_parse_picture(HvqParser *p, int frame_type, const uint8_t *pic, size_t len,
                       uint8_t *blob, size_t cap, size_t *blob_len);
 
+/* Threads that parse ONE picture of this parser (the caller's included; 1 = the caller alone, the default; at most 8): a picture's
+ * sections are independent bit buffers (h4m:1981-1993, 2030-2044), so block kinds, DC values, vectors and the planes' payloads are
+ * decoded side by side by a small persistent pool.  Same blob byte for byte.  Returns the count in effect. */
+int hvq_parser_set_threads(HvqParser *p, int threads);
+
+/* every HVQ_F_* flag the last hvq_parse_picture raised -- the blob header's, plus what a P/B picture's second pass raised behind it */
+uint32_t hvq_parser_last_flags(const HvqParser *p);
+
 /* the nest of the last I picture this parser has parsed (h4m:1132-1164), nibble-packed as the blobs carry it: `out` = ALIGN16(HVQ_NESTP_BYTES)
  * bytes.  (An I picture's blob contains its nest only when one of its own blocks needs it; later P/B pictures may need it regardless.) */
 void hvq_parser_packed_nest(const HvqParser *p, uint8_t *out);

@@ -689,7 +689,9 @@ HVQ_EXPORT int hvq_stream_submit(HvqContext *c, int sid, int frame_type, const u
     rc = hvq_parse_picture(s.parser, frame_type, pic, len, c->host_arena + off, bound, &blen);
     c->parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc) return fail(rc, "parse failed (%d) for stream %d picture %d", rc, sid, s.npics);
-    if (const char *why = unsupported_reason(((const HvqPicHeader *)(c->host_arena + off))->flags)) {
+    /* the header's flags plus what a P/B picture's second pass raised behind it (an endless overflow run in a block's scalars, a
+     * clamped vector target): refused, never decoded differently */
+    if (const char *why = unsupported_reason(((const HvqPicHeader *)(c->host_arena + off))->flags | hvq_parser_last_flags(s.parser))) {
         s.need_I = true;
         return fail(HVQ_E_UNSUPPORTED, "stream %d picture %d: %s", sid, s.npics, why);
     }
@@ -725,8 +727,8 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
     }
     /* workers parse into private growing buffers (no per-picture allocation), then copy their blobs into the
      * pinned arena in parallel once the layout is known */
-    struct Piece { int worker; size_t off, len; };
-    std::vector<Piece> pieces((size_t)n, Piece{ -1, 0, 0 });
+    struct Piece { int worker; size_t off, len; uint32_t late; };     /* late: flags raised behind the blob header (hvq_parser_last_flags) */
+    std::vector<Piece> pieces((size_t)n, Piece{ -1, 0, 0, 0 });
     std::vector<int> rcs((size_t)n, 0);
     struct RawBuf {                       /* growing byte buffer without value-initialisation */
         uint8_t *p = nullptr; size_t size = 0, cap = 0;
@@ -749,7 +751,7 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
                 size_t blen = 0;
                 rcs[(size_t)i] = hvq_parse_picture(s.parser, frame_types[i], pics[i], lens[i], buf.p + at, bound, &blen);
                 if (rcs[(size_t)i]) break;                 /* later pictures of the stream would see a wrong parser state */
-                pieces[(size_t)i] = Piece{ wid, at, blen };
+                pieces[(size_t)i] = Piece{ wid, at, blen, hvq_parser_last_flags(s.parser) };
                 buf.size = at + blen;
             }
         }
@@ -765,7 +767,7 @@ HVQ_EXPORT int hvq_submit_many(HvqContext *c, int n, const int *streams, const i
             return fail(rcs[(size_t)i] ? rcs[(size_t)i] : HVQ_E_STATE, "parse failed for picture %d (stream %d)", i, streams[i]);
     for (int i = 0; i < n; ++i) {
         const Piece &pc = pieces[(size_t)i];
-        if (const char *why = unsupported_reason(((const HvqPicHeader *)(wbuf[(size_t)pc.worker].p + pc.off))->flags)) {
+        if (const char *why = unsupported_reason(((const HvqPicHeader *)(wbuf[(size_t)pc.worker].p + pc.off))->flags | pc.late)) {
             c->streams[(size_t)streams[i]].need_I = true;
             return fail(HVQ_E_UNSUPPORTED, "picture %d (stream %d): %s; nothing of this call was queued", i, streams[i], why);
         }
@@ -2349,6 +2351,13 @@ bool sdk_open(SdkBinding *b, SeqObj *seq)
         if (sid < 0) { sdk_fail(sid); return false; }
         b->stream = sid; b->is15 = is15;
         b->pic_bytes = hvq_stream_pic_bytes(b->ctx, sid);
+        {   /* One synchronous picture at a time: its sections are parsed side by side by a small pool of the SeqObj's parser (78 % of a
+             * call was the parse on ONE core).  HVQM4_AMD_SDK_PARSE_THREADS (default 4, capped by the cores this process may run on;
+             * 1 = the calling thread alone). */
+            static const int want = getenv("HVQM4_AMD_SDK_PARSE_THREADS") ? atoi(getenv("HVQM4_AMD_SDK_PARSE_THREADS")) : 4;
+            const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+            (void)hvq_parser_set_threads(b->ctx->streams[(size_t)sid].parser, std::max(1, std::min(want, cores)));
+        }
         for (auto &p : b->stage)
             if (!p && hipHostMalloc((void **)&p, b->pic_bytes, hipHostMallocDefault) != hipSuccess) p = nullptr;   /* without staging: plain copies */
         for (int i = 0; i < 3; ++i) b->valid[i] = false;

@@ -166,3 +166,61 @@ def test_a_run_that_never_ends_is_flagged_and_costs_no_time():
         assert struct.unpack_from("<I", blob[:128].tobytes(), 20)[0] & 0x40
     assert time.time() - t0 < 2.0
     l.hvq_parser_destroy(prs)
+
+
+def _blobs(clip, threads, mangle=None):
+    """every picture's blob (bytes), return code and late flags with `threads` threads parsing one picture"""
+    from hvqm4_amd._lib import lib
+    l = lib()
+    prs = l.hvq_parser_create(clip.width, clip.height, clip.samp_h, clip.samp_v, 1 if clip.version == "1.5" else 0)
+    assert prs
+    assert l.hvq_parser_set_threads(prs, threads) == threads
+    bound = l.hvq_parser_blob_bound(prs)
+    blob = np.zeros(bound, dtype=np.uint8)
+    out = []
+    for k, (ft, pic) in enumerate(zip(clip.kinds, clip.pictures)):
+        data = mangle(k, pic) if mangle else pic
+        n = C.c_size_t(0)
+        rc = l.hvq_parse_picture(prs, ft, data + b"\0" * 8, len(data), blob.ctypes.data, bound, C.byref(n))
+        out.append((rc, blob[:n.value].tobytes() if rc == 0 else b"", l.hvq_parser_last_flags(prs)))
+    l.hvq_parser_destroy(prs)
+    return out
+
+
+@pytest.mark.parametrize("case", clips.SMALL + clips.MEDIUM[:2] + clips.REGRESSION, ids=lambda c: c[0])
+def test_sections_parsed_side_by_side_give_the_same_blob(case):
+    """hvq_parser_set_threads: block kinds, DC values, vectors and the planes' payloads are separate bit buffers (h4m:1981-1993,
+    2030-2044) decoded by a small pool -- the blob must not depend on how many threads shared the work (the SDK boundary runs 4)"""
+    clip = clips.get(case)
+    one = _blobs(clip, 1)
+    for threads in (2, 4, 8):
+        assert _blobs(clip, threads) == one, threads
+
+
+def test_threaded_parse_of_corrupted_pictures_stays_in_bounds_and_agrees_on_acceptance():
+    """bit flips behind the section table: every thread count must take or refuse the same pictures (a cap met in one section stops
+    the others at different points, so only the verdict -- return code and refusal flags -- is compared), and none may crash"""
+    clip = clips.get(clips.SMALL[3])
+    rng = np.random.default_rng(11)
+    flips = {k: rng.integers(0x60, max(0x61, len(p)), 24) for k, p in enumerate(clip.pictures)}
+
+    def mangle(k, pic):
+        b = bytearray(pic)
+        for at in flips[k]:
+            b[int(at) % len(b)] ^= 1 << (int(at) % 8)
+        return bytes(b)
+    verdicts = []
+    for threads in (1, 4):
+        verdicts.append([(rc, fl & 0x60) for rc, _b, fl in _blobs(clip, threads, mangle)])
+    assert verdicts[0] == verdicts[1]
+
+
+def test_parser_pool_is_created_and_torn_down_repeatedly():
+    from hvqm4_amd._lib import lib
+    l = lib()
+    for _ in range(20):
+        prs = l.hvq_parser_create(64, 48, 2, 2, 1)
+        assert l.hvq_parser_set_threads(prs, 4) == 4
+        assert l.hvq_parser_set_threads(prs, 1) == 1
+        assert l.hvq_parser_set_threads(prs, 3) == 3
+        l.hvq_parser_destroy(prs)
