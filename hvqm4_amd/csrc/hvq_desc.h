@@ -147,7 +147,8 @@ typedef struct HvqJob {                /* 232 bytes */
     uint32_t mcb_w;
     uint32_t pool_dwords;          /* payload pool size */
     uint32_t total_tiles;          /* 0: picture dropped by the flush, its workgroups exit */
-    uint32_t rsv0[2];              /* (rounds 3-5: list offsets of the two-pass variant; the kernel addresses this record by dword index, the layout stays) */
+    uint32_t tile_first12[2];      /* first tile of planes 1 and 2 (plane 0 starts at tile 0): a copy beside the common part, so that a workgroup knows its plane
+                                      before it has loaded a plane record (the kernel addresses this record by dword index: dwords 18, 19) */
     HvqPlaneRec plane[3];
     uint32_t rsv1[2];
     uint64_t wave_base;            /* blob section: pool offset of every run of 64 blocks (scalar loads of hvq_recon_inline_kernel) */

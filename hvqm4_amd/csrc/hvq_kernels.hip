@@ -276,6 +276,9 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 #ifndef HVQ_PRIO
 #define HVQ_PRIO 0            /* 1: head at issue priority 3 until trip 2 is issued; 2: until the motion-compensation rows are requested */
 #endif
+#ifndef HVQ_PLANE_LOAD
+#define HVQ_PLANE_LOAD 1       /* 1 (round 6): the plane record by a dependent scalar load; 0: all three records + selects (rounds 4-5).  A/B profiles/r06d_plane_load_ab.txt */
+#endif
 #ifndef HVQ_NT_STORES
 #define HVQ_NT_STORES 1        /* B pictures leave with non-temporal stores (0: plain stores; A/B in profiles/r05_recon_steps.txt) */
 #endif
@@ -591,6 +594,33 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
     const u32 slot_id = blockIdx.z * gridDim.x + blockIdx.x;
     const u32 wg = blockIdx.y;
     const HvqJob *__restrict__ J = jobs + slot_id;
+#if HVQ_PLANE_LOAD
+    /* The job record's common part first (with the planes' first tiles, which say which plane this workgroup belongs to), then the ONE
+     * plane record it needs by a dependent scalar load: a scalar round trip more at the head (measured at zero for the kernel arguments,
+     * profiles/r05_recon_steps.txt B) against 16 scalar registers and ~50 scalar instructions of loading all three records and
+     * selecting among them. */
+    const u32 *__restrict__ CW = (const u32 *)J;
+    u32 cw[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) cw[i] = CW[i];
+    u32 wb_lo = CW[46], wb_hi = CW[47], q_offs_off = CW[49];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) HVQ_PIN(cw[i]);
+    HVQ_PIN(wb_lo); HVQ_PIN(wb_hi); HVQ_PIN(q_offs_off);
+    const u32 total_tiles = cw[17];
+    const u32 n0 = cw[18], n1 = cw[19] - cw[18], n2 = total_tiles - cw[19];
+    const u32 pf1 = (n0 + TPW - 1) / TPW, pf2 = pf1 + (n1 + TPW - 1) / TPW, pend = pf2 + (n2 + TPW - 1) / TPW;
+    if (total_tiles == 0 || wg >= pend) return;                              /* picture dropped by the flush */
+    const int p = (wg >= pf1) + (wg >= pf2);
+    const u32 *__restrict__ PW = CW + 20 + 8 * p;
+    u32 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = PW[i];
+    u32 magic = CW[52 + p], magic16 = CW[55 + p];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) HVQ_PIN(w[i]);
+    HVQ_PIN(magic); HVQ_PIN(magic16);
+#else
     const u32 *__restrict__ PW = (const u32 *)&J->plane[0];
     u32 w0[8], w1[8], w2[8];
 #pragma unroll
@@ -616,6 +646,7 @@ void hvq_recon_inline_kernel(const HvqJob *__restrict__ jobs, u32 pair_cap, u32 
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = p == 0 ? w0[i] : p == 1 ? w1[i] : w2[i];
     const u32 magic = p == 0 ? mg0 : p == 1 ? mg1 : mg2, magic16 = p == 0 ? ms0 : p == 1 ? ms1 : ms2;
+#endif
     const u32 hbvb = w[6], pw_sub = w[7], tile_first = w[5];
     const u32 nplane_tiles = p == 0 ? n0 : p == 1 ? n1 : n2;
     const u32 pairw = wg - (p == 0 ? 0u : p == 1 ? pf1 : pf2);

@@ -1730,6 +1730,7 @@ static int flush_end(HvqContext *c)
             const uint32_t ws = k ? hd->wshift : 0, hs = k ? hd->hshift : 0;
             r.hbvb = (uint32_t)hd->hb[k] | ((uint32_t)hd->vb[k] << 16);
             r.pw_sub = (uint32_t)(hd->width >> ws) | (ws << 16) | (hs << 24);
+            if (k) j.tile_first12[k - 1] = hd->tile_first[k];
             j.hb_magic[k] = hd->hb[k] > 1 ? (uint32_t)(0x100000000ull / hd->hb[k]) + 1u : 0u;
             j.hb_magic16[k] = hd->hb[k] ? (65536u + hd->hb[k] - 1u) / hd->hb[k] : 0u;
         }

@@ -13,8 +13,8 @@ for p in $P; do
       python3 - $f.json "$p $name rep $rep" <<'PY' | tee -a $O/summary.txt
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]
-print("%-34s value %8.0f stage %.4f (%.1f us) | recon only %.4f (%.1f us) | queue build %.1f us" % (sys.argv[2], d["value"], r["frac"], r["stage_us_per_step"],
-      r["recon_only"]["frac"], r["recon_only"]["us_per_step"], r["queue_build"]["us_per_step"]))
+print("%-34s value %8.0f joined %.4f (%.1f us) | free-running %.4f (%.1f us)" % (sys.argv[2], d["value"], r["frac"], r["stage_us_per_step_joined"],
+      r["free_running"]["frac"], r["free_running"]["us_per_step"]))
 PY
     done
   done
