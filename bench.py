@@ -46,8 +46,8 @@ GOP16 = "IPBBPBBPBBPBBPBB"
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c5", choices=["c5", "c4"])
     ap.add_argument("--streams", type=int, default=128, help="c5: concurrent streams per GPU")
     ap.add_argument("--width", type=int, default=640)

@@ -1272,12 +1272,13 @@ static int device_parse_finish(HvqContext *c)
             const int ft = p.kind == HVQ_PIC_I ? HVQ_FRAME_I : p.kind == HVQ_PIC_P ? HVQ_FRAME_P : HVQ_FRAME_B;
             const int rcp = hvq_parse_picture(s.parser, ft, c->fl_host + p.blob_off, raw_len, c->rp_host.data() + off, bound, &out_len);
             const HvqPicHeader *hd = (const HvqPicHeader *)(c->rp_host.data() + off);
-            if (rcp == HVQ_OK && !(hd->flags & HVQ_F_CAPPED)) {
-                p.redo = true; p.redo_off = off; p.redo_hd = *hd;
+            const uint32_t all_flags = hd->flags | hvq_parser_last_flags(s.parser);     /* incl. what pass 2 raised behind the header */
+            if (rcp == HVQ_OK && !(all_flags & HVQ_F_CAPPED)) {
+                p.redo = true; p.redo_off = off; p.redo_hd = *hd; p.redo_hd.flags = all_flags;
                 out_len = align_up(out_len, 256);
                 if (p.kind == HVQ_PIC_I) hvq_parser_packed_nest(s.parser, c->rp_host.data() + off + out_len);   /* behind the blob: always, not only when the blob has one */
                 c->rp_host.resize(off + out_len + (p.kind == HVQ_PIC_I ? align_up(GP_ALIGN16(HVQ_NESTP_BYTES), 256) : 0));
-                p.flags = hd->flags; p.pool_dwords = hd->pool_dwords; p.max_items = hd->max_items; p.max_pairs = hd->max_pairs;
+                p.flags = all_flags; p.pool_dwords = hd->pool_dwords; p.max_items = hd->max_items; p.max_pairs = hd->max_pairs;
                 p.blob_len = hd->total_bytes;
                 continue;
             }
