@@ -248,9 +248,12 @@ def main():
     # every synthetic clip of the run is made HERE, before this process opens the GPU: a process pool started later would fork
     # (spawn) from a GPU-initialised parent -- under rocprofv3 every child gets the tool injected (round 4's evidence logs ended
     # in eight "Aborted" blocks from exactly that) -- and this pool is touchy about it
-    c4_share_clips = None
+    c4_share_clips = single_clips = None
     if rank == 0 and world == 1 and not args.no_sdk:
         c4_share_clips = gen_clips(c4_share_configs(), workers, args.clip_cache)
+        single_clips = gen_clips([SynthConfig(width=320, height=240, version="1.5", gop="I", n_gops=64, seed=2, preset=args.preset),
+                                  SynthConfig(width=640, height=480, version="1.5", gop=GOP16, seed=1000, preset=args.preset)],
+                                 workers, args.clip_cache)
     gen_s = time.time() - t0
     pics = [list(video_pictures(c.data)) for c in clips]
 
@@ -762,6 +765,9 @@ def main():
     # and 1.5 alternating), every picture checked against the SHA-256 the REFERENCE decoder produced (tests/golden/manifest.json)
     if rank == 0 and world == 1 and not args.no_sdk:
         out["c4_share"] = c4_share_leg(device, args.steps, args.warmup or 1, threads, c4_share_clips)
+        # BASELINE configs 2 and 3: ONE clip on one GPU (latency-bound by construction: a 16-picture GOP is seven dependent launches)
+        out["single_clip"] = {"C2": single_clip_leg(device, single_clips[0], args.steps, args.warmup or 1, not args.no_verify),
+                              "C3": single_clip_leg(device, single_clips[1], args.steps, args.warmup or 1, not args.no_verify)}
 
     if rank == 0:
         grp.emit(json.dumps(out))
@@ -860,6 +866,62 @@ def c4_share_leg(device, steps, warmup, threads, cl):
                 "pictures_checked_against_reference_sha256": checked,
                 "what": "per-GPU share of BASELINE config 4 at 8 GPUs: clips 0, 8, ..., 56 (4 x 320x240 + 4 x 640x480, HVQM4 1.3 / 1.5), "
                         f"one 16-picture GOP each per step, descriptors resident; 128 pictures in {int(st.launches)} launches"}
+    except Exception as e:
+        return {"error": str(e)}
+
+
+def single_clip_leg(device, clip, steps, warmup, verify):
+    """ONE clip through the batched API on one GPU (BASELINE configs 2 and 3): the reconstruction stage over resident descriptors
+    (roofline fraction), and bitstreams in host memory -> pictures in HBM with the host parser and with the GPU parser; every picture
+    against the CPU oracle."""
+    try:
+        import numpy as np
+        from hvqm4_amd import batch
+        from hvqm4_amd.container import video_pictures
+        seq = [(ft, bytes(p)) for ft, _d, p in video_pictures(clip.data)]
+        n = len(seq)
+        px = clip.width * clip.height * n
+        ctx = batch.Context(device)
+        res = {}
+        for name in ("host_parse", "gpu_parse"):
+            best = None
+            for rep in range(3):                                   # first pass sizes the buffers
+                sid = ctx.open_stream(clip.width, clip.height, 2, 2, clip.version == "1.5", n + 3)
+                ctx.sync()
+                t0 = time.perf_counter()
+                if name == "host_parse":
+                    ctx.set_parse_threads(sid, 4)                  # a lone stream: the sections of a picture side by side
+                    for ft, p in seq:                              # ... its pictures one after the other
+                        ctx.submit(sid, ft, p)
+                else:
+                    ctx.submit_many_device([sid] * n, [ft for ft, _p in seq], [p for _ft, p in seq])
+                ctx.flush(); ctx.sync()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+                if rep < 2:
+                    ctx.close_stream(sid)
+            res[name] = (best, sid)
+        sid = res["gpu_parse"][1]
+        checked = 0
+        if verify:
+            from oracle import bridge
+            want = bridge.oracle_decode(clip.data, n)
+            for k in range(n):
+                if not np.array_equal(ctx.read_picture(sid, k), want[k]):
+                    raise SystemExit(f"PARITY FAILURE (single clip {clip.width}x{clip.height}): picture {k} differs from the oracle")
+                checked += 1
+        st = ctx.stats()
+        ctx.replay_stage(warmup, 1)
+        ms = ctx.replay_stage(steps, 1)
+        ctx.close()
+        return {"value": round(px * steps / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+                "frac_of_roofline": round(st.algorithmic_bytes * steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "us_per_step": round(ms * 1e3 / steps, 2), "pictures_per_step": int(st.pictures), "launches_per_step": int(st.launches),
+                "end_to_end_host_parse": round(px / res["host_parse"][0] / 1e6, 1), "end_to_end_gpu_parse": round(px / res["gpu_parse"][0] / 1e6, 1),
+                "pictures_checked": checked,
+                "what": f"one {clip.width}x{clip.height} HVQM4 {clip.version} clip, {n} pictures ({''.join(sorted(set('IPB'[(ft >> 4) - 1] for ft, _p in seq)))}), one flush: "
+                        "value = reconstruction stage over resident descriptors; end_to_end_* = bitstreams in host memory -> pictures in HBM "
+                        "(submit + flush + sync, best of 3; host parse: hvq_stream_submit per picture, four threads sharing a picture's sections)"}
     except Exception as e:
         return {"error": str(e)}
 

@@ -108,6 +108,7 @@ SYMBOLS = {
     "hvq_rgb_bench": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "hvq_convert_yuv420_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hvq_read_pictures": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "hvq_stream_set_parse_threads": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "hvq_h2d_probe": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "hvq_pinned_alloc": (C.c_void_p, [C.c_size_t]),
     "hvq_pinned_free": (None, [C.c_void_p]),

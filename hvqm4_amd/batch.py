@@ -26,6 +26,10 @@ class Context:
     def close_stream(self, sid: int) -> None:
         check(lib().hvq_stream_close(self._h, sid))
 
+    def set_parse_threads(self, sid: int, threads: int) -> int:
+        """host threads that share the parse of ONE picture of this stream (hvq_stream_set_parse_threads); returns the count in effect"""
+        return check(lib().hvq_stream_set_parse_threads(self._h, sid, threads))
+
     def submit(self, sid: int, frame_type: int, picture: bytes) -> int:
         return check(lib().hvq_stream_submit(self._h, sid, frame_type, picture, len(picture)))
 

@@ -565,6 +565,15 @@ HVQ_EXPORT int hvq_stream_open(HvqContext *c, int width, int height, int h_samp,
     return (int)c->streams.size() - 1;
 }
 
+/* Host threads that share the parse of ONE picture of this stream (hvq_parser_set_threads: the picture's sections side by side; 1 = the
+ * submitting thread alone, the default).  For callers that decode few streams (a lone clip: hvq_stream_submit parses its pictures one after
+ * the other; hvq_submit_many parses streams side by side and leaves a stream's pictures to one thread).  Returns the count in effect. */
+HVQ_EXPORT int hvq_stream_set_parse_threads(HvqContext *c, int sid, int threads)
+{
+    if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);
+    return hvq_parser_set_threads(c->streams[(size_t)sid].parser, threads);
+}
+
 HVQ_EXPORT int hvq_stream_close(HvqContext *c, int sid)
 {
     if (!c || sid < 0 || sid >= (int)c->streams.size() || !c->streams[sid].open) return fail(HVQ_E_ARG, "bad stream %d", sid);

@@ -76,6 +76,11 @@ void hvq_context_destroy(HvqContext *ctx);
  * reference rotates exactly 3, h4m:2340-2350; more slots let later pictures start earlier). */
 int  hvq_stream_open(HvqContext *ctx, int width, int height, int h_samp, int v_samp, int is_1_5, int nslots);
 int  hvq_stream_close(HvqContext *ctx, int stream);
+/* Host threads that share the entropy parse of ONE picture of this stream (its sections are independent bit buffers, h4m:1981-1993,
+ * 2030-2044; same blob byte for byte): 1 (default) .. 8.  For callers with few streams -- hvq_stream_submit parses a stream's pictures one
+ * after the other, hvq_submit_many parses STREAMS side by side.  The SDK entry points set 4 (HVQM4_AMD_SDK_PARSE_THREADS).  Returns the
+ * count in effect. */
+int  hvq_stream_set_parse_threads(HvqContext *ctx, int stream, int threads);
 /* Host only: bytes of the picture ring hvq_stream_open would allocate ((nslots + 1) slots; 0: geometry refused).  The kernels
  * address reference pictures as ring base + 32-bit offset, so hvq_stream_open fails with HVQ_E_OVERFLOW from 4 GiB on. */
 uint64_t hvq_stream_ring_bytes(int width, int height, int h_samp, int v_samp, int nslots);

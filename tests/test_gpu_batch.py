@@ -271,3 +271,22 @@ def test_failed_bitstream_upload_drops_the_batch_and_the_stream_recovers(defer, 
     for i, o in enumerate(ords):
         assert np.array_equal(ctx.read_picture(sid, o), want[i]), (o, i)
     ctx.close()
+
+
+def test_lone_stream_parsed_by_four_threads_per_picture(gpu_ctx):
+    """hvq_stream_set_parse_threads: the sections of ONE picture parsed side by side (what the SDK entry points do by default), through
+    the batched API: same pictures as the oracle, and switching the count between pictures of a stream changes nothing"""
+    from oracle import bridge
+    for case in (clips.MEDIUM[1], clips.SMALL[17], clips.SMALL[9]):           # 640x480 IPBBPBB, 4:4:4, odd kinds 1.3
+        cl = clips.get(case)
+        want = bridge.oracle_decode(cl.data, cl.n_pictures)
+        sid, pics = _submit_all(gpu_ctx, cl)
+        assert gpu_ctx.set_parse_threads(sid, 4) == 4
+        for k, (ft, _d, pic) in enumerate(pics):
+            if k == len(pics) // 2:
+                assert gpu_ctx.set_parse_threads(sid, 2) == 2
+            gpu_ctx.submit(sid, ft, pic)
+        gpu_ctx.flush()
+        for i in range(len(pics)):
+            assert np.array_equal(gpu_ctx.read_picture(sid, i), want[i]), (case[0], i)
+        gpu_ctx.close_stream(sid)
