@@ -24,6 +24,10 @@ Extra objects on the JSON line:
                 (profiles/*_pmc_traffic.json), calibrated as MI355X_MICROARCH.md prescribes
   cpu_baseline  the reference decoder (oracle/_ref, kind "reference") or this repo's scalar restatement (kind "port")
                 on the host cores: one core on C1, C2, C3 and one process per clip over all cores on a C4 sample
+Side legs (rank 0 at N=1; never `value`): end_to_end_gpu_parse (bitstreams in host memory -> pictures, streaming; h2d_GBs, h2d_probe_GBs and
+pcie_bound_Mpixels say what PCIe allows at this stream density), end_to_end (host parse), sdk_path (the seven SDK calls, PCIe both ways),
+c4_share (one GPU's share of config 4 against the reference's SHA-256), single_clip (configs 2 and 3: one clip alone), c5_staggered,
+rgb_epilogue.  `--gpus N --dry-run` runs everything a multi-rank run does around the GPU work, on the CPU.
 """
 from __future__ import annotations
 
