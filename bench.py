@@ -172,6 +172,14 @@ def host_cores() -> int:
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
+def usable_cores() -> int:
+    """cores this process can actually keep busy: its affinity mask, capped by the cgroup's CPU quota (a 1-GPU box shows all of the host's
+    logical CPUs but grants a share of them: 64 busy threads on a 16-core quota spend three quarters of every period throttled)"""
+    q = cpu_quota()
+    n = host_cores()
+    return max(1, min(n, int(q + 0.5))) if q else n
+
+
 def cpu_quota():
     """CPU limit of this container's cgroup in cores (cgroup v2 cpu.max), None when unlimited or unknown"""
     try:
@@ -230,7 +238,7 @@ def main():
     mv_bits = tuple(int(x) for x in args.mv_bits.split(","))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     copy_threads, my_cores, my_node, pin_how = pin_rank(local_rank % max(1, local_world), local_world)
-    workers = args.gen_workers or max(1, host_cores())          # after pin_rank: the cores of this rank's slice
+    workers = args.gen_workers or usable_cores()                # after pin_rank: the cores of this rank's slice, capped by the cgroup quota
 
     # ---- synthetic inputs (fixed seeds) ----
     t0 = time.time()
@@ -276,7 +284,7 @@ def main():
     # decode-order interleave: picture k of every stream, then k+1 ... (the order a player would submit).
     # This first pass is also the END-TO-END measurement with the host parser: entropy parse (thread pool) +
     # descriptor upload + all launches, from bitstreams in host memory to pictures in HBM.
-    threads = max(1, min(args.parse_threads or host_cores(), 64))
+    threads = max(1, min(args.parse_threads or usable_cores(), 64))
     a_sid, a_ft, a_pic, a_stream = [], [], [], []
     for k in range(max(len(p) for p in pics)):
         for s, sid in enumerate(sids):
@@ -1047,9 +1055,9 @@ def cpu_baseline(budget_s: float, c3_clip, preset: str):
     # per clip over min(nproc, 64) processes.  nproc = cores this process may run on; the container's CPU quota (cgroup cpu.max)
     # is reported beside it -- the box gives a 1-GPU job a share of the host, so "all cores" is that share, not the host's 256.
     cores = host_cores()
-    nproc = min(cores, 64)
+    nproc = min(usable_cores(), 64)
     cfgs = [c4_clip_config(i, preset, 1) for i in range(64)]
-    sample = gen_clips(cfgs, cores)
+    sample = gen_clips(cfgs, usable_cores())
     t1, _ = timer(sample[-1].data, 1)                    # a 640x480 clip, the slow kind
     waves = (64 + nproc - 1) // nproc
     reps = max(1, int(2.0 * per / max(t1 * waves, 1e-6)))
