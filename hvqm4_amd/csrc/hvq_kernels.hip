@@ -535,7 +535,7 @@ __device__ __forceinline__ void window_finish(const uint64_t q[4], bool x2, u32 
  *     with a bounds test per entry;
  *   - phase C re-derives its rows' coordinates the same way.
  *
- *   trip 1  the picture's job record (scalar)
+ *   trip 1  the picture's job record (scalar): its common part, then -- round 6 -- the workgroup's ONE plane record by a dependent load
  *   trip 2  per block: map entry with both horizontal neighbours (one unaligned 8-byte load), the vertical neighbours, the
  *           macroblock vector; per wave: its pool offset (wave_base); by LDS-DMA the nest and the tile's range of the payload pool
  *   then    class, block operands (MC source offset with the version's half-sample rule h4m:1327-1355, weighted-DC neighbours
@@ -1164,7 +1164,10 @@ extern "C" uint32_t hvq_recon_inline_static_lds(uint32_t tiles_per_wg, uint32_t 
     return (uint32_t)(HVQ_NESTP_BYTES + 8 + 15) / 16u * 16u + tiles_per_wg * 4u * HVQ_WG * 4u + 64u * items_cap + 12u * items_cap + 16u;
 }
 
-/* as hvq_launch_recon, for pictures without tile queues; pair_cap / pool_cap: dwords of dynamic LDS for the pair list and the staged pool */
+/* One launch = one dependency level (of one launch queue).  jobs_dev: the launch's picture slots, one job each (count a multiple of 8 when
+ * there are at least 8 pictures; padding: total_tiles 0); tiles_per_wg: 1 or 2; max_wgs: the most workgroups of any picture of the launch
+ * at that setting; items_cap: the most items of any workgroup of the launch (it selects the instantiation with the next larger accumulator
+ * array); pair_cap / pool_cap: dwords of dynamic LDS for the pair list and the staged pool */
 extern "C" hipError_t hvq_launch_recon_inline(const HvqJob *jobs_dev, uint32_t nslots, uint32_t max_wgs, uint32_t tiles_per_wg,
                                               uint32_t items_cap, uint32_t pair_cap, uint32_t pool_cap, hipStream_t stream)
 {
