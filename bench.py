@@ -300,6 +300,25 @@ def main():
     ctx.sync()
     t_e2e = time.perf_counter() - t0
     st = ctx.stats()
+    # ... and once more in steady state (a context of its own, second pass: the pinned arenas and the workers' buffers are sized by then --
+    # the first pass above pays for a few hundred MB of pinned allocation)
+    e2e_steady = None
+    if rank == 0 and world == 1 and not args.no_sdk:
+        ctxh = batch.Context(device)
+        sidh = [ctxh.open_stream(clips[ci].width, clips[ci].height, 2, 2, clips[ci].version == "1.5", args.nslots) for ci in stream_clip]
+        a_sidh = [sidh[s] for s in a_stream]
+        best = None
+        for rep in range(3):
+            ctxh.sync()
+            th0 = time.perf_counter()
+            ctxh.submit_many(a_sidh, a_ft, a_pic, threads)
+            th1 = time.perf_counter()
+            ctxh.flush(); ctxh.sync()
+            th2 = time.perf_counter()
+            if rep and (best is None or th2 - th0 < best[0]):
+                best = (th2 - th0, th1 - th0)
+        ctxh.close()
+        e2e_steady = best
 
     # ---- parity check against the CPU oracle on what is still resident ----
     # every stream keeps its last min(nslots, pictures) pictures; the first `distinct` streams (c4: every 4th clip) are checked
@@ -693,7 +712,11 @@ def main():
         "end_to_end_gpu_parse": gpu_e2e,
         "end_to_end": {"value": round(px_step / t_e2e / 1e6, 1), "unit": "Mpixels/s", "parse_threads": threads,
                        "parse_only_mpix_s": round(px_step / t_parse / 1e6, 1),
-                       "what": "rank 0, first pass: host entropy parse + descriptor H2D + kernels, bitstreams in host memory -> pictures in HBM"},
+                       "steady_value": round(px_step / e2e_steady[0] / 1e6, 1) if e2e_steady else None,
+                       "steady_parse_only_mpix_s": round(px_step / e2e_steady[1] / 1e6, 1) if e2e_steady else None,
+                       "what": "rank 0: host entropy parse (pictures side by side on `parse_threads` threads) + descriptor H2D + kernels, bitstreams in "
+                               "host memory -> pictures in HBM.  value: the first pass of a fresh context (pays for the pinned arenas); "
+                               "steady_value: best of the second and third pass of a context of its own"},
         "verified_pictures": verified, "verified_pictures_expected": expected,
         "flags_or": int(st.flags_or),
     }
