@@ -177,7 +177,10 @@ def usable_cores() -> int:
     logical CPUs but grants a share of them: 64 busy threads on a 16-core quota spend three quarters of every period throttled)"""
     q = cpu_quota()
     n = host_cores()
-    return max(1, min(n, int(q + 0.5))) if q else n
+    if not q:
+        return n
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))     # the quota is the whole job's: the ranks share it
+    return max(1, min(n, int(q / ranks + 0.5)))
 
 
 def cpu_quota():
