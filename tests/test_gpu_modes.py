@@ -11,6 +11,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# tests of the device PARSER alone (17 s of crafted prefix trees): the reconstruction modes below do not touch what they exercise, and they
+# run once in the main suite and once more with the chains-only parser
+NOT_PARSER_ONLY = "not pathological_trees"
 
 
 @pytest.mark.parametrize("tiles", ["1", "2"])
@@ -18,7 +21,7 @@ def test_parity_suites_with_forced_tiles_per_workgroup(tiles):
     env = dict(os.environ, HVQM4_AMD_TILES_PER_WG=tiles)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                         "tests/test_gpu_parity.py", "tests/test_gpu_batch.py", "tests/test_gpu_gparse.py", "tests/test_gpu_configs.py",
-                        "tests/test_gpu_reject.py"],
+                        "tests/test_gpu_reject.py", "-k", NOT_PARSER_ONLY],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert " passed" in r.stdout
@@ -32,7 +35,7 @@ def test_parity_suites_with_tiles_beyond_the_pair_list(cap):
     takes that path, at 200 the two kinds of tile meet inside one workgroup."""
     env = dict(os.environ, HVQM4_AMD_PAIR_CAP=cap)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
-                        "tests/test_gpu_parity.py", "tests/test_gpu_gparse.py"],
+                        "tests/test_gpu_parity.py", "tests/test_gpu_gparse.py", "-k", NOT_PARSER_ONLY],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert " passed" in r.stdout
@@ -44,7 +47,7 @@ def test_parity_suites_with_tiles_beyond_the_staged_pool(cap):
     reads the rest from HBM.  With the share capped at 40 dwords most tiles of the parity clips mix both, at 0 nothing is staged."""
     env = dict(os.environ, HVQM4_AMD_POOL_CAP=cap)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
-                        "tests/test_gpu_parity.py", "tests/test_gpu_gparse.py"],
+                        "tests/test_gpu_parity.py", "tests/test_gpu_gparse.py", "-k", NOT_PARSER_ONLY],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert " passed" in r.stdout
