@@ -129,10 +129,10 @@ def test_corrupted_streams_do_not_fault_the_gpu_parser(gpu_ctx):
     test_nest_of_the_last_I_picture_survives_flushes(gpu_ctx, 2)
 
 
-@pytest.mark.parametrize("w,h,samp", [(1920, 1088, "420"), (2048, 8, "420"), (8, 2048, "420"), (1024, 16, "444"), (720, 576, "444"), (720, 576, "422"), (8, 1024, "422")])
+@pytest.mark.parametrize("w,h,samp", [(1920, 1088, "420"), (4096, 2176, "420"), (8192, 8, "420"), (8, 8192, "420"), (8192, 16, "444"), (2048, 8, "420"), (8, 2048, "420"), (1024, 16, "444"), (720, 576, "444"), (720, 576, "422"), (8, 1024, "422")])
 def test_large_and_extreme_geometries(gpu_ctx, w, h, samp):
-    """full-HD, one-macroblock-high strips (longest DC row buffer, ragged last tiles) and wide 4:4:4, through both
-    parsers; the oracle is the checker"""
+    """full-HD, 4K (557 056 luma blocks: 2 176 tiles, plane offsets beyond 8 MB), one-macroblock-high strips (longest DC row buffer, ragged
+    last tiles) and wide 4:4:4, through both parsers; the oracle is the checker"""
     from hvqm4_amd import batch
     from hvqm4_amd.synth import SynthConfig, make_clip
     from oracle import bridge

@@ -11,9 +11,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# tests of the device PARSER alone (17 s of crafted prefix trees): the reconstruction modes below do not touch what they exercise, and they
-# run once in the main suite and once more with the chains-only parser
-NOT_PARSER_ONLY = "not pathological_trees"
+# tests of the device PARSER alone (17 s of crafted prefix trees) and the 4K clip (11 s of clip generation): the reconstruction modes below
+# do not touch what the former exercise, the latter runs in the main suite
+NOT_PARSER_ONLY = "not pathological_trees and not 4096-2176"
 
 
 @pytest.mark.parametrize("tiles", ["1", "2"])

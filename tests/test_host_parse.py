@@ -224,3 +224,15 @@ def test_parser_pool_is_created_and_torn_down_repeatedly():
         assert l.hvq_parser_set_threads(prs, 1) == 1
         assert l.hvq_parser_set_threads(prs, 3) == 3
         l.hvq_parser_destroy(prs)
+
+
+def test_4k_pictures_through_parse_and_descriptor_spec():
+    """4096x2176: 1024 x 544 luma blocks -- the geometry fields, plane offsets and pool offsets far beyond the catalogue's sizes"""
+    from hvqm4_amd.synth import SynthConfig, make_clip
+    from oracle import bridge
+    clip = make_clip(SynthConfig(width=4096, height=2176, gop="IP", seed=4096 + 2176, runoff_prob=0.2))
+    want = bridge.oracle_decode(clip.data, clip.n_pictures)
+    got, flags = decode_via_descriptors(clip)
+    assert np.array_equal(got, want)
+    assert not flags & 0x60
+    assert _blobs(clip, 4) == _blobs(clip, 1)
