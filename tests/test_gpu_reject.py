@@ -259,3 +259,41 @@ def test_an_overflow_run_beyond_the_fast_cap_is_decoded_like_the_reference_by_ev
         got = np.stack([pl.decode(ft, p) for ft, p in _pics(clip)])
         pl.close()
         assert np.array_equal(got, want), "SDK symbols"
+
+
+def test_host_reparses_of_capped_pictures_are_bounded_per_batch(gpu_ctx):
+    """A GPU-parsed picture that comes back capped (an overflow run beyond 4096 symbols) is parsed again on the host inside the flush -- serially,
+    on the caller's thread.  At most 32 such pictures per batch (round 6): a crafted batch whose pictures are ALL capped must not turn a flush
+    of milliseconds into seconds for every stream in it.  40 streams, each with one capped P picture: 32 are decoded like the oracle, 8 are
+    refused (HVQ_E_UNSUPPORTED, dropped), and nothing else of the batch is touched."""
+    from hvqm4_amd._lib import HVQ_E_STATE, HvqError
+    from oracle import bridge
+    clip = _long_run_clip(seed=12, gop="IP")
+    want = bridge.oracle_decode(clip.data, clip.n_pictures)
+    pics = _pics(clip)
+    n = 40
+    sids = [gpu_ctx.open_stream(clip.width, clip.height, 2, 2, clip.version == "1.5", 4) for _ in range(n)]
+    s_, f_, d_ = [], [], []
+    for k in range(2):
+        for sid in sids:
+            s_.append(sid); f_.append(pics[k][0]); d_.append(pics[k][1])
+    gpu_ctx.submit_many_device(s_, f_, d_)
+    with pytest.raises(HvqError) as e:
+        gpu_ctx.flush()
+    assert e.value.code == -8                                   # HVQ_E_UNSUPPORTED: the first picture beyond the bound
+    gpu_ctx.sync()
+    assert gpu_ctx.stats().dropped == 8
+    decoded = refused = 0
+    for sid in sids:
+        assert np.array_equal(gpu_ctx.read_picture(sid, 0), want[0])          # every I picture is there
+        try:
+            got = gpu_ctx.read_picture(sid, 1)
+        except HvqError as err:
+            assert err.code == HVQ_E_STATE
+            refused += 1
+            continue
+        assert np.array_equal(got, want[1])
+        decoded += 1
+    assert (decoded, refused) == (32, 8)
+    for sid in sids:
+        gpu_ctx.close_stream(sid)
