@@ -221,6 +221,9 @@ def test_deferred_and_zero_copy_submits_decode_the_same_pictures():
     with pytest.raises(HvqError) as e:               # beyond the reservation
         ctx.submit_many_arena([sid] * n, fts, [o + at for o in offs], [len(p) for _ft, p in pics])
     assert e.value.code == HVQ_E_ARG
+    with pytest.raises(HvqError) as e:               # a length whose padded span would wrap size_t (advisor, round 5): refused before any arithmetic on it
+        ctx.submit_many_arena([sid] * n, fts, offs, [2 ** 64 - 16] + [len(p) for _ft, p in pics[1:]])
+    assert e.value.code == HVQ_E_ARG
     o2 = ctx.submit_many_arena([sid] * n, fts, offs, [len(p) for _ft, p in pics])
     with pytest.raises(HvqError) as e:               # the reservation is spent
         ctx.submit_many_arena([sid] * n, fts, offs, [len(p) for _ft, p in pics])
