@@ -282,9 +282,6 @@ __device__ __forceinline__ void block_coords(u32 b, i32 hb, float rhb, i32 &bx, 
 #ifndef HVQ_NT_STORES
 #define HVQ_NT_STORES 1        /* B pictures leave with non-temporal stores (0: plain stores; A/B in profiles/r05_recon_steps.txt) */
 #endif
-#ifndef HVQ_BARRIER1_EARLY
-#define HVQ_BARRIER1_EARLY 1     /* 0: barrier 1 behind phase A instead of in front of the second round trip (r03s: dense -7 %, flat -5 %, natural +3 %) */
-#endif
 
 /* Diagnostic build only (-DHVQ_STAMPS, tools/variant.sh): s_memtime stamps of wave phases into a buffer of their own
  * (64 x u64 per workgroup: [wave][16]); the shipped kernel executes no stamp.  VM = also wait for the wave's
